@@ -1,0 +1,174 @@
+/*
+ * monoloco_hip.h -- C ABI of the MI355X (gfx950) implementation of monoloco's
+ * keypoint -> 3D inference hot path.
+ *
+ * The reference (vita-epfl/monoloco) has no FFI: its boundary is the Python API
+ * of monoloco/network/{net,process}.py and monoloco/utils/camera.py.  Every entry
+ * point below names the reference interface it stands in for (file:line in the
+ * reference checkout).  Signatures carry only plain pointers and sizes -- no torch
+ * types -- so any host language can bind them (INTEGRATION.md shows the ctypes
+ * binding the Python host side uses).
+ *
+ * Conventions
+ *   - every function returns 0 (ML_OK) or a positive ML_ERR_* code; no exceptions
+ *     cross the ABI; ml_last_error() returns a thread-local message.
+ *   - "dev" pointers are HIP device pointers on the device that was current when the
+ *     model was finalized; "host" pointers are ordinary host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All hot
+ *     calls are asynchronous on that stream and make no allocation once
+ *     ml_loco_reserve() has been called with a large enough row count.
+ *   - a model handle is thread-compatible: use one handle per stream/thread.
+ *   - keypoints are the reference layout (m, 3, 17) fp32, rows u, v, confidence
+ *     (monoloco/network/process.py:210-218).
+ */
+#ifndef MONOLOCO_HIP_H
+#define MONOLOCO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ML_OK 0
+#define ML_ERR_ARG 1    /* bad argument (null pointer, size mismatch, unknown key) */
+#define ML_ERR_HIP 2    /* a HIP runtime call failed; see ml_last_error()           */
+#define ML_ERR_STATE 3  /* call order violated (e.g. forward before finalize)       */
+#define ML_ERR_SHAPE 4  /* unsupported model shape                                  */
+
+/* Arithmetic of the dense layers (the MFMA kernels).
+ *   ML_PREC_F16X2 : operands split into fp16 hi+lo, 3 MFMA products per term, fp32
+ *                   accumulate -- fp32-class accuracy (the default; meets 1e-4 abs).
+ *   ML_PREC_F16   : plain fp16 operands, 1 MFMA per term (fast, ~1e-2 abs deviation). */
+#define ML_PREC_F16X2 0
+#define ML_PREC_F16 1
+
+/* flags for ml_loco_finalize */
+#define ML_FLAG_MERGE_W2W3 1 /* pre-multiply w3*w2 and w_aux*w2 on the host in fp64
+                                (no non-linearity between them, architectures.py:59-63) */
+#define ML_FLAG_HOST_ONLY 256 /* test hook: fold + pack on the host, upload nothing (no GPU
+                                 needed); such a model cannot run, only be inspected */
+
+/* layout of the packed per-person result written by ml_extract_outputs / ml_loco_forward_* */
+#define ML_OUT_STRIDE 16
+#define ML_OUT_X 0        /* xyzd[:,0]  d*sin(psi)*cos(theta)   process.py:263, camera.py:231-233 */
+#define ML_OUT_Y 1        /* xyzd[:,1]  d*cos(psi)              camera.py:235-237                 */
+#define ML_OUT_Z 2        /* xyzd[:,2]  sqrt(d^2-x^2-y^2)       process.py:265 (NaN if negative)  */
+#define ML_OUT_D 3        /* d                                   process.py:264                    */
+#define ML_OUT_BI 4       /* bi = exp(s)*d                       process.py:125-133                */
+#define ML_OUT_YAW 5      /* atan2(ori0, ori1)                   process.py:272                    */
+#define ML_OUT_YAW_EGO 6  /* yaw + atan2(x,z), wrapped once      camera.py:202-208                 */
+#define ML_OUT_AUX 7      /* sigmoid(aux logit) (stereo) / raw aux-head value (mono) process.py:276 */
+#define ML_OUT_H 8
+#define ML_OUT_W 9
+#define ML_OUT_L 10
+#define ML_OUT_CONF 11    /* 0.035*box_conf/(bi/|xyz_pred|)      net.py:215 (0 if no box_conf)     */
+#define ML_OUT_ORI0 12
+#define ML_OUT_ORI1 13
+#define ML_OUT_UC 14      /* centre pixel u,v  ((max-min)/2+min) camera.py:83-86                   */
+#define ML_OUT_VC 15
+/* the parity tensor (m,5): back-projected x,y,z (net.py:198,213), d, sigma=bi */
+#define ML_XYZDS_STRIDE 5
+
+typedef struct ml_loco ml_loco; /* opaque model + workspace handle */
+
+/* ---- library ---------------------------------------------------------------------- */
+int ml_version(void);
+const char* ml_last_error(void);
+/* Number of HIP devices visible, or a negative ML_ERR code. */
+int ml_device_count(void);
+
+/* ---- model lifetime: stands in for Loco.__init__ (monoloco/network/net.py:30-81) --- */
+/* Shape of LocoModel (monoloco/network/architectures.py:8-46): in_features 34 (mono) or
+ * 68 (stereo), hidden a multiple of 256, out_features 9 or 10 (includes the auxiliary
+ * head, architectures.py:70), num_stage residual stages. */
+int ml_loco_create(int in_features, int hidden, int out_features, int num_stage, ml_loco** out);
+/* Feed one tensor of the reference state_dict by its key (e.g. "linear_stages.0.w1.weight",
+ * "batch_norm3.running_var"; net.py:77 loads exactly these).  `data` is host fp32, row-major,
+ * `numel` must match.  "*.num_batches_tracked" keys are accepted and ignored. */
+int ml_loco_set_tensor(ml_loco* h, const char* key, const float* host_data, int64_t numel);
+/* Fold eval-mode BatchNorm (eps 1e-5) into the Linear layers, optionally merge w3*w2,
+ * scale/split/pack the weights for the MFMA kernels and upload them to the current device. */
+int ml_loco_finalize(ml_loco* h, int precision, int flags);
+/* Pre-allocate activation workspace for up to max_rows network rows (persons, or
+ * left*right pairs for stereo).  Hot calls with more rows grow it (a hidden allocation). */
+int ml_loco_reserve(ml_loco* h, int64_t max_rows);
+int ml_loco_destroy(ml_loco* h);
+/* Introspection: bytes of device memory held, and the per-layer power-of-two weight scale. */
+int64_t ml_loco_device_bytes(const ml_loco* h);
+
+/* ---- stand-alone geometry kernels ------------------------------------------------- */
+/* preprocess_monoloco (process.py:47-67) = pixel_to_camera(kps[:,0:2,:], K, z_met)
+ * (camera.py:10-29) reshaped to (m,34) interleaved x0,y0,x1,y1,...  `kinv_host` is
+ * inverse(K) row-major (9 floats; the host computes it as the reference does, with
+ * torch.inverse).  x_dev (m,34) and/or centre_dev (m,2: get_keypoints(..,'center'),
+ * camera.py:82-86) may be NULL. */
+int ml_preprocess_mono(const float* kps_dev, int64_t m, const float* kinv_host, float z_met,
+                       float* x_dev, float* centre_dev, void* stream);
+/* preprocess_monstereo (process.py:25-44): all-vs-all rows [L_i, L_i - R_j], i-major;
+ * xl_dev (ml,34), xr_dev (mr,34) -> rows_dev (ml*mr, 68). */
+int ml_stereo_pairs(const float* xl_dev, int64_t ml, const float* xr_dev, int64_t mr,
+                    float* rows_dev, void* stream);
+/* extract_outputs (process.py:231-278) + the per-person geometry of Loco.post_process
+ * (net.py:195-215).  raw_dev (m, out_features); row_index_dev (m) optional int32 gather
+ * into raw (stereo: the selected pair row), NULL = identity; centre_dev (m,2) pixel centres
+ * or NULL (then xyz_pred/conf/uc/vc are 0); box_conf_dev (m) or NULL.  Writes out_dev
+ * (m, ML_OUT_STRIDE) and, if not NULL, xyzds_dev (m,5). */
+int ml_extract_outputs(const float* raw_dev, int out_features, const int32_t* row_index_dev,
+                       int64_t m, const float* centre_dev, const float* kinv_host,
+                       const float* box_conf_dev, float* out_dev, float* xyzds_dev, void* stream);
+
+/* ---- the MLP: stands in for LocoModel.forward (architectures.py:48-71) ------------- */
+/* x_dev (m, in_features) fp32 -> raw_dev (m, out_features) fp32 (aux head last). */
+int ml_loco_forward_raw(ml_loco* h, const float* x_dev, int64_t m, float* raw_dev, void* stream);
+
+/* ---- fused device pipelines: stand in for Loco.forward + post_process geometry ----- */
+/* mono (net.py:106-110,195-215): kps_dev (m,3,17) -> out_dev (m,16), xyzds_dev (m,5) or NULL,
+ * raw_dev (m,out_features) or NULL.  box_conf_dev (m) or NULL. */
+int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host,
+                         const float* box_conf_dev, float* raw_dev, float* out_dev,
+                         float* xyzds_dev, void* stream);
+/* stereo (net.py:112-122, process.py:307-327): all left x right pairs, per-left arg-max of the
+ * aux logit.  best_dev (ml) int32 receives the first arg-max right index; ties_dev (1) int32
+ * receives the number of left persons with more than one maximal pair (the reference keeps
+ * all tied rows; the host side re-does those rare cases from raw_all_dev).  raw_all_dev
+ * (ml*mr, out_features) may be NULL. */
+int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const float* kps_r_dev,
+                           int64_t mr, const float* kinv_host, const float* box_conf_dev,
+                           float* raw_all_dev, float* out_dev, float* xyzds_dev,
+                           int32_t* best_dev, int32_t* ties_dev, void* stream);
+
+/* ---- measurement: per-launch timing of the dense (MFMA) kernel ----------------------- */
+/* After ml_loco_profile_begin, every dense-kernel launch made through this handle is bracketed by
+ * a pair of HIP events recorded on the launch stream (up to max_launches launches).
+ * ml_loco_profile_end stops recording, waits for the events and returns the number of recorded
+ * launches, their summed duration, and per-dense-layer sums/counts (arrays of n_layers, may be
+ * NULL).  bench.py uses this for the live roofline figure. */
+int ml_loco_profile_begin(ml_loco* h, int max_launches);
+int ml_loco_profile_end(ml_loco* h, int64_t* launches, double* total_ms, double* per_layer_ms,
+                        int64_t* per_layer_n, int n_layers);
+
+/* ---- test hooks (exercise single kernels / host packing; used by tests/ only) ------ */
+/* Dense layer on its own: y = [relu](x . W^T + b) [+ res]; x (m,k), w (n,k), b (n), res (m,n)
+ * or NULL, y (m,n); all fp32 device pointers except w/b which are host.  k, n: n multiple of 256. */
+int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, const float* b_host,
+                    int n, int relu, const float* res_dev, float* y_dev, int precision, void* stream);
+/* Host fp32 -> fp16 hi/lo split used by the packer (round-to-nearest-even), for unit tests. */
+int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint16_t* host_lo);
+/* Copy back the folded (and merged) fp32 weight/bias of dense layer `layer` after finalize:
+ * w_host (n*k), b_host (n); returns n and k through the pointers; scale_pow2 = weight exponent. */
+int ml_debug_get_layer(const ml_loco* h, int layer, float* w_host, float* b_host, int* n, int* k,
+                       int* scale_pow2);
+int ml_debug_num_layers(const ml_loco* h);
+/* Packed fp16 hi|lo line image of a dense layer's weights (n * kpad * 2 uint16); only kept for
+ * models finalized with ML_FLAG_HOST_ONLY. */
+int ml_debug_get_packed(const ml_loco* h, int layer, uint16_t* lines_host, int64_t capacity);
+/* Head `head` (0 = aux, 1 = w_fin): weights (nh*hidden), bias (nh), first raw column, the
+ * activation buffer it reads and the dense layer it runs after. */
+int ml_debug_get_head(const ml_loco* h, int head, float* w_host, float* b_host, int* nh, int* col0, int* src_buf,
+                      int* after_layer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOLOCO_HIP_H */

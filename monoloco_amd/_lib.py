@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI declared in ``include/monoloco_hip.h``.
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (or ``make -C
+monoloco_amd/csrc``) into ``monoloco_amd/lib/libmonoloco_hip.so``.  There is no
+fallback: if the library is missing or a call fails, a ``MonolocoHipError`` is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint16, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmonoloco_hip.so')
+
+ML_PREC_F16X2 = 0
+ML_PREC_F16 = 1
+ML_FLAG_MERGE_W2W3 = 1
+ML_FLAG_HOST_ONLY = 256
+ML_OUT_STRIDE = 16
+ML_XYZDS_STRIDE = 5
+OUT_COLS = dict(x=0, y=1, z=2, d=3, bi=4, yaw=5, yaw_ego=6, aux=7, h=8, w=9, l=10, conf=11,
+                ori0=12, ori1=13, uc=14, vc=15)
+
+
+class MonolocoHipError(RuntimeError):
+    """Raised when the HIP library is missing or one of its entry points reports an error."""
+
+
+# name -> (restype, argtypes); must list every symbol of include/monoloco_hip.h
+_P = c_void_p
+SIGNATURES = {
+    'ml_version': (c_int, []),
+    'ml_last_error': (c_char_p, []),
+    'ml_device_count': (c_int, []),
+    'ml_loco_create': (c_int, [c_int, c_int, c_int, c_int, POINTER(_P)]),
+    'ml_loco_set_tensor': (c_int, [_P, c_char_p, POINTER(c_float), c_int64]),
+    'ml_loco_finalize': (c_int, [_P, c_int, c_int]),
+    'ml_loco_reserve': (c_int, [_P, c_int64]),
+    'ml_loco_destroy': (c_int, [_P]),
+    'ml_loco_device_bytes': (c_int64, [_P]),
+    'ml_preprocess_mono': (c_int, [_P, c_int64, POINTER(c_float), c_float, _P, _P, _P]),
+    'ml_stereo_pairs': (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
+    'ml_extract_outputs': (c_int, [_P, c_int, _P, c_int64, _P, POINTER(c_float), _P, _P, _P, _P]),
+    'ml_loco_forward_raw': (c_int, [_P, _P, c_int64, _P, _P]),
+    'ml_loco_forward_mono': (c_int, [_P, _P, c_int64, POINTER(c_float), _P, _P, _P, _P, _P]),
+    'ml_loco_forward_stereo': (c_int, [_P, _P, c_int64, _P, c_int64, POINTER(c_float), _P, _P, _P, _P,
+                                       _P, _P, _P]),
+    'ml_loco_profile_begin': (c_int, [_P, c_int]),
+    'ml_loco_profile_end': (c_int, [_P, POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_int]),
+    'ml_debug_linear': (c_int, [_P, c_int64, c_int, POINTER(c_float), POINTER(c_float), c_int, c_int, _P, _P,
+                                c_int, _P]),
+    'ml_debug_split_f16': (c_int, [POINTER(c_float), c_int64, POINTER(c_uint16), POINTER(c_uint16)]),
+    'ml_debug_get_layer': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
+                                   POINTER(c_int)]),
+    'ml_debug_num_layers': (c_int, [_P]),
+    'ml_debug_get_packed': (c_int, [_P, c_int, POINTER(c_uint16), c_int64]),
+    'ml_debug_get_head': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
+                                  POINTER(c_int), POINTER(c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MonolocoHipError(
+            "HIP library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C monoloco_amd/csrc` (needs hipcc); there is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # e.g. libamdhip64 not found
+        raise MonolocoHipError("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library ever diverge
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        msg = load().ml_last_error()
+        raise MonolocoHipError("monoloco_hip error %d: %s" % (code, msg.decode() if msg else '?'))
+
+
+def fptr(array):
+    """float32 numpy array -> POINTER(c_float) (array must stay alive during the call)."""
+    return array.ctypes.data_as(POINTER(c_float))

@@ -1,0 +1,349 @@
+// geom_kernels.h -- the HBM-bound kernels either side of the dense layers:
+//   prep_kernel      preprocess_monoloco / pixel_to_camera / get_keypoints('center')
+//                    (reference monoloco/network/process.py:47-67, utils/camera.py:10-29,82-86)
+//   pairs_kernel     preprocess_monstereo all-vs-all rows (process.py:25-44)
+//   f32_to_lines / lines_to_f32   fp32 matrix <-> the "k32 hi|lo line" format of dense_kernel.h
+//   heads_kernel     the GEMV-shaped heads w_aux (H->1) and w_fin (H->8|9) (architectures.py:60,67)
+//   stereo_best      per-left arg-max of the aux logit (process.py:319-327)
+//   post_kernel      extract_outputs + back-projection geometry (process.py:231-278,
+//                    camera.py:161-177,202-237, net.py:195-215)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dense_kernel.h"
+
+namespace mlk {
+
+struct Kinv {
+    float k[9];  // inverse(K), row-major
+};
+
+constexpr int NKP = 17;
+constexpr int KPS_ROW = 3 * NKP;  // 51 floats per person: u[17], v[17], conf[17]
+constexpr int NIN = 2 * NKP;      // 34 network inputs per person
+
+// [u, v, 1] . Kinv^T row `r`, times z.  The reference does this as an fp32 GEMM with K = 3
+// starting from a zero accumulator (camera.py:25-26): acc = u*k0; acc = fma(v,k1,acc);
+// acc = fma(1,k2,acc).  Written out explicitly so the compiler cannot re-associate it.
+__device__ __forceinline__ float cam_row(float u, float v, const float* kr, float z) {
+    float acc = __fmul_rn(u, kr[0]);
+    acc = __builtin_fmaf(v, kr[1], acc);
+    acc = __fadd_rn(acc, kr[2]);
+    return __fmul_rn(acc, z);
+}
+
+// ------------------------------------------------------------------------------------------
+// prep: one workgroup = 256 persons.  The (256 x 51) fp32 slab is contiguous in HBM, so it is
+// loaded fully coalesced into LDS, each thread then normalises its own person out of LDS (row
+// stride 51 dwords: odd, conflict free), and every output is written back coalesced:
+//   x_f32   (m,34) fp32 reference-format inputs            (optional)
+//   centre  (m,2)  box-centre pixel, (max-min)/2+min        (optional)
+//   x_lines (m_pad, kpad) line-format network input, zero padded in k and in rows >= m (optional)
+__global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ kps, int64_t m, Kinv ki,
+                                                   float z_met, float* __restrict__ x_f32,
+                                                   float* __restrict__ centre, char* __restrict__ x_lines,
+                                                   int kpad, int64_t m_pad) {
+    __shared__ float s_in[256 * KPS_ROW];
+    __shared__ float s_x[256 * NIN];
+    const int t = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * 256;
+    const int64_t nvalid = (m - p0) < 256 ? (m - p0 > 0 ? m - p0 : 0) : 256;
+    const float* src = kps + p0 * KPS_ROW;
+    const int nfl = (int)nvalid * KPS_ROW;
+    for (int i = t; i < nfl; i += 256) s_in[i] = src[i];
+    __syncthreads();
+    if (t < nvalid) {
+        const float* u = s_in + t * KPS_ROW;
+        const float* v = u + NKP;
+        float umin = u[0], umax = u[0], vmin = v[0], vmax = v[0];
+#pragma unroll
+        for (int j = 0; j < NKP; ++j) {
+            const float uj = u[j], vj = v[j];
+            umin = __builtin_fminf(umin, uj);
+            umax = __builtin_fmaxf(umax, uj);
+            vmin = __builtin_fminf(vmin, vj);
+            vmax = __builtin_fmaxf(vmax, vj);
+            s_x[t * NIN + 2 * j] = cam_row(uj, vj, ki.k + 0, z_met);
+            s_x[t * NIN + 2 * j + 1] = cam_row(uj, vj, ki.k + 3, z_met);
+        }
+        if (centre) {
+            centre[(p0 + t) * 2 + 0] = __fadd_rn(__fmul_rn(__fsub_rn(umax, umin), 0.5f), umin);
+            centre[(p0 + t) * 2 + 1] = __fadd_rn(__fmul_rn(__fsub_rn(vmax, vmin), 0.5f), vmin);
+        }
+    } else {
+        for (int j = 0; j < NIN; ++j) s_x[t * NIN + j] = 0.0f;
+    }
+    __syncthreads();
+    if (x_f32) {
+        float* dst = x_f32 + p0 * NIN;
+        const int n = (int)nvalid * NIN;
+        for (int i = t; i < n; i += 256) dst[i] = s_x[i];
+    }
+    if (x_lines) {
+        // 16-byte chunks: person pi, chunk c of its row; chunk (b, sub): sub<4 hi, sub>=4 lo of
+        // k = 32b + 8(sub&3) .. +7
+        const int cpr = kpad / 8;  // chunks per row = kpad*4/16
+        const int total = 256 * cpr;
+        const int64_t rows_here = (m_pad - p0) < 256 ? (m_pad - p0) : 256;
+        char* dst = x_lines + p0 * (int64_t)kpad * 4;
+        for (int id = t; id < total; id += 256) {
+            const int pi = id / cpr, c = id - pi * cpr;
+            if (pi >= rows_here) break;
+            const int b = c >> 3, sub = c & 7;
+            const int k0 = b * 32 + (sub & 3) * 8;
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                const float val = (k < NIN) ? s_x[pi * NIN + k] : 0.0f;
+                _Float16 hi, lo;
+                split_f16(val, hi, lo);
+                o[e] = (sub < 4) ? hi : lo;
+            }
+            *(half8*)(dst + (int64_t)id * 16) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic fp32 (m,k) -> line format (m_pad, kpad), zero padded.  One thread per 16-B chunk.
+__global__ __launch_bounds__(256) void f32_to_lines_kernel(const float* __restrict__ x, int64_t m, int k,
+                                                          char* __restrict__ lines, int kpad, int64_t m_pad) {
+    const int cpr = kpad / 8;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= m_pad * cpr) return;
+    const int64_t row = id / cpr;
+    const int c = (int)(id - row * cpr);
+    const int b = c >> 3, sub = c & 7;
+    const int k0 = b * 32 + (sub & 3) * 8;
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kk = k0 + e;
+        const float val = (row < m && kk < k) ? x[row * k + kk] : 0.0f;
+        _Float16 hi, lo;
+        split_f16(val, hi, lo);
+        o[e] = (sub < 4) ? hi : lo;
+    }
+    *(half8*)(lines + id * 16) = o;
+}
+
+// line format (m_pad, n) -> fp32 (m, n): value = hi + lo.  One thread per 8 values.
+__global__ __launch_bounds__(256) void lines_to_f32_kernel(const char* __restrict__ lines, int64_t m, int n,
+                                                          float* __restrict__ y) {
+    const int gpr = n / 8;  // groups of 8 values per row
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= m * gpr) return;
+    const int64_t row = id / gpr;
+    const int g = (int)(id - row * gpr);
+    const int b = g >> 2, sub = g & 3;
+    const char* p = lines + row * (int64_t)n * 4 + b * LINE + sub * 16;
+    const half8 hi = *(const half8*)p;
+    const half8 lo = *(const half8*)(p + 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[row * n + b * 32 + sub * 8 + e] = (float)hi[e] + (float)lo[e];
+}
+
+// ------------------------------------------------------------------------------------------
+// stereo pair rows, written straight into the line format: row (i*mr + j) = [L_i, L_i - R_j]
+// (68 values, kpad = 96), optionally also as fp32 (ml*mr, 68).  One thread per 16-B chunk.
+__global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ xl, int64_t ml,
+                                                    const float* __restrict__ xr, int64_t mr,
+                                                    float* __restrict__ rows_f32, char* __restrict__ lines,
+                                                    int kpad, int64_t rows_pad) {
+    const int64_t rows = ml * mr;
+    if (lines) {
+        const int cpr = kpad / 8;
+        const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (id < rows_pad * cpr) {
+            const int64_t row = id / cpr;
+            const int c = (int)(id - row * cpr);
+            const int b = c >> 3, sub = c & 7;
+            const int k0 = b * 32 + (sub & 3) * 8;
+            const int64_t i = row / mr, j = row - i * mr;
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                float val = 0.0f;
+                if (row < rows && k < 2 * NIN) {
+                    if (k < NIN) val = xl[i * NIN + k];
+                    else val = __fsub_rn(xl[i * NIN + k - NIN], xr[j * NIN + k - NIN]);
+                }
+                _Float16 hi, lo;
+                split_f16(val, hi, lo);
+                o[e] = (sub < 4) ? hi : lo;
+            }
+            *(half8*)(lines + id * 16) = o;
+        }
+    }
+    if (rows_f32) {
+        const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (id < rows * 2 * NIN) {
+            const int64_t row = id / (2 * NIN);
+            const int k = (int)(id - row * 2 * NIN);
+            const int64_t i = row / mr, j = row - i * mr;
+            rows_f32[id] = (k < NIN) ? xl[i * NIN + k] : __fsub_rn(xl[i * NIN + k - NIN], xr[j * NIN + k - NIN]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// heads: raw[row][col0 + o] = sum_n act[row][n] * wh[o][n] + bh[o], o < NH, exact fp32 FMAs on
+// hi+lo reconstructed activations.  One wave per row (4 rows per pass to amortise the weight
+// reads from LDS), lanes stride over (hi chunk, lo chunk) pairs = 8 consecutive n, butterfly
+// reduction over the 64 lanes.  HBM-bound: reads H*4 bytes per row once.
+template <int NH>
+__global__ __launch_bounds__(256) void heads_kernel(const char* __restrict__ act, int H,
+                                                    const float* __restrict__ wh, const float* __restrict__ bh,
+                                                    float* __restrict__ raw, int raw_stride, int col0,
+                                                    int64_t m) {
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    float* s_w = (float*)dyn_smem;  // [NH][H]
+    for (int i = threadIdx.x; i < NH * H; i += 256) s_w[i] = wh[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int npairs = H / 8;
+    const int64_t nquads = (m + 3) / 4;
+    for (int64_t qd = (int64_t)blockIdx.x * 4 + wave; qd < nquads; qd += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = qd * 4;
+        float acc[4][NH];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int o = 0; o < NH; ++o) acc[r][o] = 0.0f;
+        for (int pr = lane; pr < npairs; pr += 64) {
+            const int b = pr >> 2, sub = pr & 3;
+            const int n = b * 32 + sub * 8;
+            float xv[4][8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = (r0 + r < m) ? (r0 + r) : (m - 1);
+                const char* p = act + row * (int64_t)H * 4 + b * LINE + sub * 16;
+                const half8 hi = *(const half8*)p;
+                const half8 lo = *(const half8*)(p + 64);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[r][e] = (float)hi[e] + (float)lo[e];
+            }
+#pragma unroll
+            for (int o = 0; o < NH; ++o) {
+                const f32x4 wa = *(const f32x4*)(s_w + o * H + n);
+                const f32x4 wb = *(const f32x4*)(s_w + o * H + n + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = acc[r][o];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = __builtin_fmaf(xv[r][e], wa[e], a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = __builtin_fmaf(xv[r][4 + e], wb[e], a);
+                    acc[r][o] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int o = 0; o < NH; ++o) {
+                float a = acc[r][o];
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) a += __shfl_xor(a, s, 64);
+                acc[r][o] = a;
+            }
+        if (lane < 4 * NH) {
+            const int r = lane / NH, o = lane - r * NH;
+            if (r0 + r < m) {
+                float val = 0.0f;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int oo = 0; oo < NH; ++oo)
+                        if (rr == r && oo == o) val = acc[rr][oo];
+                raw[(r0 + r) * raw_stride + col0 + o] = val + bh[o];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stereo: per left person the first right index whose aux logit (last column) is maximal, and a
+// global count of left persons with tied maxima (the reference keeps every tied row,
+// process.py:325-326; the host re-does those rare cases).
+__global__ __launch_bounds__(256) void stereo_best_kernel(const float* __restrict__ raw_all, int out_f,
+                                                          int64_t ml, int64_t mr, int32_t* __restrict__ best,
+                                                          int32_t* __restrict__ row_index,
+                                                          int32_t* __restrict__ ties) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ml) return;
+    const float* p = raw_all + i * mr * out_f + (out_f - 1);
+    float bv = p[0];
+    int bj = 0, cnt = 1;
+    bool has_nan = (bv != bv);
+    for (int64_t j = 1; j < mr; ++j) {
+        const float v = p[j * out_f];
+        has_nan |= (v != v);
+        if (v > bv) {
+            bv = v;
+            bj = (int)j;
+            cnt = 1;
+        } else if (v == bv) {
+            ++cnt;
+        }
+    }
+    best[i] = bj;
+    row_index[i] = (int32_t)(i * mr + bj);
+    if (cnt > 1 || has_nan) atomicAdd(ties, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// post: one thread per person.  Column meaning of raw: theta, psi, d, s=log(b/d), h, w, l,
+// sin, cos [, aux logit].  All arithmetic fp32 in the reference's association order.
+__global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ raw, int out_f,
+                                                   const int32_t* __restrict__ row_index, int64_t m,
+                                                   const float* __restrict__ centre, Kinv ki,
+                                                   const float* __restrict__ box_conf, float* __restrict__ out,
+                                                   float* __restrict__ xyzds) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int64_t src = row_index ? (int64_t)row_index[i] : i;
+    const float* r = raw + src * out_f;
+    const float theta = r[0], psi = r[1], d = r[2], s = r[3];
+    const float bi = __fmul_rn(expf(s), d);                       // process.py:131
+    const float x = __fmul_rn(__fmul_rn(d, sinf(psi)), cosf(theta));  // camera.py:232
+    const float y = __fmul_rn(d, cosf(psi));                      // camera.py:236
+    const float z = sqrtf(__fsub_rn(__fsub_rn(__fmul_rn(d, d), __fmul_rn(x, x)), __fmul_rn(y, y)));  // process.py:265
+    const float yaw = atan2f(r[7], r[8]);                         // process.py:272
+    float ego = __fadd_rn(yaw, atan2f(x, z));                     // camera.py:203-204
+    const float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
+    if (ego > PI_F) ego = __fsub_rn(ego, TWO_PI_F);
+    if (ego < -PI_F) ego = __fadd_rn(ego, TWO_PI_F);
+    float aux = r[out_f - 1];
+    if (out_f == 10) aux = 1.0f / (1.0f + expf(-aux));            // process.py:277
+    float* o = out + i * 16;
+    float uc = 0.f, vc = 0.f, px = 0.f, py = 0.f, pz = 0.f, conf = 0.f;
+    if (centre) {
+        uc = centre[i * 2];
+        vc = centre[i * 2 + 1];
+        const float xc = cam_row(uc, vc, ki.k + 0, 1.0f);         // net.py:198
+        const float yc = cam_row(uc, vc, ki.k + 3, 1.0f);
+        const float zc = cam_row(uc, vc, ki.k + 6, 1.0f);
+        const float nrm = sqrtf(__fadd_rn(__fadd_rn(1.0f, __fmul_rn(xc, xc)), __fmul_rn(yc, yc)));  // camera.py:177
+        px = __fmul_rn(xc, d) / nrm;
+        py = __fmul_rn(yc, d) / nrm;
+        pz = __fmul_rn(zc, d) / nrm;
+        if (box_conf) {
+            const float dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz)));
+            conf = __fmul_rn(0.035f, box_conf[i]) / (bi / dist);  // net.py:214-215
+        }
+    }
+    o[0] = x; o[1] = y; o[2] = z; o[3] = d;
+    o[4] = bi; o[5] = yaw; o[6] = ego; o[7] = aux;
+    o[8] = r[4]; o[9] = r[5]; o[10] = r[6]; o[11] = conf;
+    o[12] = r[7]; o[13] = r[8]; o[14] = uc; o[15] = vc;
+    if (xyzds) {
+        float* q = xyzds + i * 5;
+        q[0] = px; q[1] = py; q[2] = pz; q[3] = d; q[4] = bi;
+    }
+}
+
+}  // namespace mlk

@@ -1,0 +1,842 @@
+// monoloco_hip.hip -- C ABI (include/monoloco_hip.h) of the gfx950 monoloco hot path.
+//
+// Host side of the library: checkpoint intake keyed by the reference's state_dict names,
+// BatchNorm folding / w3*w2 merging in fp64, fp16 hi|lo weight packing, workspace management and
+// the launch sequences.  Device side: dense_kernel.h (MFMA dense layers) and geom_kernels.h.
+// No torch types, no exceptions across the ABI, no allocation in hot calls once reserved.
+#include "../../include/monoloco_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "dense_kernel.h"
+#include "geom_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(ML_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+// ---- fp32 -> fp16 bits, round-to-nearest-even (host; the device uses v_cvt_f16_f32) ----
+uint16_t f32_to_f16_bits(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (x >= 0x477ff000u) {  // >= 65520 rounds to inf
+        return (uint16_t)(sign | 0x7c00u);
+    }
+    if (x < 0x38800000u) {  // below the smallest normal half (2^-14): subnormal or zero
+        if (x < 0x33000000u) return (uint16_t)sign;  // < 2^-25 -> 0
+        const int e = (int)(x >> 23);                 // biased exponent
+        const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;  // 14..24 : bits dropped so that the result counts 2^-24 units
+        const uint32_t q = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u);
+        const uint32_t half = 1u << (shift - 1);
+        uint32_t r = q;
+        if (rem > half || (rem == half && (q & 1u))) r++;
+        return (uint16_t)(sign | r);
+    }
+    const uint32_t e = (x >> 23) - 112;  // re-bias 127 -> 15
+    const uint32_t mant = x & 0x7fffffu;
+    uint32_t h = (e << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+
+float f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1fu;
+    const uint32_t m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) {
+            x = sign;
+        } else {
+            float v = (float)m * 5.9604644775390625e-8f;  // m * 2^-24
+            memcpy(&x, &v, 4);
+            x |= sign;
+        }
+    } else if (e == 31) {
+        x = sign | 0x7f800000u | (m << 13);
+    } else {
+        x = sign | ((e + 112) << 23) | (m << 13);
+    }
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+void split_host(float v, uint16_t& hi, uint16_t& lo) {
+    float c = v;
+    if (c > 65504.0f) c = 65504.0f;
+    if (c < -65504.0f) c = -65504.0f;
+    hi = f32_to_f16_bits(c);
+    lo = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+}
+
+inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+inline int64_t round_up64(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+
+// One dense (MFMA) layer after folding: y = act(x . W^T + b) (+ residual)
+struct DenseLayer {
+    int n = 0, k = 0, kpad = 0;
+    int relu = 0;
+    int scale_pow2 = 0;
+    std::vector<float> w, b;  // folded fp32 (n*k), (n)
+    std::vector<uint16_t> packed;  // host image of d_w (kept only for host-only models)
+    char* d_w = nullptr;      // device, line format (n, kpad), pre-scaled
+    float* d_b = nullptr;     // device fp32 (n)
+    int src = 0, dst = 0;     // activation buffer ids: 0 = input lines, 1 = A, 2 = B
+    int res = -1;             // residual buffer id or -1
+};
+
+struct Head {
+    int nh = 0;
+    int src = 0;   // activation buffer id
+    int col0 = 0;  // first raw column
+    int after_layer = 0;  // run after dense layer index
+    std::vector<float> w, b;
+    float* d_w = nullptr;
+    float* d_b = nullptr;
+};
+
+}  // namespace
+
+struct ml_loco {
+    int in_f = 0, hidden = 0, out_f = 0, num_stage = 0;
+    int precision = ML_PREC_F16X2, flags = 0;
+    bool finalized = false;
+    bool host_only = false;
+    int device = -1;
+    std::map<std::string, std::vector<float>> tensors;
+    std::vector<DenseLayer> layers;
+    std::vector<Head> heads;
+    int k0pad = 0;
+    // workspace
+    int64_t cap_rows = 0;  // padded rows the buffers hold
+    char* buf[3] = {nullptr, nullptr, nullptr};
+    float* d_xf32 = nullptr;    // (cap_rows, in_f) fp32 staging (stereo pre-process)
+    float* d_centre = nullptr;  // (cap_rows, 2)
+    float* d_raw = nullptr;     // (cap_rows, out_f)
+    float* d_xl = nullptr;      // stereo: (cap_side, 34) each
+    float* d_xr = nullptr;
+    float* d_cl = nullptr;      // stereo: left centres
+    int32_t* d_rowidx = nullptr;
+    int64_t cap_side = 0;
+    int64_t dev_bytes = 0;
+    // optional per-launch timing of the dense kernel (ml_loco_profile_*): HIP events recorded on
+    // the stream the kernel is launched on, one (start, stop) pair per launch
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;  // 2 per recorded launch
+    std::vector<int> ev_layer;        // layer index of each recorded launch
+    size_t ev_used = 0;               // pairs in use
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(ml_loco* h, T** p, int64_t bytes) {
+    if (bytes <= 0) bytes = 16;
+    HIP_TRY(hipMalloc((void**)p, (size_t)bytes));
+    h->dev_bytes += bytes;
+    return ML_OK;
+}
+
+void dev_free(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+const std::vector<float>* get_t(const ml_loco* h, const std::string& key, int64_t numel) {
+    auto it = h->tensors.find(key);
+    if (it == h->tensors.end()) {
+        fail(ML_ERR_STATE, "state_dict tensor '%s' was never set", key.c_str());
+        return nullptr;
+    }
+    if ((int64_t)it->second.size() != numel) {
+        fail(ML_ERR_ARG, "tensor '%s' has %lld elements, expected %lld", key.c_str(),
+             (long long)it->second.size(), (long long)numel);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+// Fold Linear `lin` (n x k) with eval-mode BatchNorm `bn` (or none) in fp64:
+//   W' = W * g/sqrt(var+eps),  b' = (b - mean) * g/sqrt(var+eps) + beta
+int fold(const ml_loco* h, const std::string& lin, const std::string& bn, int n, int k,
+         std::vector<double>& W, std::vector<double>& B) {
+    const auto* w = get_t(h, lin + ".weight", (int64_t)n * k);
+    const auto* b = get_t(h, lin + ".bias", n);
+    if (!w || !b) return ML_ERR_STATE;
+    W.assign(w->begin(), w->end());
+    B.assign(b->begin(), b->end());
+    if (!bn.empty()) {
+        const auto* g = get_t(h, bn + ".weight", n);
+        const auto* be = get_t(h, bn + ".bias", n);
+        const auto* mu = get_t(h, bn + ".running_mean", n);
+        const auto* var = get_t(h, bn + ".running_var", n);
+        if (!g || !be || !mu || !var) return ML_ERR_STATE;
+        const double eps = 1e-5;  // nn.BatchNorm1d default, architectures.py:25,34
+        for (int i = 0; i < n; ++i) {
+            const double s = (double)(*g)[i] / std::sqrt((double)(*var)[i] + eps);
+            for (int j = 0; j < k; ++j) W[(size_t)i * k + j] *= s;
+            B[i] = (B[i] - (double)(*mu)[i]) * s + (double)(*be)[i];
+        }
+    }
+    return ML_OK;
+}
+
+void add_dense(ml_loco* h, const std::vector<double>& W, const std::vector<double>& B, int n, int k,
+               int relu, int src, int dst, int res) {
+    DenseLayer L;
+    L.n = n;
+    L.k = k;
+    L.kpad = round_up(k, 32);
+    L.relu = relu;
+    L.src = src;
+    L.dst = dst;
+    L.res = res;
+    L.w.resize((size_t)n * k);
+    L.b.resize(n);
+    for (size_t i = 0; i < L.w.size(); ++i) L.w[i] = (float)W[i];
+    for (int i = 0; i < n; ++i) L.b[i] = (float)B[i];
+    h->layers.push_back(std::move(L));
+}
+
+// C (n x k) = A (n x p) * B (p x k), fp64, i-k-j order (unit stride inner loop)
+void matmul64(const std::vector<double>& A, const std::vector<double>& Bm, int n, int p, int k,
+              std::vector<double>& C) {
+    C.assign((size_t)n * k, 0.0);
+    for (int i = 0; i < n; ++i) {
+        double* c = &C[(size_t)i * k];
+        for (int l = 0; l < p; ++l) {
+            const double a = A[(size_t)i * p + l];
+            const double* b = &Bm[(size_t)l * k];
+            for (int j = 0; j < k; ++j) c[j] += a * b[j];
+        }
+    }
+}
+
+// Host half of the weight preparation: per-layer power-of-two scale (max |W| lands in
+// [2^13, 2^14) so that the fp16 lo parts of all but negligible weights stay normal -- DESIGN.md
+// "precision"), fp16 hi|lo split and the k32 line layout of dense_kernel.h.
+void pack_layer(int precision, DenseLayer& L) {
+    float mx = 0.f;
+    for (float v : L.w) mx = std::fmax(mx, std::fabs(v));
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) e = (int)std::floor(std::log2(16384.0 / (double)mx));
+    if (e > 40) e = 40;
+    if (e < -40) e = -40;
+    L.scale_pow2 = e;
+    const float sc = std::ldexp(1.0f, e);
+    L.packed.assign((size_t)L.n * L.kpad * 2, 0);
+    for (int i = 0; i < L.n; ++i) {
+        uint16_t* row = &L.packed[(size_t)i * L.kpad * 2];
+        for (int j = 0; j < L.k; ++j) {
+            uint16_t hi, lo;
+            split_host(L.w[(size_t)i * L.k + j] * sc, hi, lo);
+            const int b = j >> 5, o = j & 31;
+            row[b * 64 + o] = hi;
+            row[b * 64 + 32 + o] = (precision == ML_PREC_F16X2) ? lo : 0;
+        }
+    }
+}
+
+int upload_layer(ml_loco* h, DenseLayer& L) {
+    const size_t bytes = L.packed.size() * 2;
+    int rc = dev_alloc(h, &L.d_w, (int64_t)bytes);
+    if (rc) return rc;
+    rc = dev_alloc(h, &L.d_b, (int64_t)L.n * 4);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(L.d_w, L.packed.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(L.d_b, L.b.data(), (size_t)L.n * 4, hipMemcpyHostToDevice));
+    std::vector<uint16_t>().swap(L.packed);
+    return ML_OK;
+}
+
+int free_workspace(ml_loco* h) {
+    for (auto& b : h->buf) {
+        dev_free(b);
+        b = nullptr;
+    }
+    dev_free(h->d_xf32);
+    dev_free(h->d_centre);
+    dev_free(h->d_raw);
+    dev_free(h->d_rowidx);
+    h->d_xf32 = h->d_centre = h->d_raw = nullptr;
+    h->d_rowidx = nullptr;
+    h->cap_rows = 0;
+    return ML_OK;
+}
+
+int ensure_rows(ml_loco* h, int64_t rows) {
+    const int64_t need = round_up64(rows > 0 ? rows : 1, 256);
+    if (need <= h->cap_rows) return ML_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    free_workspace(h);
+    int rc;
+    if ((rc = dev_alloc(h, &h->buf[0], need * (int64_t)h->k0pad * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->buf[1], need * (int64_t)h->hidden * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->buf[2], need * (int64_t)h->hidden * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_xf32, need * (int64_t)h->in_f * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_centre, need * 2 * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_raw, need * (int64_t)h->out_f * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_rowidx, need * 4))) return rc;
+    h->cap_rows = need;
+    return ML_OK;
+}
+
+int ensure_side(ml_loco* h, int64_t persons) {
+    if (persons <= h->cap_side) return ML_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    dev_free(h->d_xl);
+    dev_free(h->d_xr);
+    dev_free(h->d_cl);
+    const int64_t need = round_up64(persons, 256);
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_xl, need * mlk::NIN * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_xr, need * mlk::NIN * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cl, need * 2 * 4))) return rc;
+    h->cap_side = need;
+    return ML_OK;
+}
+
+mlk::Kinv make_kinv(const float* k) {
+    mlk::Kinv ki;
+    for (int i = 0; i < 9; ++i) ki.k[i] = k[i];
+    return ki;
+}
+
+int launch_dense(int precision, const mlk::DenseParams& p, hipStream_t st) {
+    const int grid = (p.M_pad / mlk::BM) * (p.N / mlk::BN);
+    if (precision == ML_PREC_F16X2)
+        hipLaunchKernelGGL(mlk::dense_kernel<3>, dim3(grid), dim3(mlk::DENSE_THREADS), 0, st, p);
+    else
+        hipLaunchKernelGGL(mlk::dense_kernel<1>, dim3(grid), dim3(mlk::DENSE_THREADS), 0, st, p);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+int launch_heads(const Head& hd, const char* act, int H, float* raw, int raw_stride, int64_t m,
+                 hipStream_t st) {
+    const size_t lds = (size_t)hd.nh * H * 4;
+    int64_t nquads = (m + 3) / 4;
+    int grid = (int)((nquads + 3) / 4);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+#define ML_HEADS(NH)                                                                                 \
+    case NH:                                                                                         \
+        if (lds > 65536)                                                                             \
+            HIP_TRY(hipFuncSetAttribute((const void*)mlk::heads_kernel<NH>,                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL(mlk::heads_kernel<NH>, dim3(grid), dim3(256), lds, st, act, H, hd.d_w,    \
+                           hd.d_b, raw, raw_stride, hd.col0, m);                                     \
+        break;
+    switch (hd.nh) {
+        ML_HEADS(1)
+        ML_HEADS(2)
+        ML_HEADS(8)
+        ML_HEADS(9)
+        ML_HEADS(10)
+        default:
+            return fail(ML_ERR_SHAPE, "unsupported head width %d", hd.nh);
+    }
+#undef ML_HEADS
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+// Runs the dense chain + heads on `rows` network rows whose line-format input already sits in
+// buf[0]; leaves raw (rows, out_f) fp32 in raw_out.
+int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st) {
+    const int64_t m_pad = round_up64(rows, 256);
+    for (size_t li = 0; li < h->layers.size(); ++li) {
+        const DenseLayer& L = h->layers[li];
+        mlk::DenseParams p;
+        p.x = h->buf[L.src];
+        p.w = L.d_w;
+        p.bias = L.d_b;
+        p.res = L.res >= 0 ? h->buf[L.res] : nullptr;
+        p.y = h->buf[L.dst];
+        p.descale = std::ldexp(1.0f, -L.scale_pow2);
+        p.M_pad = (int)m_pad;
+        p.N = L.n;
+        p.K = L.kpad;
+        p.relu = L.relu;
+        const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
+        if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
+        int rc = launch_dense(h->precision, p, st);
+        if (rc) return rc;
+        if (timed) {
+            HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));
+            h->ev_layer[h->ev_used] = (int)li;
+            h->ev_used++;
+        }
+        for (const Head& hd : h->heads)
+            if (hd.after_layer == (int)li) {
+                rc = launch_heads(hd, h->buf[hd.src], h->hidden, raw_out, h->out_f, rows, st);
+                if (rc) return rc;
+            }
+    }
+    return ML_OK;
+}
+
+int check_ready(const ml_loco* h) {
+    if (!h) return fail(ML_ERR_ARG, "null model handle");
+    if (!h->finalized) return fail(ML_ERR_STATE, "model not finalized");
+    if (h->host_only) return fail(ML_ERR_STATE, "model was finalized host-only (ML_FLAG_HOST_ONLY): it cannot run");
+    return ML_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int ml_version(void) { return 100; }
+
+const char* ml_last_error(void) { return g_err; }
+
+int ml_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        fail(ML_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+        return -ML_ERR_HIP;
+    }
+    return n;
+}
+
+int ml_loco_create(int in_features, int hidden, int out_features, int num_stage, ml_loco** out) {
+    if (!out) return fail(ML_ERR_ARG, "out is null");
+    if (in_features <= 0 || in_features > 1024) return fail(ML_ERR_SHAPE, "in_features %d unsupported", in_features);
+    if (hidden <= 0 || hidden % 256 != 0 || hidden > 4096)
+        return fail(ML_ERR_SHAPE, "hidden size %d unsupported (must be a multiple of 256, <= 4096)", hidden);
+    if (out_features < 2 || out_features > 11) return fail(ML_ERR_SHAPE, "out_features %d unsupported", out_features);
+    if (num_stage < 0 || num_stage > 16) return fail(ML_ERR_SHAPE, "num_stage %d unsupported", num_stage);
+    ml_loco* h = new (std::nothrow) ml_loco();
+    if (!h) return fail(ML_ERR_HIP, "out of host memory");
+    h->in_f = in_features;
+    h->hidden = hidden;
+    h->out_f = out_features;
+    h->num_stage = num_stage;
+    *out = h;
+    return ML_OK;
+}
+
+int ml_loco_set_tensor(ml_loco* h, const char* key, const float* host_data, int64_t numel) {
+    if (!h || !key) return fail(ML_ERR_ARG, "null argument");
+    if (h->finalized) return fail(ML_ERR_STATE, "model already finalized");
+    const std::string k(key);
+    const std::string nbt = "num_batches_tracked";
+    if (k.size() >= nbt.size() && k.compare(k.size() - nbt.size(), nbt.size(), nbt) == 0) return ML_OK;
+    if (!host_data || numel <= 0) return fail(ML_ERR_ARG, "tensor '%s': null data or bad size", key);
+    h->tensors[k].assign(host_data, host_data + numel);
+    return ML_OK;
+}
+
+int ml_loco_finalize(ml_loco* h, int precision, int flags) {
+    if (!h) return fail(ML_ERR_ARG, "null model handle");
+    if (h->finalized) return fail(ML_ERR_STATE, "model already finalized");
+    if (precision != ML_PREC_F16X2 && precision != ML_PREC_F16) return fail(ML_ERR_ARG, "unknown precision %d", precision);
+    h->precision = precision;
+    h->flags = flags;
+    h->host_only = (flags & ML_FLAG_HOST_ONLY) != 0;
+    if (!h->host_only) HIP_TRY(hipGetDevice(&h->device));
+    const int H = h->hidden, IN = h->in_f;
+    const int NFIN = h->out_f - 1;  // w_fin rows; the aux head adds the last column (architectures.py:12,70)
+    std::vector<double> W, B;
+    int rc;
+    // w1 + batch_norm1 + relu (architectures.py:50-53): input lines (buf0) -> A (buf1)
+    if ((rc = fold(h, "w1", "batch_norm1", H, IN, W, B))) return rc;
+    add_dense(h, W, B, H, IN, 1, 0, 1, -1);
+    // residual stages (architectures.py:88-102): A -> B -> A (+A)
+    for (int s = 0; s < h->num_stage; ++s) {
+        const std::string p = "linear_stages." + std::to_string(s) + ".";
+        if ((rc = fold(h, p + "w1", p + "batch_norm1", H, H, W, B))) return rc;
+        add_dense(h, W, B, H, H, 1, 1, 2, -1);
+        if ((rc = fold(h, p + "w2", p + "batch_norm2", H, H, W, B))) return rc;
+        add_dense(h, W, B, H, H, 1, 2, 1, 1);
+    }
+    std::vector<double> W2, B2, W3, B3, WA, BA;
+    if ((rc = fold(h, "w2", "", H, H, W2, B2))) return rc;
+    if ((rc = fold(h, "w3", "batch_norm3", H, H, W3, B3))) return rc;
+    if ((rc = fold(h, "w_aux", "", 1, H, WA, BA))) return rc;
+    const auto* wf = get_t(h, "w_fin.weight", (int64_t)NFIN * H);
+    const auto* bf = get_t(h, "w_fin.bias", NFIN);
+    if (!wf || !bf) return ML_ERR_STATE;
+    Head aux, fin;
+    aux.nh = 1;
+    aux.col0 = NFIN;
+    fin.nh = NFIN;
+    fin.col0 = 0;
+    fin.w.assign(wf->begin(), wf->end());
+    fin.b.assign(bf->begin(), bf->end());
+    if (flags & ML_FLAG_MERGE_W2W3) {
+        // y3 = relu(bn3(w3(w2 a + b2) + b3)) = relu((W3' W2) a + (W3' b2 + b3'));  aux = (wa W2) a + (wa b2 + ba)
+        std::vector<double> W32, B32(H), WAM, BAM(1);
+        matmul64(W3, W2, H, H, H, W32);
+        for (int i = 0; i < H; ++i) {
+            double s = B3[i];
+            for (int j = 0; j < H; ++j) s += W3[(size_t)i * H + j] * B2[j];
+            B32[i] = s;
+        }
+        matmul64(WA, W2, 1, H, H, WAM);
+        double s = BA[0];
+        for (int j = 0; j < H; ++j) s += WA[j] * B2[j];
+        BAM[0] = s;
+        aux.w.resize(H);
+        for (int j = 0; j < H; ++j) aux.w[j] = (float)WAM[j];
+        aux.b.assign(1, (float)BAM[0]);
+        aux.src = 1;  // reads a3 (buffer A) once the last stage is done
+        aux.after_layer = (int)h->layers.size() - 1;
+        add_dense(h, W32, B32, H, H, 1, 1, 2, -1);  // A -> B
+        fin.src = 2;
+        fin.after_layer = (int)h->layers.size() - 1;
+    } else {
+        add_dense(h, W2, B2, H, H, 0, 1, 2, -1);  // y2 = w2 a      A -> B   (architectures.py:59)
+        aux.w.resize(H);
+        for (int j = 0; j < H; ++j) aux.w[j] = (float)WA[j];
+        aux.b.assign(1, (float)BA[0]);
+        aux.src = 2;
+        aux.after_layer = (int)h->layers.size() - 1;
+        add_dense(h, W3, B3, H, H, 1, 2, 1, -1);  // y3 = relu(bn3(w3 y2))  B -> A
+        fin.src = 1;
+        fin.after_layer = (int)h->layers.size() - 1;
+    }
+    h->heads.push_back(std::move(aux));
+    h->heads.push_back(std::move(fin));
+    h->k0pad = h->layers[0].kpad;
+    for (auto& L : h->layers) pack_layer(h->precision, L);
+    h->tensors.clear();
+    if (h->host_only) {
+        h->finalized = true;
+        return ML_OK;
+    }
+    for (auto& L : h->layers)
+        if ((rc = upload_layer(h, L))) return rc;
+    for (auto& hd : h->heads) {
+        if ((rc = dev_alloc(h, &hd.d_w, (int64_t)hd.w.size() * 4))) return rc;
+        if ((rc = dev_alloc(h, &hd.d_b, (int64_t)hd.b.size() * 4))) return rc;
+        HIP_TRY(hipMemcpy(hd.d_w, hd.w.data(), hd.w.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(hd.d_b, hd.b.data(), hd.b.size() * 4, hipMemcpyHostToDevice));
+    }
+    h->tensors.clear();
+    h->finalized = true;
+    return ML_OK;
+}
+
+int ml_loco_reserve(ml_loco* h, int64_t max_rows) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (max_rows <= 0) return fail(ML_ERR_ARG, "max_rows must be positive");
+    return ensure_rows(h, max_rows);
+}
+
+int ml_loco_profile_begin(ml_loco* h, int max_launches) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (max_launches <= 0 || max_launches > (1 << 20)) return fail(ML_ERR_ARG, "max_launches out of range");
+    while (h->ev_pool.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->ev_pool.push_back(e);
+    }
+    h->ev_layer.assign(h->ev_pool.size() / 2, -1);
+    h->ev_used = 0;
+    h->profiling = true;
+    return ML_OK;
+}
+
+int ml_loco_profile_end(ml_loco* h, int64_t* launches, double* total_ms, double* per_layer_ms, int64_t* per_layer_n,
+                        int n_layers) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    h->profiling = false;
+    double tot = 0.0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (per_layer_ms) per_layer_ms[i] = 0.0;
+        if (per_layer_n) per_layer_n[i] = 0;
+    }
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        HIP_TRY(hipEventSynchronize(h->ev_pool[i * 2 + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i * 2], h->ev_pool[i * 2 + 1]));
+        tot += ms;
+        const int li = h->ev_layer[i];
+        if (li >= 0 && li < n_layers) {
+            if (per_layer_ms) per_layer_ms[li] += ms;
+            if (per_layer_n) per_layer_n[li] += 1;
+        }
+    }
+    if (launches) *launches = (int64_t)h->ev_used;
+    if (total_ms) *total_ms = tot;
+    h->ev_used = 0;
+    return ML_OK;
+}
+
+int ml_loco_destroy(ml_loco* h) {
+    if (!h) return ML_OK;
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    free_workspace(h);
+    dev_free(h->d_xl);
+    dev_free(h->d_xr);
+    dev_free(h->d_cl);
+    for (auto& L : h->layers) {
+        dev_free(L.d_w);
+        dev_free(L.d_b);
+    }
+    for (auto& hd : h->heads) {
+        dev_free(hd.d_w);
+        dev_free(hd.d_b);
+    }
+    delete h;
+    return ML_OK;
+}
+
+int64_t ml_loco_device_bytes(const ml_loco* h) { return h ? h->dev_bytes : 0; }
+
+// ---------------------------------------------------------------- stand-alone geometry
+int ml_preprocess_mono(const float* kps_dev, int64_t m, const float* kinv_host, float z_met, float* x_dev,
+                       float* centre_dev, void* stream) {
+    if (m < 0 || !kinv_host || (m > 0 && !kps_dev)) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    const int grid = (int)((m + 255) / 256);
+    hipLaunchKernelGGL(mlk::prep_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, kps_dev, m,
+                       make_kinv(kinv_host), z_met, x_dev, centre_dev, (char*)nullptr, 0, m);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+int ml_stereo_pairs(const float* xl_dev, int64_t ml, const float* xr_dev, int64_t mr, float* rows_dev,
+                    void* stream) {
+    if (ml < 0 || mr < 0 || !rows_dev) return fail(ML_ERR_ARG, "bad argument");
+    if (ml == 0 || mr == 0) return ML_OK;
+    if (!xl_dev || !xr_dev) return fail(ML_ERR_ARG, "null input");
+    const int64_t total = ml * mr * 2 * mlk::NIN;
+    const int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(mlk::pairs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, xl_dev, ml, xr_dev, mr,
+                       rows_dev, (char*)nullptr, 0, (int64_t)0);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+int ml_extract_outputs(const float* raw_dev, int out_features, const int32_t* row_index_dev, int64_t m,
+                       const float* centre_dev, const float* kinv_host, const float* box_conf_dev,
+                       float* out_dev, float* xyzds_dev, void* stream) {
+    if (m < 0 || !out_dev || (m > 0 && !raw_dev)) return fail(ML_ERR_ARG, "bad argument");
+    if (out_features != 9 && out_features != 10) return fail(ML_ERR_SHAPE, "out_features must be 9 or 10");
+    if (centre_dev && !kinv_host) return fail(ML_ERR_ARG, "centre given without kinv");
+    if (m == 0) return ML_OK;
+    mlk::Kinv ki;
+    for (int i = 0; i < 9; ++i) ki.k[i] = kinv_host ? kinv_host[i] : 0.f;
+    const int grid = (int)((m + 255) / 256);
+    hipLaunchKernelGGL(mlk::post_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, raw_dev, out_features,
+                       row_index_dev, m, centre_dev, ki, box_conf_dev, out_dev, xyzds_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+// ---------------------------------------------------------------- the MLP
+int ml_loco_forward_raw(ml_loco* h, const float* x_dev, int64_t m, float* raw_dev, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (m < 0 || !raw_dev || (m > 0 && !x_dev)) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    if ((rc = ensure_rows(h, m))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t m_pad = round_up64(m, 256);
+    const int64_t chunks = m_pad * (h->k0pad / 8);
+    hipLaunchKernelGGL(mlk::f32_to_lines_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, x_dev, m,
+                       h->in_f, h->buf[0], h->k0pad, m_pad);
+    HIP_TRY(hipGetLastError());
+    return run_network(h, m, raw_dev, st);
+}
+
+// ---------------------------------------------------------------- fused pipelines
+int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host,
+                         const float* box_conf_dev, float* raw_dev, float* out_dev, float* xyzds_dev,
+                         void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->in_f != mlk::NIN) return fail(ML_ERR_SHAPE, "mono pipeline needs a 34-input model, this one has %d", h->in_f);
+    if (h->out_f != 9 && h->out_f != 10) return fail(ML_ERR_SHAPE, "mono pipeline needs 9 or 10 outputs");
+    if (m < 0 || !kinv_host || !out_dev || (m > 0 && !kps_dev)) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    if ((rc = ensure_rows(h, m))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t m_pad = round_up64(m, 256);
+    const mlk::Kinv ki = make_kinv(kinv_host);
+    hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(m_pad / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
+                       (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, m_pad);
+    HIP_TRY(hipGetLastError());
+    float* raw = raw_dev ? raw_dev : h->d_raw;
+    if ((rc = run_network(h, m, raw, st))) return rc;
+    hipLaunchKernelGGL(mlk::post_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, raw, h->out_f,
+                       (const int32_t*)nullptr, m, h->d_centre, ki, box_conf_dev, out_dev, xyzds_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const float* kps_r_dev, int64_t mr,
+                           const float* kinv_host, const float* box_conf_dev, float* raw_all_dev, float* out_dev,
+                           float* xyzds_dev, int32_t* best_dev, int32_t* ties_dev, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->in_f != 2 * mlk::NIN || h->out_f != 10)
+        return fail(ML_ERR_SHAPE, "stereo pipeline needs a 68-input / 10-output model");
+    if (ml < 0 || mr <= 0 || !kinv_host || !out_dev || !best_dev || !ties_dev || (ml > 0 && (!kps_l_dev || !kps_r_dev)))
+        return fail(ML_ERR_ARG, "bad argument");
+    if (ml == 0) return ML_OK;
+    const int64_t rows = ml * mr;
+    if ((rc = ensure_rows(h, rows))) return rc;
+    if ((rc = ensure_side(h, ml > mr ? ml : mr))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const mlk::Kinv ki = make_kinv(kinv_host);
+    hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, st, kps_l_dev, ml, ki, 10.0f,
+                       h->d_xl, h->d_cl, (char*)nullptr, 0, ml);
+    hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)((mr + 255) / 256)), dim3(256), 0, st, kps_r_dev, mr, ki, 10.0f,
+                       h->d_xr, (float*)nullptr, (char*)nullptr, 0, mr);
+    HIP_TRY(hipGetLastError());
+    const int64_t rows_pad = round_up64(rows, 256);
+    const int64_t chunks = rows_pad * (h->k0pad / 8);
+    hipLaunchKernelGGL(mlk::pairs_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, h->d_xl, ml, h->d_xr,
+                       mr, (float*)nullptr, h->buf[0], h->k0pad, rows_pad);
+    HIP_TRY(hipGetLastError());
+    float* raw = raw_all_dev ? raw_all_dev : h->d_raw;
+    if ((rc = run_network(h, rows, raw, st))) return rc;
+    HIP_TRY(hipMemsetAsync(ties_dev, 0, 4, st));
+    hipLaunchKernelGGL(mlk::stereo_best_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, st, raw, h->out_f, ml,
+                       mr, best_dev, h->d_rowidx, ties_dev);
+    hipLaunchKernelGGL(mlk::post_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, st, raw, h->out_f,
+                       (const int32_t*)h->d_rowidx, ml, h->d_cl, ki, box_conf_dev, out_dev, xyzds_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+// ---------------------------------------------------------------- test hooks
+int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint16_t* host_lo) {
+    if (!host_in || !host_hi || !host_lo || n < 0) return fail(ML_ERR_ARG, "bad argument");
+    for (int64_t i = 0; i < n; ++i) split_host(host_in[i], host_hi[i], host_lo[i]);
+    return ML_OK;
+}
+
+int ml_debug_num_layers(const ml_loco* h) { return h ? (int)h->layers.size() : 0; }
+
+int ml_debug_get_layer(const ml_loco* h, int layer, float* w_host, float* b_host, int* n, int* k, int* scale_pow2) {
+    if (!h || layer < 0 || layer >= (int)h->layers.size()) return fail(ML_ERR_ARG, "bad layer index");
+    const DenseLayer& L = h->layers[layer];
+    if (n) *n = L.n;
+    if (k) *k = L.k;
+    if (scale_pow2) *scale_pow2 = L.scale_pow2;
+    if (w_host) memcpy(w_host, L.w.data(), L.w.size() * 4);
+    if (b_host) memcpy(b_host, L.b.data(), L.b.size() * 4);
+    return ML_OK;
+}
+
+int ml_debug_get_packed(const ml_loco* h, int layer, uint16_t* lines_host, int64_t capacity) {
+    if (!h || layer < 0 || layer >= (int)h->layers.size()) return fail(ML_ERR_ARG, "bad layer index");
+    const DenseLayer& L = h->layers[layer];
+    if (L.packed.empty()) return fail(ML_ERR_STATE, "packed image only kept for ML_FLAG_HOST_ONLY models");
+    if (!lines_host || capacity < (int64_t)L.packed.size()) return fail(ML_ERR_ARG, "buffer too small");
+    memcpy(lines_host, L.packed.data(), L.packed.size() * 2);
+    return ML_OK;
+}
+
+int ml_debug_get_head(const ml_loco* h, int head, float* w_host, float* b_host, int* nh, int* col0, int* src_buf,
+                      int* after_layer) {
+    if (!h || head < 0 || head >= (int)h->heads.size()) return fail(ML_ERR_ARG, "bad head index");
+    const Head& hd = h->heads[head];
+    if (nh) *nh = hd.nh;
+    if (col0) *col0 = hd.col0;
+    if (src_buf) *src_buf = hd.src;
+    if (after_layer) *after_layer = hd.after_layer;
+    if (w_host) memcpy(w_host, hd.w.data(), hd.w.size() * 4);
+    if (b_host) memcpy(b_host, hd.b.data(), hd.b.size() * 4);
+    return ML_OK;
+}
+
+int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, const float* b_host, int n, int relu,
+                    const float* res_dev, float* y_dev, int precision, void* stream) {
+    if (!x_dev || !w_host || !b_host || !y_dev || m <= 0 || k <= 0 || n <= 0 || n % 256 != 0)
+        return fail(ML_ERR_ARG, "bad argument (n must be a multiple of 256)");
+    hipStream_t st = (hipStream_t)stream;
+    ml_loco tmp;
+    tmp.precision = precision;
+    DenseLayer L;
+    L.n = n;
+    L.k = k;
+    L.kpad = round_up(k, 32);
+    L.relu = relu;
+    L.w.assign(w_host, w_host + (size_t)n * k);
+    L.b.assign(b_host, b_host + n);
+    pack_layer(precision, L);
+    int rc = upload_layer(&tmp, L);
+    const int64_t m_pad = round_up64(m, 256);
+    char *xl = nullptr, *yl = nullptr, *rl = nullptr;
+    if (!rc) rc = dev_alloc(&tmp, &xl, m_pad * (int64_t)L.kpad * 4);
+    if (!rc) rc = dev_alloc(&tmp, &yl, m_pad * (int64_t)n * 4);
+    if (!rc && res_dev) rc = dev_alloc(&tmp, &rl, m_pad * (int64_t)n * 4);
+    if (!rc) {
+        int64_t chunks = m_pad * (L.kpad / 8);
+        hipLaunchKernelGGL(mlk::f32_to_lines_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, x_dev, m, k,
+                           xl, L.kpad, m_pad);
+        if (res_dev) {
+            chunks = m_pad * (n / 8);
+            hipLaunchKernelGGL(mlk::f32_to_lines_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, res_dev,
+                               m, n, rl, n, m_pad);
+        }
+        mlk::DenseParams p;
+        p.x = xl;
+        p.w = L.d_w;
+        p.bias = L.d_b;
+        p.res = rl;
+        p.y = res_dev ? rl : yl;  // exercises the in-place residual form the model uses
+        p.descale = std::ldexp(1.0f, -L.scale_pow2);
+        p.M_pad = (int)m_pad;
+        p.N = n;
+        p.K = L.kpad;
+        p.relu = relu;
+        rc = launch_dense(precision, p, st);
+        if (!rc) {
+            const int64_t groups = m * (n / 8);
+            hipLaunchKernelGGL(mlk::lines_to_f32_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, p.y, m,
+                               n, y_dev);
+            if (hipGetLastError() != hipSuccess) rc = fail(ML_ERR_HIP, "lines_to_f32 launch failed");
+        }
+        if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(ML_ERR_HIP, "debug_linear: stream sync failed");
+    }
+    dev_free(xl);
+    dev_free(yl);
+    dev_free(rl);
+    dev_free(L.d_w);
+    dev_free(L.d_b);
+    return rc;
+}
+
+}  // extern "C"

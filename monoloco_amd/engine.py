@@ -1,0 +1,249 @@
+"""Device engine: torch tensors in, C-ABI calls out.
+
+PyTorch is used here for plumbing only -- device memory (``tensor.data_ptr()``), the current
+HIP stream and host<->device copies.  All arithmetic of the hot path happens inside
+``libmonoloco_hip.so`` (hand-written gfx950 kernels); nothing here falls back to torch ops.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MonolocoHipError, check, fptr
+
+PRECISIONS = {'f16x2': _lib.ML_PREC_F16X2, 'f16': _lib.ML_PREC_F16}
+
+
+def _require_cuda(device):
+    if not torch.cuda.is_available():
+        raise MonolocoHipError("no HIP device visible to PyTorch: the monoloco_amd hot path needs an AMD GPU "
+                               "(there is no CPU fallback)")
+    dev = torch.device(device if device is not None else 'cuda')
+    if dev.type != 'cuda':
+        raise MonolocoHipError("monoloco_amd runs on HIP devices only, got device %r" % (device,))
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    return dev
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev_f32(x, dev, shape=None):
+    """list / numpy / tensor -> contiguous fp32 tensor on dev (no copy if already there)."""
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(np.asarray(x, dtype=np.float32))
+    x = x.to(device=dev, dtype=torch.float32).contiguous()
+    if shape is not None:
+        x = x.reshape(shape)
+    return x
+
+
+def inverse_intrinsics(kk):
+    """inverse(K) as 9 fp32 numbers, taken the way the reference takes it: torch.inverse on an
+    fp32 CPU tensor (reference monoloco/utils/camera.py:23)."""
+    k = torch.as_tensor(np.asarray(kk, dtype=np.float32)).reshape(3, 3).cpu()
+    return np.ascontiguousarray(torch.inverse(k).numpy().reshape(9).astype(np.float32))
+
+
+# ------------------------------------------------------------------ stand-alone kernels
+def preprocess_mono(kps, kk, z_met=10.0, device=None, want_centre=False):
+    """(m,3,17) pixel keypoints -> (m,34) normalised inputs [and (m,2) centres] on the device."""
+    lib = _lib.load()
+    dev = _require_cuda(device if device is not None else (kps.device if isinstance(kps, torch.Tensor) and kps.is_cuda else None))
+    kps = _dev_f32(kps, dev)
+    assert kps.dim() == 3 and kps.shape[1] == 3 and kps.shape[2] == 17, "keypoints must be (m, 3, 17)"
+    m = kps.shape[0]
+    x = torch.empty((m, 34), dtype=torch.float32, device=dev)
+    c = torch.empty((m, 2), dtype=torch.float32, device=dev) if want_centre else None
+    kinv = inverse_intrinsics(kk)
+    with torch.cuda.device(dev):
+        check(lib.ml_preprocess_mono(_ptr(kps), m, fptr(kinv), float(z_met), _ptr(x), _ptr(c), _stream(dev)))
+    return (x, c) if want_centre else x
+
+
+def stereo_pairs(xl, xr):
+    lib = _lib.load()
+    dev = _require_cuda(xl.device)
+    xl = _dev_f32(xl, dev)
+    xr = _dev_f32(xr, dev)
+    rows = torch.empty((xl.shape[0] * xr.shape[0], 68), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ml_stereo_pairs(_ptr(xl), xl.shape[0], _ptr(xr), xr.shape[0], _ptr(rows), _stream(dev)))
+    return rows
+
+
+def extract_outputs_device(raw, centre=None, kk=None, box_conf=None, row_index=None):
+    """raw (m, 9|10) device tensor -> packed (m,16) and parity tensor (m,5) on the device."""
+    lib = _lib.load()
+    dev = _require_cuda(raw.device)
+    raw = _dev_f32(raw, dev)
+    m = raw.shape[0] if row_index is None else row_index.shape[0]
+    out = torch.empty((m, _lib.ML_OUT_STRIDE), dtype=torch.float32, device=dev)
+    xyzds = torch.empty((m, _lib.ML_XYZDS_STRIDE), dtype=torch.float32, device=dev)
+    kinv = inverse_intrinsics(kk) if kk is not None else None
+    centre = _dev_f32(centre, dev) if centre is not None else None
+    box_conf = _dev_f32(box_conf, dev) if box_conf is not None else None
+    if row_index is not None:
+        row_index = row_index.to(device=dev, dtype=torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        check(lib.ml_extract_outputs(_ptr(raw), raw.shape[1], _ptr(row_index), m, _ptr(centre),
+                                     fptr(kinv) if kinv is not None else None, _ptr(box_conf), _ptr(out),
+                                     _ptr(xyzds), _stream(dev)))
+    return out, xyzds
+
+
+def debug_linear(x, w, b, relu=False, res=None, precision='f16x2'):
+    """Single dense layer through the MFMA kernel (test hook)."""
+    lib = _lib.load()
+    dev = _require_cuda(x.device)
+    x = _dev_f32(x, dev)
+    w = np.ascontiguousarray(np.asarray(w, dtype=np.float32))
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float32))
+    n, k = w.shape
+    y = torch.empty((x.shape[0], n), dtype=torch.float32, device=dev)
+    res = _dev_f32(res, dev) if res is not None else None
+    with torch.cuda.device(dev):
+        check(lib.ml_debug_linear(_ptr(x), x.shape[0], k, fptr(w), fptr(b), n, int(bool(relu)), _ptr(res), _ptr(y),
+                                  PRECISIONS[precision], _stream(dev)))
+    return y
+
+
+# ------------------------------------------------------------------ the model engine
+class LocoEngine:
+    """One packed LocoModel on one HIP device (handle of ``ml_loco_*``).
+
+    ``state_dict`` uses the reference's parameter names (reference
+    monoloco/network/architectures.py:24-43); tensors may live anywhere, they are read once.
+    """
+
+    def __init__(self, state_dict, device=None, precision='f16x2', merge_w2w3=True, reserve_rows=0):
+        self._h = None
+        lib = _lib.load()
+        self.device = _require_cuda(device)
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
+        self.precision = precision
+        self.merge_w2w3 = bool(merge_w2w3)
+        sd = {k: v for k, v in state_dict.items()}
+        w1 = sd['w1.weight']
+        self.hidden, self.in_features = int(w1.shape[0]), int(w1.shape[1])
+        self.out_features = int(sd['w_fin.weight'].shape[0]) + 1
+        self.num_stage = len({k.split('.')[1] for k in sd if k.startswith('linear_stages.')})
+        handle = ctypes.c_void_p()
+        check(lib.ml_loco_create(self.in_features, self.hidden, self.out_features, self.num_stage,
+                                 ctypes.byref(handle)))
+        self._h = handle
+        for key, val in sd.items():
+            if key.endswith('num_batches_tracked'):
+                continue
+            arr = np.ascontiguousarray(val.detach().to('cpu', torch.float32).numpy() if isinstance(val, torch.Tensor)
+                                       else np.asarray(val, dtype=np.float32))
+            check(lib.ml_loco_set_tensor(self._h, key.encode(), fptr(arr), arr.size))
+        with torch.cuda.device(self.device):
+            check(lib.ml_loco_finalize(self._h, PRECISIONS[precision],
+                                       _lib.ML_FLAG_MERGE_W2W3 if self.merge_w2w3 else 0))
+            if reserve_rows:
+                check(lib.ml_loco_reserve(self._h, int(reserve_rows)))
+
+    # -- lifetime
+    def close(self):
+        if self._h is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize(self.device)
+            _lib.load().ml_loco_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def reserve(self, rows):
+        with torch.cuda.device(self.device):
+            check(_lib.load().ml_loco_reserve(self._h, int(rows)))
+
+    @property
+    def device_bytes(self):
+        return int(_lib.load().ml_loco_device_bytes(self._h))
+
+    # -- hot calls (asynchronous on the current stream of self.device)
+    def forward_raw(self, x, out=None):
+        dev = self.device
+        x = _dev_f32(x, dev)
+        assert x.dim() == 2 and x.shape[1] == self.in_features
+        m = x.shape[0]
+        raw = out if out is not None else torch.empty((m, self.out_features), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.load().ml_loco_forward_raw(self._h, _ptr(x), m, _ptr(raw), _stream(dev)))
+        return raw
+
+    def forward_mono(self, kps, kinv, box_conf=None, want_raw=False, out=None, xyzds=None, raw=None):
+        """kps (m,3,17) device fp32; kinv = inverse_intrinsics(K).  Returns (out (m,16), xyzds (m,5), raw|None)."""
+        dev = self.device
+        kps = _dev_f32(kps, dev)
+        m = kps.shape[0]
+        if out is None:
+            out = torch.empty((m, _lib.ML_OUT_STRIDE), dtype=torch.float32, device=dev)
+        if xyzds is None:
+            xyzds = torch.empty((m, _lib.ML_XYZDS_STRIDE), dtype=torch.float32, device=dev)
+        if want_raw and raw is None:
+            raw = torch.empty((m, self.out_features), dtype=torch.float32, device=dev)
+        box_conf = _dev_f32(box_conf, dev) if box_conf is not None else None
+        with torch.cuda.device(dev):
+            check(_lib.load().ml_loco_forward_mono(self._h, _ptr(kps), m, fptr(kinv), _ptr(box_conf), _ptr(raw),
+                                                   _ptr(out), _ptr(xyzds), _stream(dev)))
+        return out, xyzds, raw
+
+    def forward_stereo(self, kps_l, kps_r, kinv, box_conf=None, want_raw_all=False):
+        """All-vs-all stereo.  Returns dict(out, xyzds, best, ties, raw_all)."""
+        dev = self.device
+        kps_l = _dev_f32(kps_l, dev)
+        kps_r = _dev_f32(kps_r, dev)
+        ml, mr = kps_l.shape[0], kps_r.shape[0]
+        out = torch.empty((ml, _lib.ML_OUT_STRIDE), dtype=torch.float32, device=dev)
+        xyzds = torch.empty((ml, _lib.ML_XYZDS_STRIDE), dtype=torch.float32, device=dev)
+        best = torch.empty((ml,), dtype=torch.int32, device=dev)
+        ties = torch.zeros((1,), dtype=torch.int32, device=dev)
+        raw_all = torch.empty((ml * mr, self.out_features), dtype=torch.float32, device=dev) if want_raw_all else None
+        box_conf = _dev_f32(box_conf, dev) if box_conf is not None else None
+        with torch.cuda.device(dev):
+            check(_lib.load().ml_loco_forward_stereo(self._h, _ptr(kps_l), ml, _ptr(kps_r), mr, fptr(kinv),
+                                                     _ptr(box_conf), _ptr(raw_all), _ptr(out), _ptr(xyzds),
+                                                     _ptr(best), _ptr(ties), _stream(dev)))
+        return dict(out=out, xyzds=xyzds, best=best, ties=ties, raw_all=raw_all)
+
+    # -- measurement
+    def profile_begin(self, max_launches=65536):
+        check(_lib.load().ml_loco_profile_begin(self._h, int(max_launches)))
+
+    def profile_end(self):
+        """-> dict(launches, total_ms, per_layer_ms, per_layer_n) of the dense-kernel launches since begin."""
+        nl = self.num_layers
+        n = ctypes.c_int64()
+        tot = ctypes.c_double()
+        pl = (ctypes.c_double * nl)()
+        pn = (ctypes.c_int64 * nl)()
+        check(_lib.load().ml_loco_profile_end(self._h, ctypes.byref(n), ctypes.byref(tot), pl, pn, nl))
+        return dict(launches=int(n.value), total_ms=float(tot.value), per_layer_ms=list(pl), per_layer_n=list(pn))
+
+    # -- test hooks
+    def folded_layer(self, idx):
+        lib = _lib.load()
+        n, k, e = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib.ml_debug_get_layer(self._h, idx, None, None, ctypes.byref(n), ctypes.byref(k), ctypes.byref(e)))
+        w = np.empty((n.value, k.value), dtype=np.float32)
+        b = np.empty((n.value,), dtype=np.float32)
+        check(lib.ml_debug_get_layer(self._h, idx, fptr(w), fptr(b), None, None, None))
+        return w, b, e.value
+
+    @property
+    def num_layers(self):
+        return int(_lib.load().ml_debug_num_layers(self._h))

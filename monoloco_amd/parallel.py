@@ -1,0 +1,78 @@
+"""Multi-GPU layout of the path: rows (persons) are independent in eval mode, so a batch is cut
+into contiguous row shards, one per rank (one process per GPU), weights are replicated, there is
+no communication during compute and exactly ONE collective at the end: a gather of the (rows, 5)
+fp32 (x, y, z, d, sigma) block to rank 0 (RCCL over xGMI with the ``nccl`` backend; ``gloo`` in
+the CPU tests).  xGMI is point-to-point, so the direct all-to-one gather (7 concurrent receives
+on rank 0, one per link) is link-optimal; nothing is ringed.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total_rows, world_size, rank):
+    """Contiguous, balanced [lo, hi) row range of `rank` (first `total % world` ranks get one more)."""
+    base, rem = divmod(int(total_rows), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's env (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*).
+    Returns (rank, world_size, local_rank).  A single process is (0, 1, 0) with no group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class RowGather:
+    """Pre-allocated gather of per-rank (rows_r, width) blocks to rank `dst`, in rank order."""
+
+    def __init__(self, total_rows, width, device, dtype=torch.float32, dst=0, group=None):
+        self.group = group
+        self.dst = dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.bounds = [shard_bounds(total_rows, self.world, r) for r in range(self.world)]
+        self.full = None
+        self.parts = None
+        if self.rank == dst:
+            self.full = torch.empty((total_rows, width), dtype=dtype, device=device)
+            self.parts = [self.full[lo:hi] for lo, hi in self.bounds]
+        equal = len({hi - lo for lo, hi in self.bounds}) == 1
+        self._equal = equal
+
+    def __call__(self, local_block):
+        """Collective: returns the (total_rows, width) tensor on rank dst, None elsewhere."""
+        if self.world == 1:
+            self.full.copy_(local_block)
+            return self.full
+        if self._equal:
+            dist.gather(local_block, gather_list=self.parts if self.rank == self.dst else None, dst=self.dst,
+                        group=self.group)
+        else:  # ragged shards: point-to-point (gather needs equal sizes)
+            if self.rank == self.dst:
+                reqs = []
+                for r, part in enumerate(self.parts):
+                    if r == self.dst:
+                        part.copy_(local_block)
+                    elif part.numel():
+                        reqs.append(dist.irecv(part, src=r, group=self.group))
+                for q in reqs:
+                    q.wait()
+            elif local_block.numel():
+                dist.send(local_block, dst=self.dst, group=self.group)
+        return self.full

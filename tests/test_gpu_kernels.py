@@ -1,0 +1,197 @@
+"""-m gpu: every HIP kernel against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import monoloco_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _sd_t(sd):
+    return {k: torch.tensor(v) for k, v in sd.items()}
+
+
+def test_dense_layout_asymmetric(hip_lib, cuda_device):
+    """Transpose-detecting check of the MFMA fragment / C-D layouts: integer-valued asymmetric
+    operands (exactly representable in fp16) must reproduce x.W^T + b exactly."""
+    from monoloco_amd import engine
+    m, k, n = 300, 96, 512
+    x = (np.arange(m * k, dtype=np.float32).reshape(m, k) % 13) - 6 + (np.arange(m)[:, None] % 7)
+    w = ((np.arange(n * k, dtype=np.float32).reshape(n, k) * 7) % 11) - 5 + (np.arange(n)[:, None] % 3)
+    b = np.arange(n, dtype=np.float32) - 100
+    y = engine.debug_linear(torch.tensor(x, device=cuda_device), w, b).cpu().numpy()
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    assert np.array_equal(y, ref.astype(np.float32))
+
+
+@pytest.mark.parametrize("precision,tol", [("f16x2", 2e-6), ("f16", 3e-3)])
+@pytest.mark.parametrize("m,k,n,relu,res", [(1000, 1024, 1024, True, True), (257, 34, 256, True, False),
+                                             (4096, 1024, 1024, False, False), (64, 68, 512, False, True)])
+def test_dense_vs_fp64(hip_lib, cuda_device, precision, tol, m, k, n, relu, res):
+    from monoloco_amd import engine
+    rng = np.random.default_rng(m + k)
+    x = (rng.standard_normal((m, k)) * 1.5).astype(np.float32)
+    w = rng.uniform(-1, 1, (n, k)).astype(np.float32) / np.sqrt(k)
+    b = rng.standard_normal(n).astype(np.float32)
+    r = rng.standard_normal((m, n)).astype(np.float32) if res else None
+    y = engine.debug_linear(torch.tensor(x, device=cuda_device), w, b, relu=relu,
+                            res=torch.tensor(r, device=cuda_device) if res else None, precision=precision)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    if res:
+        ref = ref + r
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err < tol * max(1.0, np.abs(ref).max()), err
+
+
+def test_dense_fp16_subnormal_operands(hip_lib, cuda_device):
+    """The lo halves of small values are fp16 subnormals: the MFMA must not flush them."""
+    from monoloco_amd import engine
+    m, k, n = 256, 64, 256
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((m, k)) * 1e-3).astype(np.float32)
+    w = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    y = engine.debug_linear(torch.tensor(x, device=cuda_device), w, np.zeros(n, np.float32)).cpu().numpy()
+    ref = x.astype(np.float64) @ w.astype(np.float64).T
+    assert np.abs(y - ref).max() < 2e-6 * np.abs(ref).max() + 1e-9
+
+
+@pytest.mark.parametrize("m", [1, 16, 255, 256, 1000, 4097])
+def test_preprocess_matches_oracle(hip_lib, cuda_device, m):
+    from monoloco_amd import engine
+    kps = synth.make_keypoints(m, seed=m)
+    x, c = engine.preprocess_mono(torch.tensor(kps), synth.KITTI_K, device=cuda_device, want_centre=True)
+    ref = O.preprocess_monoloco(torch.tensor(kps), synth.KITTI_K)
+    cref = O.get_keypoints(torch.tensor(kps), 'center')
+    assert torch.equal(c.cpu(), cref)
+    d = (x.cpu() - ref).abs().max().item()
+    assert d <= 1e-6, d  # at most one ulp at |x| < 16 (bit-exactness is checked on the goldens)
+
+
+def test_stereo_pairs_matches_oracle(hip_lib, cuda_device):
+    from monoloco_amd import engine
+    kl, kr = synth.make_poses(13, 1), synth.make_poses(7, 2)
+    xl = engine.preprocess_mono(torch.tensor(kl), synth.KITTI_K, device=cuda_device)
+    xr = engine.preprocess_mono(torch.tensor(kr), synth.KITTI_K, device=cuda_device)
+    rows = engine.stereo_pairs(xl, xr).cpu()
+    ref, _ = O.preprocess_monstereo(torch.tensor(kl), torch.tensor(kr), synth.KITTI_K)
+    assert (rows - ref).abs().max().item() <= 2e-6
+
+
+def test_extract_outputs_matches_oracle(hip_lib, cuda_device):
+    from monoloco_amd import engine
+    m = 3000
+    rng = np.random.default_rng(0)
+    raw = rng.standard_normal((m, 10)).astype(np.float32)
+    raw[:, 0] = rng.uniform(0.2, 2.9, m)          # theta
+    raw[:, 1] = rng.uniform(1.2, 1.9, m)          # psi
+    raw[:, 2] = rng.uniform(0.5, 60, m)           # d
+    raw[:, 3] = rng.uniform(-5, 0.5, m)           # log b/d
+    kps = synth.make_poses(m, 4)
+    conf = rng.uniform(0.1, 1, m).astype(np.float32)
+    centre = O.get_keypoints(torch.tensor(kps), 'center')
+    out, xyzds = engine.extract_outputs_device(torch.tensor(raw, device=cuda_device), centre=centre,
+                                               kk=synth.KITTI_K, box_conf=conf)
+    out, xyzds = out.cpu(), xyzds.cpu()
+    ref = O.extract_outputs(torch.tensor(raw))
+    xyz, cf = O.back_project(torch.tensor(kps), synth.KITTI_K, ref['d'], ref['bi'], conf)
+    from monoloco_amd._lib import OUT_COLS as C
+    assert (out[:, C['d']] - ref['d'][:, 0]).abs().max() == 0
+    assert (out[:, C['bi']] - ref['bi'][:, 0]).abs().max() <= 1e-5 * ref['bi'].abs().max()
+    assert (out[:, 0:2] - ref['xyzd'][:, 0:2]).abs().max() <= 2e-5
+    zref = ref['xyzd'][:, 2]
+    ok = ~torch.isnan(zref)
+    assert torch.equal(torch.isnan(out[:, 2]), ~ok) or (torch.isnan(out[:, 2]) != ~ok).sum() <= 2
+    # z = sqrt(d^2-x^2-y^2): error amplified by d/z
+    both = ok & ~torch.isnan(out[:, 2])
+    amp = (ref['d'][:, 0] / zref.clamp_min(1e-3))[both]
+    assert ((out[:, 2] - zref)[both].abs() / amp).max() <= 5e-5
+    assert (out[:, C['yaw']] - ref['yaw'][0][:, 0]).abs().max() <= 2e-6
+    assert (out[:, C['aux']] - ref['aux'][:, 0]).abs().max() <= 2e-6
+    assert (out[:, 8:11] - raw[:, 4:7]).abs().max() == 0
+    assert (xyzds[:, 0:3] - xyz).abs().max() <= 1e-5
+    assert ((out[:, C['conf']] - cf).abs() / cf.abs().clamp_min(1e-6)).max() <= 1e-5
+    ego = out[:, C['yaw_ego']][both]
+    eref = ref['yaw'][1][:, 0][both]
+    dd = (ego - eref).abs()
+    dd = torch.minimum(dd, (dd - 2 * np.pi).abs())
+    assert (dd / amp.clamp_min(1)).max() <= 5e-5
+
+
+@pytest.mark.parametrize("merge", [True, False])
+@pytest.mark.parametrize("m", [16, 700])
+def test_forward_mono_parity(hip_lib, cuda_device, merge, m):
+    """Whole mono pipeline vs the fp32 oracle (= the reference's CPU path) and vs fp64 truth."""
+    from monoloco_amd import engine
+    sd = synth.make_state_dict(1)
+    kps = synth.make_poses(m, 11)
+    conf = np.linspace(0.2, 1, m).astype(np.float32)
+    eng = engine.LocoEngine(_sd_t(sd), device=cuda_device, merge_w2w3=merge)
+    out, xyzds, raw = eng.forward_mono(torch.tensor(kps), engine.inverse_intrinsics(synth.KITTI_K), box_conf=conf,
+                                       want_raw=True)
+    out, xyzds, raw = out.cpu(), xyzds.cpu(), raw.cpu()
+    ref = O.forward_mono(_sd_t(sd), torch.tensor(kps), synth.KITTI_K, box_conf=conf)
+    ref64 = O.forward_mono(_sd_t(sd), torch.tensor(kps), synth.KITTI_K, box_conf=conf, dtype=torch.float64)
+    e_raw = (raw - ref['raw']).abs().max().item()
+    e_par = (xyzds - ref['xyzds']).abs().max().item()
+    e_raw64 = (raw.double() - ref64['raw']).abs().max().item()
+    noise = (ref['raw'].double() - ref64['raw']).abs().max().item()
+    print("mono m=%d merge=%s: raw vs fp32 %.2e, vs fp64 %.2e (reference's own fp32 noise %.2e), xyzds %.2e"
+          % (m, merge, e_raw, e_raw64, noise, e_par))
+    assert e_par <= 1e-4      # the north-star bar on (x, y, z, d, sigma)
+    assert e_raw <= 1e-4
+    assert e_raw64 <= max(4 * noise, 2e-5)
+    eng.close()
+
+
+def test_forward_raw_matches_pipeline(hip_lib, cuda_device):
+    from monoloco_amd import engine
+    sd = synth.make_state_dict(2)
+    kps = synth.make_poses(300, 5)
+    eng = engine.LocoEngine(_sd_t(sd), device=cuda_device)
+    _, _, raw = eng.forward_mono(torch.tensor(kps), engine.inverse_intrinsics(synth.KITTI_K), want_raw=True)
+    x = engine.preprocess_mono(torch.tensor(kps), synth.KITTI_K, device=cuda_device)
+    raw2 = eng.forward_raw(x)
+    assert (raw - raw2).abs().max().item() <= 1e-6
+    eng.close()
+
+
+def test_forward_stereo_parity(hip_lib, cuda_device):
+    from monoloco_amd import engine
+    sd = synth.make_state_dict(3, in_features=68, out_features=10)
+    kl, kr = synth.make_poses(37, 1), synth.make_poses(9, 2)
+    eng = engine.LocoEngine(_sd_t(sd), device=cuda_device)
+    res = eng.forward_stereo(torch.tensor(kl), torch.tensor(kr), engine.inverse_intrinsics(synth.KITTI_K),
+                             want_raw_all=True)
+    ref = O.forward_stereo(_sd_t(sd), torch.tensor(kl), torch.tensor(kr), synth.KITTI_K)
+    raw_all = res['raw_all'].cpu()
+    assert (raw_all - ref['raw_all']).abs().max().item() <= 1e-4
+    assert int(res['ties'].item()) == 0
+    best_ref = ref['mask'].float().argmax(1).int()
+    # the arg-max may legitimately differ only where two logits are closer than the parity bar
+    best = res['best'].cpu()
+    diff = (best != best_ref).nonzero().flatten()
+    aux = ref['raw_all'].view(37, 9, 10)[:, :, -1]
+    for i in diff.tolist():
+        assert abs(aux[i, best[i]] - aux[i, best_ref[i]]) < 1e-4
+    same = best == best_ref
+    assert (res['xyzds'].cpu()[same] - ref['xyzds'][same]).abs().max().item() <= 1e-4
+    eng.close()
+
+
+def test_empty_and_errors(hip_lib, cuda_device):
+    from monoloco_amd import engine, _lib
+    sd = synth.make_state_dict(1, hidden=256)
+    eng = engine.LocoEngine(_sd_t(sd), device=cuda_device)
+    out, xyzds, _ = eng.forward_mono(torch.zeros((0, 3, 17)), engine.inverse_intrinsics(synth.KITTI_K))
+    assert out.shape == (0, 16) and xyzds.shape == (0, 5)
+    with pytest.raises(_lib.MonolocoHipError):
+        eng.forward_stereo(torch.zeros((2, 3, 17)), torch.zeros((2, 3, 17)), engine.inverse_intrinsics(synth.KITTI_K))
+    eng.close()
+    bad = dict(sd)
+    bad['w1.weight'] = np.zeros((250, 34), np.float32)
+    with pytest.raises(_lib.MonolocoHipError):
+        engine.LocoEngine(_sd_t(bad), device=cuda_device)
