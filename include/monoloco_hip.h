@@ -118,6 +118,22 @@ int ml_extract_outputs(const float* raw_dev, int out_features, const int32_t* ro
                        int64_t m, const float* centre_dev, const float* kinv_host,
                        const float* box_conf_dev, float* out_dev, float* xyzds_dev, void* stream);
 
+/* pixel_to_camera (utils/camera.py:10-29) on n points: uv_dev (n,2) -> out_dev (n,3) = [u,v,1].Kinv^T*z_met. */
+int ml_pixel_to_camera(const float* uv_dev, int64_t n, const float* kinv_host, float z_met, float* out_dev,
+                       void* stream);
+/* get_keypoints (utils/camera.py:69-107): kps_dev (m,3,17) -> out_dev (m,2).  mode: 0 center, 1 bottom,
+ * 2 head, 3 shoulder, 4 hip, 5 ankle. */
+int ml_get_keypoints(const float* kps_dev, int64_t m, int mode, float* out_dev, void* stream);
+/* xyz_from_distance (utils/camera.py:161-177): d_dev (m) (or one value if d_is_scalar), centres_dev (m,3)
+ * -> out_dev (m,3). */
+int ml_xyz_from_distance(const float* d_dev, int d_is_scalar, const float* centres_dev, int64_t m, float* out_dev,
+                         void* stream);
+/* to_cartesian, tensor branch (utils/camera.py:223-248): rtp_dev (m,3); mode 0 = 'x', 1 = 'y' with rows
+ * (theta, psi, r) -> out (m); mode 2 = rows (r, theta, psi) -> out (m,3). */
+int ml_to_cartesian(const float* rtp_dev, int64_t m, int mode, float* out_dev, void* stream);
+/* back_correct_angles (utils/camera.py:202-208): yaw_dev (m), xyz_dev (m,3) -> out_dev (m). */
+int ml_back_correct_angles(const float* yaw_dev, const float* xyz_dev, int64_t m, float* out_dev, void* stream);
+
 /* ---- the MLP: stands in for LocoModel.forward (architectures.py:48-71) ------------- */
 /* x_dev (m, in_features) fp32 -> raw_dev (m, out_features) fp32 (aux head last). */
 int ml_loco_forward_raw(ml_loco* h, const float* x_dev, int64_t m, float* raw_dev, void* stream);

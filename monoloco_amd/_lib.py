@@ -40,6 +40,11 @@ SIGNATURES = {
     'ml_preprocess_mono': (c_int, [_P, c_int64, POINTER(c_float), c_float, _P, _P, _P]),
     'ml_stereo_pairs': (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
     'ml_extract_outputs': (c_int, [_P, c_int, _P, c_int64, _P, POINTER(c_float), _P, _P, _P, _P]),
+    'ml_pixel_to_camera': (c_int, [_P, c_int64, POINTER(c_float), c_float, _P, _P]),
+    'ml_get_keypoints': (c_int, [_P, c_int64, c_int, _P, _P]),
+    'ml_xyz_from_distance': (c_int, [_P, c_int, _P, c_int64, _P, _P]),
+    'ml_to_cartesian': (c_int, [_P, c_int64, c_int, _P, _P]),
+    'ml_back_correct_angles': (c_int, [_P, _P, c_int64, _P, _P]),
     'ml_loco_forward_raw': (c_int, [_P, _P, c_int64, _P, _P]),
     'ml_loco_forward_mono': (c_int, [_P, _P, c_int64, POINTER(c_float), _P, _P, _P, _P, _P]),
     'ml_loco_forward_stereo': (c_int, [_P, _P, c_int64, _P, c_int64, POINTER(c_float), _P, _P, _P, _P,

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ kps
     if (x_lines) {
         // 16-byte chunks: person pi, chunk c of its row; chunk (b, sub): sub<4 hi, sub>=4 lo of
         // k = 32b + 8(sub&3) .. +7
-        const int cpr = kpad / 8;  // chunks per row = kpad*4/16
+        const int cpr = kpad / 4;  // 16-B chunks per row = kpad*4/16
         const int total = 256 * cpr;
         const int64_t rows_here = (m_pad - p0) < 256 ? (m_pad - p0) : 256;
         char* dst = x_lines + p0 * (int64_t)kpad * 4;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ kps
 // generic fp32 (m,k) -> line format (m_pad, kpad), zero padded.  One thread per 16-B chunk.
 __global__ __launch_bounds__(256) void f32_to_lines_kernel(const float* __restrict__ x, int64_t m, int k,
                                                           char* __restrict__ lines, int kpad, int64_t m_pad) {
-    const int cpr = kpad / 8;
+    const int cpr = kpad / 4;
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= m_pad * cpr) return;
     const int64_t row = id / cpr;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ xl
                                                     int kpad, int64_t rows_pad) {
     const int64_t rows = ml * mr;
     if (lines) {
-        const int cpr = kpad / 8;
+        const int cpr = kpad / 4;
         const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (id < rows_pad * cpr) {
             const int64_t row = id / cpr;

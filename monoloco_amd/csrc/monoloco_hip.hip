@@ -18,6 +18,7 @@
 
 #include "dense_kernel.h"
 #include "geom_kernels.h"
+#include "geom_ops.h"
 
 namespace {
 
@@ -624,8 +625,8 @@ int64_t ml_loco_device_bytes(const ml_loco* h) { return h ? h->dev_bytes : 0; }
 // ---------------------------------------------------------------- stand-alone geometry
 int ml_preprocess_mono(const float* kps_dev, int64_t m, const float* kinv_host, float z_met, float* x_dev,
                        float* centre_dev, void* stream) {
-    if (m < 0 || !kinv_host || (m > 0 && !kps_dev)) return fail(ML_ERR_ARG, "bad argument");
     if (m == 0) return ML_OK;
+    if (m < 0 || !kinv_host || !kps_dev) return fail(ML_ERR_ARG, "bad argument");
     const int grid = (int)((m + 255) / 256);
     hipLaunchKernelGGL(mlk::prep_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, kps_dev, m,
                        make_kinv(kinv_host), z_met, x_dev, centre_dev, (char*)nullptr, 0, m);
@@ -635,9 +636,8 @@ int ml_preprocess_mono(const float* kps_dev, int64_t m, const float* kinv_host, 
 
 int ml_stereo_pairs(const float* xl_dev, int64_t ml, const float* xr_dev, int64_t mr, float* rows_dev,
                     void* stream) {
-    if (ml < 0 || mr < 0 || !rows_dev) return fail(ML_ERR_ARG, "bad argument");
     if (ml == 0 || mr == 0) return ML_OK;
-    if (!xl_dev || !xr_dev) return fail(ML_ERR_ARG, "null input");
+    if (ml < 0 || mr < 0 || !rows_dev || !xl_dev || !xr_dev) return fail(ML_ERR_ARG, "bad argument");
     const int64_t total = ml * mr * 2 * mlk::NIN;
     const int grid = (int)((total + 255) / 256);
     hipLaunchKernelGGL(mlk::pairs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, xl_dev, ml, xr_dev, mr,
@@ -649,10 +649,10 @@ int ml_stereo_pairs(const float* xl_dev, int64_t ml, const float* xr_dev, int64_
 int ml_extract_outputs(const float* raw_dev, int out_features, const int32_t* row_index_dev, int64_t m,
                        const float* centre_dev, const float* kinv_host, const float* box_conf_dev,
                        float* out_dev, float* xyzds_dev, void* stream) {
-    if (m < 0 || !out_dev || (m > 0 && !raw_dev)) return fail(ML_ERR_ARG, "bad argument");
     if (out_features != 9 && out_features != 10) return fail(ML_ERR_SHAPE, "out_features must be 9 or 10");
-    if (centre_dev && !kinv_host) return fail(ML_ERR_ARG, "centre given without kinv");
     if (m == 0) return ML_OK;
+    if (m < 0 || !out_dev || !raw_dev) return fail(ML_ERR_ARG, "bad argument");
+    if (centre_dev && !kinv_host) return fail(ML_ERR_ARG, "centre given without kinv");
     mlk::Kinv ki;
     for (int i = 0; i < 9; ++i) ki.k[i] = kinv_host ? kinv_host[i] : 0.f;
     const int grid = (int)((m + 255) / 256);
@@ -662,16 +662,61 @@ int ml_extract_outputs(const float* raw_dev, int out_features, const int32_t* ro
     return ML_OK;
 }
 
+#define ML_GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, (hipStream_t)stream
+
+int ml_pixel_to_camera(const float* uv_dev, int64_t n, const float* kinv_host, float z_met, float* out_dev,
+                       void* stream) {
+    if (n < 0 || !kinv_host || (n > 0 && (!uv_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
+    if (n == 0) return ML_OK;
+    hipLaunchKernelGGL(mlk::pix2cam_kernel, ML_GRID(n), uv_dev, n, make_kinv(kinv_host), z_met, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+int ml_get_keypoints(const float* kps_dev, int64_t m, int mode, float* out_dev, void* stream) {
+    if (m < 0 || mode < 0 || mode > 5 || (m > 0 && (!kps_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    hipLaunchKernelGGL(mlk::keypoints_kernel, ML_GRID(m), kps_dev, m, mode, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+int ml_xyz_from_distance(const float* d_dev, int d_is_scalar, const float* centres_dev, int64_t m, float* out_dev,
+                         void* stream) {
+    if (m < 0 || (m > 0 && (!d_dev || !centres_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    hipLaunchKernelGGL(mlk::xyz_from_distance_kernel, ML_GRID(m), d_dev, d_is_scalar ? 0 : 1, centres_dev, m, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+int ml_to_cartesian(const float* rtp_dev, int64_t m, int mode, float* out_dev, void* stream) {
+    if (m < 0 || mode < 0 || mode > 2 || (m > 0 && (!rtp_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    hipLaunchKernelGGL(mlk::to_cartesian_kernel, ML_GRID(m), rtp_dev, m, mode, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+int ml_back_correct_angles(const float* yaw_dev, const float* xyz_dev, int64_t m, float* out_dev, void* stream) {
+    if (m < 0 || (m > 0 && (!yaw_dev || !xyz_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    hipLaunchKernelGGL(mlk::back_correct_kernel, ML_GRID(m), yaw_dev, xyz_dev, m, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+#undef ML_GRID
+
 // ---------------------------------------------------------------- the MLP
 int ml_loco_forward_raw(ml_loco* h, const float* x_dev, int64_t m, float* raw_dev, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (m < 0 || !raw_dev || (m > 0 && !x_dev)) return fail(ML_ERR_ARG, "bad argument");
     if (m == 0) return ML_OK;
+    if (m < 0 || !raw_dev || !x_dev) return fail(ML_ERR_ARG, "bad argument");
     if ((rc = ensure_rows(h, m))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t m_pad = round_up64(m, 256);
-    const int64_t chunks = m_pad * (h->k0pad / 8);
+    const int64_t chunks = m_pad * (h->k0pad / 4);
     hipLaunchKernelGGL(mlk::f32_to_lines_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, x_dev, m,
                        h->in_f, h->buf[0], h->k0pad, m_pad);
     HIP_TRY(hipGetLastError());
@@ -686,8 +731,8 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
     if (rc) return rc;
     if (h->in_f != mlk::NIN) return fail(ML_ERR_SHAPE, "mono pipeline needs a 34-input model, this one has %d", h->in_f);
     if (h->out_f != 9 && h->out_f != 10) return fail(ML_ERR_SHAPE, "mono pipeline needs 9 or 10 outputs");
-    if (m < 0 || !kinv_host || !out_dev || (m > 0 && !kps_dev)) return fail(ML_ERR_ARG, "bad argument");
     if (m == 0) return ML_OK;
+    if (m < 0 || !kinv_host || !out_dev || !kps_dev) return fail(ML_ERR_ARG, "bad argument");
     if ((rc = ensure_rows(h, m))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t m_pad = round_up64(m, 256);
@@ -710,9 +755,9 @@ int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const
     if (rc) return rc;
     if (h->in_f != 2 * mlk::NIN || h->out_f != 10)
         return fail(ML_ERR_SHAPE, "stereo pipeline needs a 68-input / 10-output model");
-    if (ml < 0 || mr <= 0 || !kinv_host || !out_dev || !best_dev || !ties_dev || (ml > 0 && (!kps_l_dev || !kps_r_dev)))
-        return fail(ML_ERR_ARG, "bad argument");
     if (ml == 0) return ML_OK;
+    if (ml < 0 || mr <= 0 || !kinv_host || !out_dev || !best_dev || !ties_dev || !kps_l_dev || !kps_r_dev)
+        return fail(ML_ERR_ARG, "bad argument");
     const int64_t rows = ml * mr;
     if ((rc = ensure_rows(h, rows))) return rc;
     if ((rc = ensure_side(h, ml > mr ? ml : mr))) return rc;
@@ -724,7 +769,7 @@ int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const
                        h->d_xr, (float*)nullptr, (char*)nullptr, 0, mr);
     HIP_TRY(hipGetLastError());
     const int64_t rows_pad = round_up64(rows, 256);
-    const int64_t chunks = rows_pad * (h->k0pad / 8);
+    const int64_t chunks = rows_pad * (h->k0pad / 4);
     hipLaunchKernelGGL(mlk::pairs_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, h->d_xl, ml, h->d_xr,
                        mr, (float*)nullptr, h->buf[0], h->k0pad, rows_pad);
     HIP_TRY(hipGetLastError());
@@ -803,11 +848,11 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
     if (!rc) rc = dev_alloc(&tmp, &yl, m_pad * (int64_t)n * 4);
     if (!rc && res_dev) rc = dev_alloc(&tmp, &rl, m_pad * (int64_t)n * 4);
     if (!rc) {
-        int64_t chunks = m_pad * (L.kpad / 8);
+        int64_t chunks = m_pad * (L.kpad / 4);
         hipLaunchKernelGGL(mlk::f32_to_lines_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, x_dev, m, k,
                            xl, L.kpad, m_pad);
         if (res_dev) {
-            chunks = m_pad * (n / 8);
+            chunks = m_pad * (n / 4);
             hipLaunchKernelGGL(mlk::f32_to_lines_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, res_dev,
                                m, n, rl, n, m_pad);
         }

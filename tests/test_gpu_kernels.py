@@ -48,15 +48,16 @@ def test_dense_vs_fp64(hip_lib, cuda_device, precision, tol, m, k, n, relu, res)
 
 
 def test_dense_fp16_subnormal_operands(hip_lib, cuda_device):
-    """The lo halves of small values are fp16 subnormals: the MFMA must not flush them."""
+    """The lo halves of small activations are fp16 subnormals; the MFMA must not flush them.
+    x = 2^-3 + 3*2^-24 splits into hi = 2^-3, lo = 3*2^-24 (an exactly representable fp16 subnormal);
+    with unit weights over k = 32 the exact answer 4 + 3*2^-19 is representable in fp32, and a
+    flushed lo would give exactly 4."""
     from monoloco_amd import engine
-    m, k, n = 256, 64, 256
-    rng = np.random.default_rng(5)
-    x = (rng.standard_normal((m, k)) * 1e-3).astype(np.float32)
-    w = rng.uniform(-1, 1, (n, k)).astype(np.float32)
+    m, k, n = 256, 32, 256
+    x = np.full((m, k), 2.0 ** -3 + 3 * 2.0 ** -24, dtype=np.float32)
+    w = np.ones((n, k), dtype=np.float32)
     y = engine.debug_linear(torch.tensor(x, device=cuda_device), w, np.zeros(n, np.float32)).cpu().numpy()
-    ref = x.astype(np.float64) @ w.astype(np.float64).T
-    assert np.abs(y - ref).max() < 2e-6 * np.abs(ref).max() + 1e-9
+    assert np.all(y == np.float32(4 + 3 * 2.0 ** -19)), (y.min(), y.max())
 
 
 @pytest.mark.parametrize("m", [1, 16, 255, 256, 1000, 4097])
