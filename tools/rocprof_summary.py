@@ -1,0 +1,31 @@
+"""Turn a rocprofv3 results .db (rocpd sqlite) into the per-kernel stats table we commit under profiles/."""
+import sqlite3
+import sys
+
+
+def main(db_path, out_path=None):
+    db = sqlite3.connect(db_path)
+    cur = db.cursor()
+    rows = cur.execute(
+        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+        "group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    lines = ["# rocprofv3 --kernel-trace --stats summary of %s" % db_path,
+             "%-78s %8s %14s %12s %12s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct")]
+    for name, n, tot, avg, mn, mx in rows:
+        lines.append("%-78s %8d %14d %12.0f %12d %12d %6.2f%%" % (name[:78], n, tot, avg, mn, mx, 100.0 * tot / total))
+    # per-grid breakdown of the dense kernel (the K=64 first layer vs the 1024x1024 layers)
+    lines.append("")
+    lines.append("# dense kernel by grid size / kernarg (first layer K=64 is the short one)")
+    for name, gx, n, avg, mn, mx in cur.execute(
+            "select name, grid_x, count(*), avg(duration), min(duration), max(duration) from kernels "
+            "where name like '%dense_kernel%' group by name, grid_x").fetchall():
+        lines.append("%-60s grid_x=%-8d calls=%-5d avg_ns=%-10.0f min=%-9d max=%d" % (name[:60], gx, n, avg, mn, mx))
+    txt = "\n".join(lines) + "\n"
+    if out_path:
+        open(out_path, 'w').write(txt)
+    print(txt)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
