@@ -101,10 +101,11 @@ int64_t ml_loco_device_bytes(const ml_loco* h);
 /* preprocess_monoloco (process.py:47-67) = pixel_to_camera(kps[:,0:2,:], K, z_met)
  * (camera.py:10-29) reshaped to (m,34) interleaved x0,y0,x1,y1,...  `kinv_host` is
  * inverse(K) row-major (9 floats; the host computes it as the reference does, with
- * torch.inverse).  x_dev (m,34) and/or centre_dev (m,2: get_keypoints(..,'center'),
+ * torch.inverse).  zero_center != 0 subtracts the normalised box centre (legacy MonoLoco,
+ * process.py:61-62).  x_dev (m,34) and/or centre_dev (m,2: get_keypoints(..,'center'),
  * camera.py:82-86) may be NULL. */
 int ml_preprocess_mono(const float* kps_dev, int64_t m, const float* kinv_host, float z_met,
-                       float* x_dev, float* centre_dev, void* stream);
+                       int zero_center, float* x_dev, float* centre_dev, void* stream);
 /* preprocess_monstereo (process.py:25-44): all-vs-all rows [L_i, L_i - R_j], i-major;
  * xl_dev (ml,34), xr_dev (mr,34) -> rows_dev (ml*mr, 68). */
 int ml_stereo_pairs(const float* xl_dev, int64_t ml, const float* xr_dev, int64_t mr,

@@ -37,7 +37,7 @@ SIGNATURES = {
     'ml_loco_reserve': (c_int, [_P, c_int64]),
     'ml_loco_destroy': (c_int, [_P]),
     'ml_loco_device_bytes': (c_int64, [_P]),
-    'ml_preprocess_mono': (c_int, [_P, c_int64, POINTER(c_float), c_float, _P, _P, _P]),
+    'ml_preprocess_mono': (c_int, [_P, c_int64, POINTER(c_float), c_float, c_int, _P, _P, _P]),
     'ml_stereo_pairs': (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
     'ml_extract_outputs': (c_int, [_P, c_int, _P, c_int64, _P, POINTER(c_float), _P, _P, _P, _P]),
     'ml_pixel_to_camera': (c_int, [_P, c_int64, POINTER(c_float), c_float, _P, _P]),

@@ -42,7 +42,7 @@ __device__ __forceinline__ float cam_row(float u, float v, const float* kr, floa
 __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ kps, int64_t m, Kinv ki,
                                                    float z_met, float* __restrict__ x_f32,
                                                    float* __restrict__ centre, char* __restrict__ x_lines,
-                                                   int kpad, int64_t m_pad) {
+                                                   int kpad, int64_t m_pad, int zero_center) {
     __shared__ float s_in[256 * KPS_ROW];
     __shared__ float s_x[256 * NIN];
     const int t = threadIdx.x;
@@ -57,18 +57,27 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ kps
         const float* v = u + NKP;
         float umin = u[0], umax = u[0], vmin = v[0], vmax = v[0];
 #pragma unroll
+        for (int j = 1; j < NKP; ++j) {
+            umin = __builtin_fminf(umin, u[j]);
+            umax = __builtin_fmaxf(umax, u[j]);
+            vmin = __builtin_fminf(vmin, v[j]);
+            vmax = __builtin_fmaxf(vmax, v[j]);
+        }
+        const float uc = __fadd_rn(__fmul_rn(__fsub_rn(umax, umin), 0.5f), umin);  // camera.py:85
+        const float vc = __fadd_rn(__fmul_rn(__fsub_rn(vmax, vmin), 0.5f), vmin);
+        // zero_center (legacy MonoLoco, process.py:61-62): subtract the normalised box centre
+        const float cx = zero_center ? cam_row(uc, vc, ki.k + 0, z_met) : 0.0f;
+        const float cy = zero_center ? cam_row(uc, vc, ki.k + 3, z_met) : 0.0f;
+#pragma unroll
         for (int j = 0; j < NKP; ++j) {
-            const float uj = u[j], vj = v[j];
-            umin = __builtin_fminf(umin, uj);
-            umax = __builtin_fmaxf(umax, uj);
-            vmin = __builtin_fminf(vmin, vj);
-            vmax = __builtin_fmaxf(vmax, vj);
-            s_x[t * NIN + 2 * j] = cam_row(uj, vj, ki.k + 0, z_met);
-            s_x[t * NIN + 2 * j + 1] = cam_row(uj, vj, ki.k + 3, z_met);
+            const float xj = cam_row(u[j], v[j], ki.k + 0, z_met);
+            const float yj = cam_row(u[j], v[j], ki.k + 3, z_met);
+            s_x[t * NIN + 2 * j] = zero_center ? __fsub_rn(xj, cx) : xj;
+            s_x[t * NIN + 2 * j + 1] = zero_center ? __fsub_rn(yj, cy) : yj;
         }
         if (centre) {
-            centre[(p0 + t) * 2 + 0] = __fadd_rn(__fmul_rn(__fsub_rn(umax, umin), 0.5f), umin);
-            centre[(p0 + t) * 2 + 1] = __fadd_rn(__fmul_rn(__fsub_rn(vmax, vmin), 0.5f), vmin);
+            centre[(p0 + t) * 2 + 0] = uc;
+            centre[(p0 + t) * 2 + 1] = vc;
         }
     } else {
         for (int j = 0; j < NIN; ++j) s_x[t * NIN + j] = 0.0f;

@@ -623,13 +623,13 @@ int ml_loco_destroy(ml_loco* h) {
 int64_t ml_loco_device_bytes(const ml_loco* h) { return h ? h->dev_bytes : 0; }
 
 // ---------------------------------------------------------------- stand-alone geometry
-int ml_preprocess_mono(const float* kps_dev, int64_t m, const float* kinv_host, float z_met, float* x_dev,
-                       float* centre_dev, void* stream) {
+int ml_preprocess_mono(const float* kps_dev, int64_t m, const float* kinv_host, float z_met, int zero_center,
+                       float* x_dev, float* centre_dev, void* stream) {
     if (m == 0) return ML_OK;
     if (m < 0 || !kinv_host || !kps_dev) return fail(ML_ERR_ARG, "bad argument");
     const int grid = (int)((m + 255) / 256);
     hipLaunchKernelGGL(mlk::prep_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, kps_dev, m,
-                       make_kinv(kinv_host), z_met, x_dev, centre_dev, (char*)nullptr, 0, m);
+                       make_kinv(kinv_host), z_met, x_dev, centre_dev, (char*)nullptr, 0, m, zero_center);
     HIP_TRY(hipGetLastError());
     return ML_OK;
 }
@@ -738,7 +738,7 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
     const int64_t m_pad = round_up64(m, 256);
     const mlk::Kinv ki = make_kinv(kinv_host);
     hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(m_pad / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
-                       (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, m_pad);
+                       (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, m_pad, 0);
     HIP_TRY(hipGetLastError());
     float* raw = raw_dev ? raw_dev : h->d_raw;
     if ((rc = run_network(h, m, raw, st))) return rc;
@@ -764,9 +764,9 @@ int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const
     hipStream_t st = (hipStream_t)stream;
     const mlk::Kinv ki = make_kinv(kinv_host);
     hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, st, kps_l_dev, ml, ki, 10.0f,
-                       h->d_xl, h->d_cl, (char*)nullptr, 0, ml);
+                       h->d_xl, h->d_cl, (char*)nullptr, 0, ml, 0);
     hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)((mr + 255) / 256)), dim3(256), 0, st, kps_r_dev, mr, ki, 10.0f,
-                       h->d_xr, (float*)nullptr, (char*)nullptr, 0, mr);
+                       h->d_xr, (float*)nullptr, (char*)nullptr, 0, mr, 0);
     HIP_TRY(hipGetLastError());
     const int64_t rows_pad = round_up64(rows, 256);
     const int64_t chunks = rows_pad * (h->k0pad / 4);

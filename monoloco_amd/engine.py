@@ -53,7 +53,7 @@ def inverse_intrinsics(kk):
 
 
 # ------------------------------------------------------------------ stand-alone kernels
-def preprocess_mono(kps, kk, z_met=10.0, device=None, want_centre=False):
+def preprocess_mono(kps, kk, z_met=10.0, device=None, want_centre=False, zero_center=False):
     """(m,3,17) pixel keypoints -> (m,34) normalised inputs [and (m,2) centres] on the device."""
     lib = _lib.load()
     dev = _require_cuda(device if device is not None else (kps.device if isinstance(kps, torch.Tensor) and kps.is_cuda else None))
@@ -64,7 +64,8 @@ def preprocess_mono(kps, kk, z_met=10.0, device=None, want_centre=False):
     c = torch.empty((m, 2), dtype=torch.float32, device=dev) if want_centre else None
     kinv = inverse_intrinsics(kk)
     with torch.cuda.device(dev):
-        check(lib.ml_preprocess_mono(_ptr(kps), m, fptr(kinv), float(z_met), _ptr(x), _ptr(c), _stream(dev)))
+        check(lib.ml_preprocess_mono(_ptr(kps), m, fptr(kinv), float(z_met), int(bool(zero_center)), _ptr(x), _ptr(c),
+                                     _stream(dev)))
     return (x, c) if want_centre else x
 
 

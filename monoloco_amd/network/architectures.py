@@ -1,0 +1,108 @@
+"""``LocoModel`` / ``MonolocoModel`` parameter containers with the reference's state_dict layout
+(reference monoloco/network/architectures.py), whose eval forward runs on the HIP engine.
+
+The modules own ordinary ``nn.Linear`` / ``nn.BatchNorm1d`` parameters under the reference's names
+(``w1``, ``batch_norm1``, ``linear_stages.{i}.w1`` ...), so reference checkpoints load with
+``load_state_dict`` unchanged.  ``forward`` in eval mode packs the current parameters once
+(BN folded, fp16 hi|lo split, uploaded) and calls the MFMA kernels; there is no torch compute path.
+Training-mode forward (batch-stat BN, dropout, backward) is the "next" row of SURVEY.md 8f.
+"""
+import torch
+from torch import nn
+
+from .. import engine
+
+
+class _Stage(nn.Module):
+    """One residual stage: y = x + relu(bn2(w2(relu(bn1(w1 x))))) (reference architectures.py:74-102)."""
+
+    def __init__(self, size, p_dropout):
+        super().__init__()
+        self.l_size = size
+        self.w1 = nn.Linear(size, size)
+        self.batch_norm1 = nn.BatchNorm1d(size)
+        self.w2 = nn.Linear(size, size)
+        self.batch_norm2 = nn.BatchNorm1d(size)
+        self.relu = nn.ReLU(inplace=True)
+        self.dropout = nn.Dropout(p_dropout)
+
+
+class LocoModel(nn.Module):
+    """MonoLoco++ (input 34) / MonStereo (input 68) residual MLP (reference architectures.py:6-71).
+
+    ``output_size`` counts the auxiliary head as in the reference: w_fin has output_size-1 rows and
+    w_aux one."""
+
+    def __init__(self, input_size, output_size=2, linear_size=512, p_dropout=0.2, num_stage=3, device='cuda',
+                 precision='f16x2', merge_w2w3=True):
+        super().__init__()
+        self.stereo_size = input_size
+        self.mono_size = int(input_size / 2)
+        self.output_size = output_size - 1
+        self.linear_size = linear_size
+        self.p_dropout = p_dropout
+        self.num_stage = num_stage
+        self.device = device
+        self.precision = precision
+        self.merge_w2w3 = merge_w2w3
+        self.w1 = nn.Linear(input_size, linear_size)
+        self.batch_norm1 = nn.BatchNorm1d(linear_size)
+        self.linear_stages = nn.ModuleList([_Stage(linear_size, p_dropout) for _ in range(num_stage)])
+        self.w2 = nn.Linear(linear_size, linear_size)
+        self.w3 = nn.Linear(linear_size, linear_size)
+        self.batch_norm3 = nn.BatchNorm1d(linear_size)
+        self.w_aux = nn.Linear(linear_size, 1)
+        self.w_fin = nn.Linear(linear_size, self.output_size)
+        self.relu = nn.ReLU(inplace=True)
+        self.dropout = nn.Dropout(p_dropout)
+        self._engine = None
+        self._engine_key = None
+
+    # -- engine management: re-pack when parameters were replaced or modified in place
+    def _params_key(self, dev):
+        return (str(dev), self.precision, self.merge_w2w3) + tuple(
+            (t.data_ptr(), t._version) for t in self.state_dict().values())
+
+    def hip_engine(self, device=None):
+        dev = engine._require_cuda(device)
+        key = self._params_key(dev)
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = engine.LocoEngine(self.state_dict(), device=dev, precision=self.precision,
+                                             merge_w2w3=self.merge_w2w3)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, x):
+        if self.training or self.dropout.training:
+            raise NotImplementedError(
+                "monoloco_amd implements the eval-mode forward (running-stat BatchNorm, no dropout); the training "
+                "step and MC-dropout are the next rows of the hot-path scope (SURVEY.md 8f)")
+        home = x.device
+        eng = self.hip_engine(home if home.type == 'cuda' else None)
+        return eng.forward_raw(x.detach()).to(home)
+
+
+class MonolocoModel(nn.Module):
+    """Legacy MonoLoco (hidden 256, 2 outputs; reference architectures.py:105-145).  Kept as a
+    checkpoint-compatible container only: the reference's own ``Loco`` cannot reach it (passing
+    ``net=`` raises before assignment, reference net.py:41), so no kernel is built for it."""
+
+    def __init__(self, input_size, output_size=2, linear_size=256, p_dropout=0.2, num_stage=3):
+        super().__init__()
+        self.input_size = input_size
+        self.output_size = output_size
+        self.linear_size = linear_size
+        self.p_dropout = p_dropout
+        self.num_stage = num_stage
+        self.w1 = nn.Linear(input_size, linear_size)
+        self.batch_norm1 = nn.BatchNorm1d(linear_size)
+        self.linear_stages = nn.ModuleList([_Stage(linear_size, p_dropout) for _ in range(num_stage)])
+        self.w2 = nn.Linear(linear_size, output_size)
+        self.relu = nn.ReLU(inplace=True)
+        self.dropout = nn.Dropout(p_dropout)
+
+    def forward(self, x):
+        raise NotImplementedError("legacy MonolocoModel has no HIP kernel (unreachable through Loco in the "
+                                  "reference as well); use LocoModel (monoloco_pp / monstereo)")

@@ -1,0 +1,181 @@
+"""``Loco`` -- the inference API of the reference (monoloco/network/net.py:23-271) on the HIP engine.
+
+Same constructor, ``forward`` and ``post_process`` signatures, same returned dictionaries (keys,
+shapes, CPU fp32 tensors / Python lists, ``None`` for empty input).  Differences that are not
+visible through the reference's own call sites: inputs may also be tensors (no list marshalling),
+``device`` must be a HIP device (default: the current one) and ``post_process`` is vectorised (the
+reference's per-person Python loop is quadratic in the number of persons).
+"""
+import logging
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from .. import engine
+from ..utils import get_iou_matches, get_keypoints, pixel_to_camera, reorder_matches, xyz_from_distance
+from .architectures import LocoModel, MonolocoModel
+from .process import packed_to_dict
+
+
+class Loco:
+    """Class for both MonoLoco++ (mode 'mono') and MonStereo (mode 'stereo')."""
+    logger = logging.getLogger(__name__)
+    LINEAR_SIZE_MONO = 256
+    N_SAMPLES = 100
+
+    def __init__(self, model, mode, net=None, device=None, n_dropout=0, p_dropout=0.2, linear_size=1024):
+        assert mode in ('mono', 'stereo'), "mode not recognized"
+        self.mode = mode
+        if net is None:
+            self.net = 'monoloco_pp' if mode == 'mono' else 'monstereo'
+        else:
+            # The reference reads self.net before assigning it here (net.py:41) and raises
+            # AttributeError; only the default nets are reachable there.  Be explicit instead.
+            assert net in ('monstereo', 'monoloco', 'monoloco_p', 'monoloco_pp')
+            if net in ('monoloco', 'monoloco_p'):
+                raise NotImplementedError("legacy nets 'monoloco'/'monoloco_p' are not reachable through the "
+                                          "reference's Loco either; use monoloco_pp or monstereo")
+            assert (net == 'monstereo') == (mode == 'stereo'), "Assert arguments mode and net are in conflict"
+            self.net = net
+        input_size, output_size = (68, 10) if self.net == 'monstereo' else (34, 9)
+        self.device = engine._require_cuda(device)
+        self.n_dropout = n_dropout
+        self.epistemic = bool(self.n_dropout > 0)
+        if isinstance(model, str):
+            self.model = LocoModel(p_dropout=p_dropout, input_size=input_size, output_size=output_size,
+                                   linear_size=linear_size, device=self.device)
+            self.model.load_state_dict(torch.load(model, map_location=lambda storage, loc: storage))
+        else:
+            self.model = model
+        self.model.eval()
+        sd = self.model.state_dict()
+        assert sd['w1.weight'].shape[1] == input_size, "model input size does not match mode '%s'" % mode
+        self.engine = engine.LocoEngine(sd, device=self.device,
+                                        precision=getattr(self.model, 'precision', 'f16x2'),
+                                        merge_w2w3=getattr(self.model, 'merge_w2w3', True))
+
+    def forward(self, keypoints, kk, keypoints_r=None):
+        """Pre-process, network forward and output extraction for one image (reference net.py:83-133).
+        Returns the reference's dictionary of CPU tensors, or None when there are no keypoints."""
+        if keypoints is None or len(keypoints) == 0:
+            return None
+        dev = self.device
+        kps = engine._dev_f32(keypoints, dev)
+        kinv = engine.inverse_intrinsics(kk.tolist() if isinstance(kk, torch.Tensor) else kk)
+        if self.net == 'monoloco_pp':
+            out, _, _ = self.engine.forward_mono(kps, kinv)
+            dic_out = packed_to_dict(out, 9)
+            n_out = kps.shape[0]
+        else:
+            if keypoints_r is not None and len(keypoints_r) > 0:
+                kps_r = engine._dev_f32(keypoints_r, dev)
+            else:
+                kps_r = kps[0:1].clone()  # reference net.py:115-116
+            res = self.engine.forward_stereo(kps, kps_r, kinv, want_raw_all=True)
+            if int(res['ties'].item()) == 0:
+                dic_out = packed_to_dict(res['out'], 10)
+            else:
+                # exact ties of the aux logit: the reference keeps every tied pair row (process.py:325)
+                raw = res['raw_all'].view(kps.shape[0], kps_r.shape[0], 10)
+                val = raw[:, :, -1]
+                rows = (val >= val.max(dim=1, keepdim=True).values).reshape(-1).nonzero().flatten().int()
+                out, _ = engine.extract_outputs_device(res['raw_all'], row_index=rows)
+                dic_out = packed_to_dict(out, 10)
+            n_out = kps.shape[0]
+        if self.n_dropout > 0 and self.net != 'monstereo':
+            raise NotImplementedError("MC-dropout epistemic uncertainty (reference net.py:135-161) is a 'next' row "
+                                      "of the hot-path scope; run with n_dropout=0")
+        dic_out['epi'] = [0.] * n_out
+        return dic_out
+
+    @staticmethod
+    def post_process(dic_in, boxes, keypoints, kk, dic_gt=None, iou_min=0.3, reorder=True, verbose=False):
+        """Final per-image dictionary for visualisation / json (reference net.py:163-248): optional
+        IoU matching with ground truth, representative pixels, back-projected xyz and confidence."""
+        dic_out = defaultdict(list)
+        if dic_in is None:
+            return dic_out
+        if dic_gt:
+            boxes_gt = dic_gt['boxes']
+            dds_gt = [el[3] for el in dic_gt['ys']]
+            matches = get_iou_matches(boxes, boxes_gt, iou_min=iou_min)
+            dic_out['gt'] = [True]
+            if verbose:
+                print("found {} matches with ground-truth".format(len(matches)))
+            matched = [el[0] for el in matches]
+            not_matches = [idx for idx, _ in enumerate(boxes) if idx not in matched]
+        else:
+            matches = []
+            not_matches = list(range(len(boxes)))
+            if verbose:
+                print("NO ground-truth associated")
+        if reorder and matches:
+            matches = reorder_matches(matches, boxes, mode='left_right')
+        all_idxs = [idx for idx, _ in matches] + not_matches
+        dic_out['gt'] = [True] * len(matches) + [False] * len(not_matches)
+
+        # device geometry, whole image at once
+        uv_shoulders = get_keypoints(keypoints, mode='shoulder')
+        uv_heads = get_keypoints(keypoints, mode='head')
+        uv_centers = get_keypoints(keypoints, mode='center')
+        xy_centers = pixel_to_camera(uv_centers, kk, 1)
+        d_all = torch.as_tensor(dic_in['d'], dtype=torch.float32).reshape(-1)
+        n_pred = min(d_all.shape[0], xy_centers.shape[0])
+        xyz_all = xyz_from_distance(d_all[:n_pred], xy_centers[:n_pred]).double().numpy()
+        dist_all = np.sqrt(xyz_all[:, 0] ** 2 + xyz_all[:, 1] ** 2 + xyz_all[:, 2] ** 2)
+        bi_all = torch.as_tensor(dic_in['bi'], dtype=torch.float32).reshape(-1).double().numpy()
+        uv_s = np.rint(uv_shoulders.double().numpy()).astype(int)
+        uv_c = np.rint(uv_centers.double().numpy()).astype(int)
+        uv_h = np.rint(uv_heads.double().numpy()).astype(int)
+        has_yaw = 'yaw' in dic_in
+        has_aux = 'aux' in dic_in
+        if not has_yaw and all_idxs:
+            dic_out['angles']  # the reference touches the key before the KeyError (net.py:231)
+        for idx in all_idxs:
+            box = boxes[idx]
+            bi = float(bi_all[idx])
+            dic_out['boxes'].append(box)
+            dic_out['confs'].append(0.035 * (box[-1]) / (bi / float(dist_all[idx])))
+            dic_out['dds_pred'].append(float(d_all[idx]))
+            dic_out['stds_ale'].append(bi)
+            dic_out['stds_epi'].append(float(dic_in['epi'][idx]))
+            dic_out['xyz_pred'].append(xyz_all[idx].tolist())
+            dic_out['uv_kps'].append(keypoints[idx])
+            dic_out['uv_centers'].append(uv_c[idx].tolist())
+            dic_out['uv_shoulders'].append(uv_s[idx].tolist())
+            dic_out['uv_heads'].append(uv_h[idx].tolist())
+            if not has_yaw:
+                continue
+            dic_out['angles'].append(float(dic_in['yaw'][0][idx]))
+            dic_out['angles_egocentric'].append(float(dic_in['yaw'][1][idx]))
+            if has_aux:
+                dic_out['aux'].append(float(dic_in['aux'][idx]))
+            else:
+                dic_out['aux']  # mono: the key exists and stays empty (reference net.py:237-240)
+        for idx, idx_gt in matches:
+            dd_real = dds_gt[idx_gt]
+            xyz_real = xyz_from_distance(float(dd_real), xy_centers[idx])
+            dic_out['dds_real'].append(dd_real)
+            dic_out['boxes_gt'].append(boxes_gt[idx_gt])
+            dic_out['xyz_real'].append(xyz_real.squeeze().tolist())
+        return dic_out
+
+    @staticmethod
+    def social_distance(dic_out, args):
+        """Delegates to the reference's rule engine (monoloco/activity.py:17-67) when the reference
+        package is importable; that O(n^2) host logic is out of this path's scope."""
+        from monoloco.activity import social_interactions  # pylint: disable=import-error
+        xz = [[xx[0], xx[2]] for xx in dic_out['xyz_pred']]
+        dic_out['social_distance'] = [bool(social_interactions(idx, xz, dic_out['angles'], dic_out['dds_pred'],
+                                                               stds=dic_out['stds_ale'],
+                                                               threshold_prob=args.threshold_prob,
+                                                               threshold_dist=args.threshold_dist, radii=args.radii))
+                                      for idx, _ in enumerate(dic_out['xyz_pred'])]
+        return dic_out
+
+    @staticmethod
+    def raising_hand(dic_out, keypoints):
+        from monoloco.activity import is_raising_hand  # pylint: disable=import-error
+        dic_out['raising_hand'] = [is_raising_hand(keypoint) for keypoint in keypoints]
+        return dic_out

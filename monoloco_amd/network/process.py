@@ -1,0 +1,193 @@
+"""Host mirror of ``monoloco.network.process`` for the keypoint->3D path.
+
+Same names, argument meaning, return types and side effects as the reference
+(monoloco/network/process.py); the JSON/list helpers are plain host Python (as in the
+reference), every tensor computation runs in the HIP kernels behind the C ABI.
+"""
+import json
+import logging
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from .. import engine
+from .._lib import OUT_COLS as _C
+
+logger = logging.getLogger(__name__)
+
+SENSOR_W_MM = 7.2  # nuScenes sensor size used by the 'custom' calibration (reference process.py:20-21)
+SENSOR_H_MM = 5.4
+
+
+# ----------------------------------------------------------------------------- host-side JSON helpers
+def prepare_pif_kps(kps_in):
+    """Flat [x0, y0, c0, x1, ...] (51) -> [[x...], [y...], [c...]] (reference process.py:210-218)."""
+    assert len(kps_in) % 3 == 0, "keypoints expected as a multiple of 3"
+    return [kps_in[0::3], kps_in[1::3], kps_in[2::3]]
+
+
+def preprocess_pifpaf(annotations, im_size=None, enlarge_boxes=True, min_conf=0.):
+    """OpenPifPaf annotations -> (boxes [x1,y1,x2,y2,conf], keypoints [3][17]) (reference
+    process.py:155-207).  Like the reference it edits each annotation's 'bbox' list IN PLACE and
+    appends the confidence to it.  With a 'score' key the bbox is (x, y, w, h) and grows by h/10,
+    w/5; without, it is already corners, conf = mean keypoint confidence and it grows by 1/7 of the
+    height and 1/3.5 of the width; `enlarge_boxes=False` halves the growth."""
+    boxes, keypoints = [], []
+    shrink = 1 if enlarge_boxes else 2
+    for ann in annotations:
+        kps = prepare_pif_kps(ann['keypoints'])
+        box = ann['bbox']
+        if 'score' in ann:
+            conf = ann['score']
+            dh = box[3] / (10 * shrink)
+            dw = box[2] / (5 * shrink)
+            box[2] += box[0]
+            box[3] += box[1]
+        else:
+            conf = float(np.mean(np.array(kps[2])))
+            dh = (box[3] - box[1]) / (7 * shrink)
+            dw = (box[2] - box[0]) / (3.5 * shrink)
+            assert dh > -5 and dw > -5, "Bounding box <=0"
+        box[0] -= dw
+        box[1] -= dh
+        box[2] += dw
+        box[3] += dh
+        if im_size is not None:
+            box[0] = max(0, box[0])
+            box[1] = max(0, box[1])
+            box[2] = min(box[2], im_size[0])
+            box[3] = min(box[3], im_size[1])
+        if conf >= min_conf:
+            box.append(conf)
+            boxes.append(box)
+            keypoints.append(kps)
+    return boxes, keypoints
+
+
+def load_calibration(calibration, im_size, focal_length=5.7):
+    """Intrinsic matrix as nested lists (reference process.py:70-86): 'custom' derives it from the
+    image size and a focal length in mm, otherwise intrinsics.yaml rescaled to im_size."""
+    if calibration == 'custom':
+        kk = [[im_size[0] * focal_length / SENSOR_W_MM, 0., im_size[0] / 2],
+              [0., im_size[1] * focal_length / SENSOR_H_MM, im_size[1] / 2],
+              [0., 0., 1.]]
+    else:
+        with open(os.path.join(os.path.dirname(os.path.realpath(__file__)), 'intrinsics.yaml')) as f:
+            cfg = yaml.safe_load(f)[calibration]
+        kk = cfg['intrinsics']
+        sx, sy = (size / orig for size, orig in zip(im_size, cfg['im_size']))
+        kk[0] = [el * sx for el in kk[0]]
+        kk[1] = [el * sy for el in kk[1]]
+    logger.info("Using %s calibration matrix", calibration)
+    return kk
+
+
+def factory_for_gt(path_gt, name=None):
+    """(ground-truth dict of image `name`, its K) from a names-*.json file (reference process.py:89-98)."""
+    assert os.path.exists(path_gt), "Ground-truth file not found"
+    with open(path_gt, 'r') as f:
+        dic_names = json.load(f)
+    return dic_names[name], dic_names[name]['K']
+
+
+# ----------------------------------------------------------------------------- tensor functions (HIP)
+def _home(x):
+    return x.device if isinstance(x, torch.Tensor) else torch.device('cpu')
+
+
+def preprocess_monoloco(keypoints, kk, zero_center=False):
+    """(m,3,17) pixel keypoints -> (m,34) normalised inputs at z = 10 m (reference process.py:47-67)."""
+    home = _home(keypoints)
+    x = engine.preprocess_mono(keypoints, kk.tolist() if isinstance(kk, torch.Tensor) else kk,
+                               device=home if home.type == 'cuda' else None, zero_center=zero_center)
+    return x.to(home)
+
+
+def preprocess_monstereo(keypoints, keypoints_r, kk):
+    """All-vs-all left x right rows [L_i, L_i - R_j] (reference process.py:25-44) -> (inputs, clusters)."""
+    home = _home(keypoints)
+    kk = kk.tolist() if isinstance(kk, torch.Tensor) else kk
+    dev = home if home.type == 'cuda' else None
+    xl = engine.preprocess_mono(keypoints, kk, device=dev)
+    xr = engine.preprocess_mono(keypoints_r, kk, device=xl.device)
+    rows = engine.stereo_pairs(xl, xr)
+    return rows.to(home), [xr.shape[0]] * xl.shape[0]
+
+
+def unnormalize_bi(loc):
+    """bi = exp(loc[:,1]) * loc[:,0] for loc (m,2) = (d, log b/d) (reference process.py:125-133)."""
+    assert loc.size()[1] == 2, "size of the output tensor should be (m, 2)"
+    home = loc.device
+    raw = torch.zeros((loc.shape[0], 9), dtype=torch.float32, device=loc.device)
+    raw[:, 2:4] = loc
+    out, _ = engine.extract_outputs_device(raw.to(engine._require_cuda(home if home.type == 'cuda' else None)))
+    return out[:, _C['bi']:_C['bi'] + 1].to(home)
+
+
+def packed_to_dict(out, n_cols, home=torch.device('cpu')):
+    """The (m,16) packed device result -> the reference's extract_outputs dictionary of (m,k) tensors,
+    in the reference's key order (process.py:240-278)."""
+    o = out.to(home)
+    dic = {'h': o[:, 8:9].clone(), 'w': o[:, 9:10].clone(), 'l': o[:, 10:11].clone(),
+           'ori': o[:, 12:14].clone()}
+    if n_cols == 10:
+        dic['aux'] = o[:, 7:8].clone()
+    dic['bi'] = o[:, 4:5].clone()
+    dic['xyzd'] = o[:, 0:4].clone()
+    dic['d'] = o[:, 3:4].clone()
+    dic['yaw'] = (o[:, 5:6].clone(), o[:, 6:7].clone())
+    return dic
+
+
+def extract_outputs(outputs, tasks=()):
+    """Raw network rows (m, 9|10) -> processed dictionary, or the raw per-task slices when `tasks` is
+    given (reference process.py:231-278).  The dictionary tensors are detached CPU tensors."""
+    slices = {'x': outputs[:, 0:1], 'y': outputs[:, 1:2], 'd': outputs[:, 2:4], 'h': outputs[:, 4:5],
+              'w': outputs[:, 5:6], 'l': outputs[:, 6:7], 'ori': outputs[:, 7:9]}
+    if outputs.shape[1] == 10:
+        slices['aux'] = outputs[:, 9:10]
+    if len(tasks) >= 1:
+        assert isinstance(tasks, tuple), "tasks need to be a tuple"
+        return [slices[task] for task in tasks]
+    dev = engine._require_cuda(outputs.device if outputs.is_cuda else None)
+    out, _ = engine.extract_outputs_device(outputs.detach().to(dev))
+    return packed_to_dict(out, outputs.shape[1])
+
+
+def extract_labels_aux(labels, tasks=None):
+    """reference process.py:281-290."""
+    dic = {'aux': labels[:, 0:1]}
+    if tasks is not None:
+        assert isinstance(tasks, tuple), "tasks need to be a tuple"
+        return [dic[task] for task in tasks]
+    return {key: el.detach().cpu() for key, el in dic.items()}
+
+
+def extract_labels(labels, tasks=None):
+    """Label columns theta, psi, z, d, h, w, l, sin, cos, yaw, aux (reference process.py:293-304)."""
+    dic = {'x': labels[:, 0:1], 'y': labels[:, 1:2], 'z': labels[:, 2:3], 'd': labels[:, 3:4],
+           'h': labels[:, 4:5], 'w': labels[:, 5:6], 'l': labels[:, 6:7], 'ori': labels[:, 7:9],
+           'aux': labels[:, 10:11]}
+    if tasks is not None:
+        assert isinstance(tasks, tuple), "tasks need to be a tuple"
+        return [dic[task] for task in tasks]
+    return {key: el.detach().cpu() for key, el in dic.items()}
+
+
+def cluster_outputs(outputs, clusters):
+    """(ml*mr, C) -> (ml, mr, C) view; clusters == 0 means 'no right keypoints' (reference
+    process.py:307-316)."""
+    if clusters == 0:
+        clusters = max(1, round(outputs.shape[0] / 2))
+    assert outputs.shape[0] % clusters == 0, "Unexpected number of inputs"
+    return outputs.view(-1, clusters, outputs.shape[1])
+
+
+def filter_outputs(outputs):
+    """Per left person keep the pair rows whose aux logit (last column) equals the row maximum; exact
+    ties keep several rows (reference process.py:319-327).  Returns (rows, mask)."""
+    val = outputs[:, :, -1]
+    mask = val >= val.max(dim=1, keepdim=True).values  # index selection only, no path arithmetic
+    return outputs[mask], mask

@@ -1,0 +1,236 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference; the GPU box never sees it).  The
+reference is imported read-only with stub modules for its unused heavy imports (torchvision is
+imported at monoloco/network/process.py:9 but only used by image_transform).  Nothing from the
+reference is copied: this script calls it and stores inputs/outputs as .npz / .json fixtures.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import types
+
+os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+for name in ('torchvision', 'torchvision.transforms'):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import synth  # noqa: E402
+from monoloco.network import Loco, load_calibration, preprocess_pifpaf  # noqa: E402
+from monoloco.network.architectures import LocoModel  # noqa: E402
+from monoloco.network.process import preprocess_monoloco, preprocess_monstereo  # noqa: E402
+from monoloco.train import Trainer  # noqa: E402
+from monoloco.utils import get_keypoints, pixel_to_camera, xyz_from_distance  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def np_sd(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def ref_model(sd, in_f, out_f, hidden, dtype=torch.float32):
+    m = LocoModel(in_f, out_f, hidden, device='cpu')
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    m.eval()
+    return m.to(dtype)
+
+
+def train(mode, hidden, epochs, tmp):
+    """The reference's own fixture training (tests/test_train_{mono,stereo}.py: lr 0.001, -e 10 / 20)."""
+    args = argparse.Namespace(mode=mode, joints=os.path.join(REF, 'tests', 'sample_joints-kitti-%s.json' % mode),
+                              epochs=epochs, no_save=True, print_loss=False, lr=0.001, sched_step=30,
+                              sched_gamma=0.98, hidden_size=hidden, n_stage=3, r_seed=1, auto_tune_mtl=False,
+                              out=os.path.join(tmp, 'x.pkl'), bs=512, dropout=0.2)
+    tr = Trainer(args)
+    tr.train()
+    return {k: v.clone() for k, v in tr.model.state_dict().items()}
+
+
+def dic_to_np(dic, prefix):
+    out = {}
+    for k, v in dic.items():
+        if k == 'yaw':
+            out[prefix + 'yaw_pred'] = v[0].numpy()
+            out[prefix + 'yaw_ego'] = v[1].numpy()
+        elif k == 'epi':
+            out[prefix + 'epi'] = np.asarray(v, dtype=np.float32)
+        else:
+            out[prefix + k] = v.numpy()
+    return out
+
+
+def geometry(kps, kk, d, bi, conf):
+    """The per-person geometry of Loco.post_process, through the reference's own functions."""
+    uv_c = get_keypoints(kps, mode='center')
+    xy_c = pixel_to_camera(uv_c, kk, 1)
+    xyz = xyz_from_distance(d, xy_c)
+    dist = torch.sqrt((xyz.double() ** 2).sum(1))
+    cf = 0.035 * torch.as_tensor(conf).double() / (bi.reshape(-1).double() / dist)
+    return xyz.numpy(), cf.numpy()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    tmp = '/tmp/make_golden'
+    os.makedirs(tmp, exist_ok=True)
+    torch.set_num_threads(8)
+    g = {}
+
+    # ---------------------------------------------------------------- weights
+    sd_a = synth.make_state_dict(1, 34, 9, 1024)           # W-A mono  (seeded synthetic, 1024)
+    sd_as = synth.make_state_dict(3, 68, 10, 1024)         # W-A stereo
+    g['synth_checksum_mono'] = np.float64(synth.checksum(sd_a))
+    g['synth_checksum_stereo'] = np.float64(synth.checksum(sd_as))
+    sd_b = np_sd(train('mono', 256, 10, tmp))              # W-B mono  (reference fixture training, 256)
+    sd_bs = np_sd(train('stereo', 256, 20, tmp))           # W-B stereo
+    np.savez(os.path.join(OUT, 'ckpt_mono_h256.npz'), **sd_b)
+    np.savez(os.path.join(OUT, 'ckpt_stereo_h256.npz'), **sd_bs)
+
+    # ---------------------------------------------------------------- fixture poses (sample_joints-*.json)
+    dj = json.load(open(os.path.join(REF, 'tests', 'sample_joints-kitti-mono.json')))
+    kps = torch.tensor(dj['train']['kps'] + dj['val']['kps'])[:, 0]        # (500, 3, 17)
+    x_fix = torch.tensor(dj['train']['X'] + dj['val']['X'])               # (500, 34) stored by the reference prep
+    ks = []
+    for k in dj['train']['K'] + dj['val']['K']:
+        kt = torch.tensor(k)
+        if not any(torch.equal(kt, u) for u in ks):
+            ks.append(kt)
+    g['mono_kps'] = kps.numpy()
+    g['mono_x_fixture'] = x_fix.numpy()
+    g['mono_unique_k'] = torch.stack(ks).numpy()
+    # which K reproduces each fixture row bit-exactly (the data pin of the pre-process)
+    which = np.full(len(kps), -1)
+    for i, k in enumerate(ks):
+        hit = (preprocess_monoloco(kps, k) == x_fix).all(1).numpy()
+        which[(which < 0) & hit] = i
+    assert (which >= 0).all()
+    g['mono_k_index'] = which
+    kk = synth.KITTI_K
+    g['kk'] = np.asarray(kk, dtype=np.float64)
+    conf = np.linspace(0.2, 1.0, len(kps)).astype(np.float32)
+    g['mono_conf'] = conf
+    for tag, sd, hidden in (('A', sd_a, 1024), ('B', sd_b, 256)):
+        with torch.no_grad():
+            x = preprocess_monoloco(kps, torch.tensor(kk))
+            net = Loco(model=ref_model(sd, 34, 9, hidden), mode='mono', linear_size=hidden)
+            dic = net.forward(kps.tolist(), kk)
+            raw = net.model(x)
+            raw64 = ref_model(sd, 34, 9, hidden, torch.float64)(
+                preprocess_monoloco(kps.double(), torch.tensor(kk, dtype=torch.float64)))
+        g.update(dic_to_np(dic, 'mono_%s_' % tag))
+        g['mono_%s_raw' % tag] = raw.numpy()
+        g['mono_%s_raw64' % tag] = raw64.numpy()
+        xyz, cf = geometry(kps, kk, dic['d'], dic['bi'], conf)
+        g['mono_%s_xyz_pred' % tag] = xyz
+        g['mono_%s_conf' % tag] = cf
+        if tag == 'A':
+            g['mono_x_kitti'] = x.numpy()
+
+    # ---------------------------------------------------------------- stereo fixture pairs
+    ds = json.load(open(os.path.join(REF, 'tests', 'sample_joints-kitti-stereo.json')))
+    kps_s = torch.tensor(ds['train']['kps'] + ds['val']['kps'])[:, 0]     # (556, 3, 34): left 17 | right 17
+    x_s = torch.tensor(ds['train']['X'] + ds['val']['X'])                 # (556, 68)
+    kl, kr = kps_s[:, :, :17].contiguous(), kps_s[:, :, 17:].contiguous()
+    ks_s = []
+    for k in ds['train']['K'] + ds['val']['K']:
+        kt = torch.tensor(k)
+        if not any(torch.equal(kt, u) for u in ks_s):
+            ks_s.append(kt)
+    which = np.full(len(kl), -1)
+    for i, k in enumerate(ks_s):
+        xl, xr = preprocess_monoloco(kl, k), preprocess_monoloco(kr, k)
+        hit = (torch.cat((xl, xl - xr), 1) == x_s).all(1).numpy()
+        which[(which < 0) & hit] = i
+    g['stereo_kps_l'] = kl.numpy()
+    g['stereo_kps_r'] = kr.numpy()
+    g['stereo_x_fixture'] = x_s.numpy()
+    g['stereo_unique_k'] = torch.stack(ks_s).numpy()
+    g['stereo_k_index'] = which
+    for tag, sd, hidden in (('A', sd_as, 1024), ('B', sd_bs, 256)):
+        with torch.no_grad():
+            raw = ref_model(sd, 68, 10, hidden)(x_s)
+            raw64 = ref_model(sd, 68, 10, hidden, torch.float64)(x_s.double())
+        g['stereo_%s_raw_fixture' % tag] = raw.numpy()
+        g['stereo_%s_raw64_fixture' % tag] = raw64.numpy()
+        # all-vs-all through Loco.forward: 40 left x 7 right fixture poses
+        nl, nr = 40, 7
+        with torch.no_grad():
+            net = Loco(model=ref_model(sd, 68, 10, hidden), mode='stereo', linear_size=hidden)
+            dic = net.forward(kl[:nl].tolist(), kk, keypoints_r=kr[:nr].tolist())
+            inputs, _ = preprocess_monstereo(kl[:nl], kr[:nr], torch.tensor(kk))
+            raw_all = net.model(inputs)
+        g.update(dic_to_np(dic, 'stereo_%s_ava_' % tag))
+        g['stereo_%s_ava_raw_all' % tag] = raw_all.numpy()
+        if tag == 'A':
+            g['stereo_ava_inputs'] = inputs.numpy()
+            # no right keypoints: right := first left pose (net.py:115-116)
+            with torch.no_grad():
+                dic0 = net.forward(kl[:5].tolist(), kk)
+            g.update(dic_to_np(dic0, 'stereo_A_noright_'))
+    g['stereo_ava_nl_nr'] = np.array([40, 7])
+
+    np.savez_compressed(os.path.join(OUT, 'golden_path.npz'), **g)
+
+    # ---------------------------------------------------------------- C1: the pifpaf fixture image
+    ann = json.load(open(os.path.join(REF, 'tests', '002282.png.pifpaf.json')))
+    json.dump(ann, open(os.path.join(OUT, 'pifpaf_002282.json'), 'w'))
+    c1 = {}
+    for name, kwargs in (('predict', dict(im_size=(1238, 374), enlarge_boxes=False)),
+                         ('default', dict(im_size=None)), ('eval', dict(im_size=(1242, 374))),
+                         ('minconf', dict(im_size=(1238, 374), min_conf=0.55))):
+        boxes, kpl = preprocess_pifpaf(copy.deepcopy(ann), **kwargs)
+        c1['pre_' + name] = {'boxes': boxes, 'keypoints': kpl}
+    # a score-keyed annotation (bbox as x, y, w, h)
+    ann_s = copy.deepcopy(ann[:3])
+    for i, a in enumerate(ann_s):
+        b = a['bbox']
+        a['bbox'] = [b[0], b[1], b[2] - b[0], b[3] - b[1]]
+        a['score'] = 0.5 + 0.1 * i
+    boxes, kpl = preprocess_pifpaf(copy.deepcopy(ann_s), im_size=(1238, 374))
+    c1['pre_score'] = {'input': ann_s, 'boxes': boxes, 'keypoints': kpl}
+    c1['calib'] = {'kitti_1238_374': load_calibration('kitti', (1238, 374)),
+                   'kitti_1242_375': load_calibration('kitti', (1242, 375)),
+                   'custom_1920_1080': load_calibration('custom', (1920, 1080), focal_length=5.7),
+                   'nuscenes_1600_900': load_calibration('nuscenes', (1600, 900))}
+    boxes, kpl = preprocess_pifpaf(copy.deepcopy(ann), im_size=(1238, 374), enlarge_boxes=False)
+    kk1 = load_calibration('kitti', (1238, 374))
+    c1np = {}
+    for tag, sd, hidden in (('A', sd_a, 1024), ('B', sd_b, 256)):
+        net = Loco(model=ref_model(sd, 34, 9, hidden), mode='mono', linear_size=hidden)
+        dic = net.forward(kpl, kk1)
+        c1np.update(dic_to_np(dic, 'fwd_%s_' % tag))
+        pp = Loco.post_process(dic, boxes, kpl, kk1)
+        c1['post_%s' % tag] = dict(pp)
+        # with ground truth: fake gt = a few of the detections' own boxes, shuffled distances
+        dic_gt = {'boxes': [boxes[i][:4] for i in (3, 0, 7, 12)],
+                  'ys': [[0, 0, 0, 10.0 + 2 * i] for i in range(4)]}
+        c1['post_gt_%s' % tag] = dict(Loco.post_process(dic, boxes, kpl, kk1, dic_gt=dic_gt))
+        c1['dic_gt'] = dic_gt
+    np.savez_compressed(os.path.join(OUT, 'golden_c1.npz'), **c1np)
+    json.dump(c1, open(os.path.join(OUT, 'golden_c1.json'), 'w'))
+
+    # the reference's own unit test of this path (tests/test_utils.py:18-25): exact linearity in z_met
+    uv = [1000., 400.]
+    a = pixel_to_camera(uv, kk, 1)[0] * 10
+    b = pixel_to_camera(uv, kk, 10)[0]
+    assert a == b
+    print('golden files written to', OUT)
+    for f in sorted(os.listdir(OUT)):
+        print('  %-28s %8.1f KiB' % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
+
+
+if __name__ == '__main__':
+    main()

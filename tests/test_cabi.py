@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a CPU-only box and exports exactly what include/monoloco_hip.h declares."""
+import ctypes
+import os
+import re
+
+from monoloco_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'monoloco_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ml_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_exported_and_bound(hip_lib):
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(hip_lib, n), "library does not export %s" % n
+        assert n in _lib.SIGNATURES, "python binding lacks %s" % n
+    assert sorted(_lib.SIGNATURES) == names, "binding declares symbols the header does not"
+
+
+def test_version_and_error_string(hip_lib):
+    assert hip_lib.ml_version() >= 100
+    h = ctypes.c_void_p()
+    assert hip_lib.ml_loco_create(34, 1000, 9, 3, ctypes.byref(h)) == 4          # ML_ERR_SHAPE
+    assert b'multiple of 256' in hip_lib.ml_last_error()
+    assert hip_lib.ml_loco_create(34, 256, 9, 3, None) == 1                      # ML_ERR_ARG
+    assert hip_lib.ml_loco_create(34, 256, 9, 3, ctypes.byref(h)) == 0
+    assert hip_lib.ml_loco_finalize(h, 0, _lib.ML_FLAG_HOST_ONLY) == 3           # tensors missing: ML_ERR_STATE
+    assert b'never set' in hip_lib.ml_last_error()
+    assert hip_lib.ml_loco_reserve(h, 10) == 3                                   # not finalized
+    assert hip_lib.ml_loco_destroy(h) == 0
+
+
+def test_no_fallback_without_gpu():
+    """On a box without a HIP device the product path must fail loudly, not fall back."""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from monoloco_amd import engine
+    from monoloco_amd.network import Loco
+    from monoloco_amd.network.process import preprocess_monoloco
+    import synth
+    with pytest.raises(_lib.MonolocoHipError):
+        preprocess_monoloco(torch.zeros((2, 3, 17)), synth.KITTI_K)
+    with pytest.raises(_lib.MonolocoHipError):
+        engine.LocoEngine({k: torch.tensor(v) for k, v in synth.make_state_dict(1, hidden=256).items()})
+    with pytest.raises(_lib.MonolocoHipError):
+        Loco(model=None, mode='mono')
+
+
+def test_product_never_imports_oracle():
+    """Nothing under monoloco_amd/ may import, call or execute the oracle."""
+    pkg = os.path.join(ROOT, 'monoloco_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.h', '.hip', '.cpp')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in txt.replace('no oracle', ''), os.path.join(dirpath, f)

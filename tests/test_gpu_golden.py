@@ -1,0 +1,241 @@
+"""-m gpu: the HIP path (through the C ABI and the reference-shaped Python surface) against the golden
+vectors recorded from the real reference, plus size-independent properties at the full batch size."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TOL = 1e-4  # the north-star bar: abs deviation on (x, y, z, d, sigma) and on the raw outputs
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return dict(np.load(os.path.join(G, 'golden_path.npz')))
+
+
+@pytest.fixture(scope='module')
+def c1():
+    return json.load(open(os.path.join(G, 'golden_c1.json'))), dict(np.load(os.path.join(G, 'golden_c1.npz')))
+
+
+def _weights(tag, mode):
+    if tag == 'A':
+        sd = synth.make_state_dict(1, 34, 9, 1024) if mode == 'mono' else synth.make_state_dict(3, 68, 10, 1024)
+    else:
+        sd = dict(np.load(os.path.join(G, 'ckpt_%s_h256.npz' % mode)))
+    return {k: torch.tensor(v) for k, v in sd.items()}
+
+
+def _model(tag, mode):
+    from monoloco_amd.network.architectures import LocoModel
+    sd = _weights(tag, mode)
+    m = LocoModel(68 if mode == 'stereo' else 34, 10 if mode == 'stereo' else 9, sd['w1.weight'].shape[0])
+    m.load_state_dict(sd)
+    return m
+
+
+def test_preprocess_bit_exact_on_fixture_rows(hip_lib, cuda_device, gold):
+    """Data pin of the reference's fixtures: X == preprocess_monoloco(kps, K), bit for bit, from the HIP kernel."""
+    from monoloco_amd.network.process import preprocess_monoloco, preprocess_monstereo
+    kps = torch.tensor(gold['mono_kps'])
+    for i, k in enumerate(gold['mono_unique_k']):
+        rows = gold['mono_k_index'] == i
+        if rows.any():
+            x = preprocess_monoloco(kps[rows], k.tolist())
+            assert x.device.type == 'cpu'
+            assert torch.equal(x, torch.tensor(gold['mono_x_fixture'][rows]))
+    x = preprocess_monoloco(kps.to(cuda_device), synth.KITTI_K)
+    assert x.is_cuda and torch.equal(x.cpu(), torch.tensor(gold['mono_x_kitti']))
+    nl, nr = gold['stereo_ava_nl_nr']
+    rows, clusters = preprocess_monstereo(torch.tensor(gold['stereo_kps_l'][:nl]), torch.tensor(gold['stereo_kps_r'][:nr]),
+                                          synth.KITTI_K)
+    assert clusters == [int(nr)] * int(nl)
+    assert torch.equal(rows, torch.tensor(gold['stereo_ava_inputs']))
+
+
+def test_reference_unit_test_pixel_to_camera(hip_lib, cuda_device):
+    """reference tests/test_utils.py:18-25, run against the HIP-backed pixel_to_camera."""
+    from monoloco_amd.utils import pixel_to_camera
+    uv = [1000., 400.]
+    a = pixel_to_camera(uv, synth.KITTI_K, 1)[0] * 10
+    b = pixel_to_camera(uv, synth.KITTI_K, 10)[0]
+    assert torch.equal(a, b)
+
+
+def test_utils_against_oracle(hip_lib, cuda_device, gold):
+    from monoloco_amd import utils as U
+    from oracle import monoloco_oracle as O
+    kps = torch.tensor(gold['mono_kps'])
+    for mode in ('center', 'bottom', 'head', 'shoulder', 'hip', 'ankle'):
+        assert (U.get_keypoints(kps, mode) - O.get_keypoints(kps, mode)).abs().max() <= 1.3e-4  # 1 ulp at 1238 px
+    assert torch.equal(U.get_keypoints(kps, 'center'), O.get_keypoints(kps, 'center'))
+    assert U.get_keypoints(kps[0], 'center').shape == (1, 2)
+    uv = O.get_keypoints(kps, 'center')
+    assert torch.equal(U.pixel_to_camera(uv, synth.KITTI_K, 1), O.pixel_to_camera(uv, synth.KITTI_K, 1))
+    assert torch.equal(U.pixel_to_camera(kps[:, 0:2, :], synth.KITTI_K, 10), O.pixel_to_camera(kps[:, 0:2, :], synth.KITTI_K, 10))
+    xy = O.pixel_to_camera(uv, synth.KITTI_K, 1)
+    d = torch.linspace(1, 40, len(kps))
+    assert (U.xyz_from_distance(d, xy) - O.xyz_from_distance(d, xy)).abs().max() <= 4e-6
+    assert (U.xyz_from_distance(7.5, xy[3]) - O.xyz_from_distance(7.5, xy[3])).abs().max() <= 1e-6
+    rtp = torch.stack((torch.linspace(0.2, 2.9, 50), torch.linspace(1.2, 1.9, 50), torch.linspace(1, 50, 50)), 1)
+    x_ref = rtp[:, 2] * torch.sin(rtp[:, 1]) * torch.cos(rtp[:, 0])
+    assert (U.to_cartesian(rtp, 'x')[:, 0] - x_ref).abs().max() <= 1e-5
+    yaw = torch.linspace(-3, 3, 50).view(-1, 1)
+    xyz = torch.stack((torch.linspace(-5, 5, 50), torch.ones(50), torch.linspace(1, 30, 50)), 1)
+    ego = yaw + torch.atan2(xyz[:, 0], xyz[:, 2]).view(-1, 1)
+    ego = torch.where(ego > np.pi, ego - 2 * np.pi, ego)
+    ego = torch.where(ego < -np.pi, ego + 2 * np.pi, ego)
+    assert (U.back_correct_angles(yaw, xyz) - ego).abs().max() <= 1e-6
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_fixture_poses_vs_reference(hip_lib, cuda_device, gold, tag):
+    """500 real KITTI poses of the reference's fixture: raw outputs and the parity tensor vs the reference."""
+    from monoloco_amd import engine
+    p = 'mono_%s_' % tag
+    eng = engine.LocoEngine(_weights(tag, 'mono'), device=cuda_device)
+    out, xyzds, raw = eng.forward_mono(torch.tensor(gold['mono_kps']), engine.inverse_intrinsics(synth.KITTI_K),
+                                       box_conf=gold['mono_conf'], want_raw=True)
+    out, xyzds, raw = out.cpu().numpy(), xyzds.cpu().numpy(), raw.cpu().numpy()
+    e_raw = np.abs(raw - gold[p + 'raw']).max()
+    e_raw64 = np.abs(raw - gold[p + 'raw64']).max()
+    noise = np.abs(gold[p + 'raw'] - gold[p + 'raw64']).max()
+    ref_par = np.concatenate((gold[p + 'xyz_pred'], gold[p + 'd'], gold[p + 'bi']), 1)
+    e_par = np.abs(xyzds - ref_par).max()
+    print("fixture poses W-%s: raw vs ref fp32 %.2e, vs ref fp64 %.2e (ref fp32-vs-fp64 %.2e), xyzds %.2e"
+          % (tag, e_raw, e_raw64, noise, e_par))
+    assert e_raw <= TOL and e_par <= TOL
+    assert e_raw64 <= max(3 * noise, 2e-5)  # not worse than the reference's own rounding noise class
+    assert np.abs(out[:, 0:2] - gold[p + 'xyzd'][:, 0:2]).max() <= TOL
+    assert np.abs(out[:, 8:11] - np.concatenate((gold[p + 'h'], gold[p + 'w'], gold[p + 'l']), 1)).max() <= TOL
+    assert np.abs(out[:, 5] - gold[p + 'yaw_pred'][:, 0]).max() <= TOL
+    rel = np.abs(out[:, 11] / gold[p + 'conf'] - 1)
+    assert rel.max() <= 1e-4
+    # spherical z = sqrt(d^2-x^2-y^2) is ill-conditioned (amplification d/z): report against conditioning
+    z_ref, d_ref = gold[p + 'xyzd'][:, 2], gold[p + 'xyzd'][:, 3]
+    both = ~np.isnan(z_ref) & ~np.isnan(out[:, 2])
+    amp = (np.abs(d_ref) / np.maximum(z_ref, 1e-3))[both]
+    assert (np.abs(out[:, 2] - z_ref)[both] / np.maximum(amp, 1)).max() <= TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_loco_dropin_on_pifpaf_fixture(hip_lib, cuda_device, c1, tag):
+    """BASELINE config 1: the reference's call sequence (predict.py:226-236) on tests/002282.png.pifpaf.json."""
+    from monoloco_amd.network import Loco, load_calibration, preprocess_pifpaf
+    cj, cn = c1
+    ann = json.load(open(os.path.join(G, 'pifpaf_002282.json')))
+    boxes, kps = preprocess_pifpaf(copy.deepcopy(ann), im_size=(1238, 374), enlarge_boxes=False)
+    kk = load_calibration('kitti', (1238, 374))
+    net = Loco(model=_model(tag, 'mono'), mode='mono', device=cuda_device)
+    dic = net.forward(kps, kk)
+    assert list(dic.keys()) == ['h', 'w', 'l', 'ori', 'bi', 'xyzd', 'd', 'yaw', 'epi']
+    for key in ('h', 'w', 'l', 'ori', 'bi', 'd'):
+        t = dic[key]
+        assert t.device.type == 'cpu' and t.dtype == torch.float32 and tuple(t.shape) == cn['fwd_%s_%s' % (tag, key)].shape
+        assert np.abs(t.numpy() - cn['fwd_%s_%s' % (tag, key)]).max() <= TOL, key
+    assert np.abs(dic['xyzd'].numpy()[:, [0, 1, 3]] - cn['fwd_%s_xyzd' % tag][:, [0, 1, 3]]).max() <= TOL
+    assert np.abs(dic['yaw'][0].numpy() - cn['fwd_%s_yaw_pred' % tag]).max() <= TOL
+    assert dic['epi'] == [0.] * 16 and isinstance(dic['epi'], list)
+    pp = net.post_process(dic, boxes, kps, kk)
+    ref = cj['post_%s' % tag]
+    assert set(pp.keys()) == set(ref.keys())
+    assert pp['aux'] == [] and pp['gt'] == ref['gt'] and pp['boxes'] == ref['boxes'] and pp['uv_kps'] == ref['uv_kps']
+    for key in ('uv_centers', 'uv_shoulders', 'uv_heads'):
+        assert pp[key] == ref[key], key
+    for key in ('dds_pred', 'stds_ale', 'xyz_pred', 'angles'):
+        assert np.abs(np.array(pp[key]) - np.array(ref[key])).max() <= TOL, key
+    assert np.abs(np.array(pp['confs']) / np.array(ref['confs']) - 1).max() <= 1e-4
+    assert pp['stds_epi'] == ref['stds_epi']
+    # with ground truth (IoU matching, re-ordering, xyz_real)
+    ppg = net.post_process(dic, boxes, kps, kk, dic_gt=cj['dic_gt'])
+    refg = cj['post_gt_%s' % tag]
+    assert ppg['gt'] == refg['gt'] and ppg['boxes'] == refg['boxes'] and ppg['boxes_gt'] == refg['boxes_gt']
+    assert ppg['dds_real'] == refg['dds_real']
+    assert np.abs(np.array(ppg['xyz_real']) - np.array(refg['xyz_real'])).max() <= 1e-5
+    assert np.abs(np.array(ppg['xyz_pred']) - np.array(refg['xyz_pred'])).max() <= TOL
+    # empty input and the no-prediction branch
+    assert net.forward([], kk) is None
+    assert dict(net.post_process(None, [], [], kk)) == {}
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_stereo_vs_reference(hip_lib, cuda_device, gold, tag):
+    from monoloco_amd import engine
+    from monoloco_amd.network import Loco
+    p = 'stereo_%s_' % tag
+    eng = engine.LocoEngine(_weights(tag, 'stereo'), device=cuda_device)
+    raw = eng.forward_raw(torch.tensor(gold['stereo_x_fixture'])).cpu().numpy()
+    e = np.abs(raw - gold[p + 'raw_fixture']).max()
+    noise = np.abs(gold[p + 'raw_fixture'] - gold[p + 'raw64_fixture']).max()
+    print("stereo fixture rows W-%s: raw vs ref fp32 %.2e, vs fp64 %.2e (ref noise %.2e)"
+          % (tag, e, np.abs(raw - gold[p + 'raw64_fixture']).max(), noise))
+    assert e <= TOL
+    eng.close()
+    nl, nr = (int(v) for v in gold['stereo_ava_nl_nr'])
+    net = Loco(model=_model(tag, 'stereo'), mode='stereo', device=cuda_device)
+    dic = net.forward(gold['stereo_kps_l'][:nl].tolist(), synth.KITTI_K, keypoints_r=gold['stereo_kps_r'][:nr].tolist())
+    assert list(dic.keys()) == ['h', 'w', 'l', 'ori', 'aux', 'bi', 'xyzd', 'd', 'yaw', 'epi']
+    # pairs are selected by arg-max of the aux logit; a different pick is legitimate only within TOL of a tie
+    ref_all = gold[p + 'ava_raw_all'].reshape(nl, nr, 10)
+    gap = np.sort(ref_all[:, :, -1], 1)
+    clear = (gap[:, -1] - gap[:, -2]) > 2 * TOL
+    assert clear.sum() >= nl // 2
+    for key in ('d', 'bi', 'h', 'w', 'l', 'aux'):
+        assert np.abs(dic[key].numpy() - gold[p + 'ava_' + key])[clear].max() <= TOL, key
+    if tag == 'A':
+        dic0 = net.forward(gold['stereo_kps_l'][:5].tolist(), synth.KITTI_K)
+        assert np.abs(dic0['d'].numpy() - gold['stereo_A_noright_d']).max() <= TOL
+        assert len(dic0['epi']) == 5
+
+
+def test_stereo_exact_ties_keep_all_rows(hip_lib, cuda_device, gold):
+    """Two identical right poses tie exactly: the reference returns both pair rows per left person."""
+    from monoloco_amd.network import Loco
+    net = Loco(model=_model('B', 'stereo'), mode='stereo', device=cuda_device)
+    kl = gold['stereo_kps_l'][:6]
+    kr = np.stack((gold['stereo_kps_r'][0], gold['stereo_kps_r'][0]))
+    dic = net.forward(kl.tolist(), synth.KITTI_K, keypoints_r=kr.tolist())
+    assert dic['d'].shape[0] == 12
+    assert torch.equal(dic['d'][0::2], dic['d'][1::2])
+
+
+def test_full_batch_properties(hip_lib, cuda_device):
+    """BASELINE config 2 size (65536 persons): rows are independent, so the result must be bit-identical
+    under any row permutation and under batching, and every row must equal the same row computed alone
+    in a small batch (checked on a sample against the small-batch path that the oracle tests pin)."""
+    from monoloco_amd import engine
+    m = 65536
+    eng = engine.LocoEngine({k: torch.tensor(v) for k, v in synth.make_state_dict(1).items()}, device=cuda_device,
+                            reserve_rows=m)
+    kinv = engine.inverse_intrinsics(synth.KITTI_K)
+    kps = torch.tensor(synth.make_keypoints(m, seed=9)).to(cuda_device)
+    conf = torch.rand(m, device=cuda_device)
+    out, xyzds, raw = eng.forward_mono(kps, kinv, box_conf=conf, want_raw=True)
+    out, xyzds, raw = out.clone(), xyzds.clone(), raw.clone()
+    assert torch.isfinite(raw).all() and torch.isfinite(xyzds).all()
+    perm = torch.randperm(m, device=cuda_device)
+    out_p, xyzds_p, raw_p = eng.forward_mono(kps[perm].contiguous(), kinv, box_conf=conf[perm].contiguous(), want_raw=True)
+    assert torch.equal(raw_p, raw[perm]) and torch.equal(xyzds_p, xyzds[perm])
+    assert torch.equal(out_p.nan_to_num(), out[perm].nan_to_num())
+    sub = slice(12345, 12345 + 777)
+    out_s, xyzds_s, raw_s = eng.forward_mono(kps[sub].contiguous(), kinv, box_conf=conf[sub].contiguous(), want_raw=True)
+    assert torch.equal(raw_s, raw[sub]) and torch.equal(xyzds_s, xyzds[sub])
+    # idempotence: same input, same bits
+    out2, xyzds2, _ = eng.forward_mono(kps, kinv, box_conf=conf)
+    assert torch.equal(xyzds2, xyzds)
+    # a CPU-checkable sample of the big batch against the oracle
+    from oracle import monoloco_oracle as O
+    idx = torch.arange(0, m, 97)[:600]
+    ref = O.forward_mono({k: torch.tensor(v) for k, v in synth.make_state_dict(1).items()}, kps[idx].cpu(),
+                         synth.KITTI_K, box_conf=conf[idx].cpu())
+    assert (xyzds[idx].cpu() - ref['xyzds']).abs().max().item() <= TOL
+    assert (raw[idx].cpu() - ref['raw']).abs().max().item() <= TOL
+    eng.close()
