@@ -74,7 +74,7 @@ def test_utils_against_oracle(hip_lib, cuda_device, gold):
     from oracle import monoloco_oracle as O
     kps = torch.tensor(gold['mono_kps'])
     for mode in ('center', 'bottom', 'head', 'shoulder', 'hip', 'ankle'):
-        assert (U.get_keypoints(kps, mode) - O.get_keypoints(kps, mode)).abs().max() <= 1.3e-4  # 1 ulp at 1238 px
+        assert (U.get_keypoints(kps, mode) - O.get_keypoints(kps, mode)).abs().max() <= 2.5e-4  # 2 ulp at 1238 px (mean order)
     assert torch.equal(U.get_keypoints(kps, 'center'), O.get_keypoints(kps, 'center'))
     assert U.get_keypoints(kps[0], 'center').shape == (1, 2)
     uv = O.get_keypoints(kps, 'center')
