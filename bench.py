@@ -118,7 +118,7 @@ def main():
         step()
     fence()
     if not args.no_profile:
-        eng.profile_begin(args.steps * eng.num_layers + 8)
+        eng.profile_begin(args.steps * eng.num_layers * 16 + 8)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -42,11 +42,14 @@ struct DenseParams {
     const char* x;      // [M_pad][K] line format
     const char* w;      // [N][K]     line format (pre-scaled)
     const float* bias;  // [N]
+    const float* bias_scaled;  // [N] bias * 2^e: dense_kernel_pp starts its accumulators there
     const char* res;    // [M_pad][N] line format or nullptr (may alias y: same tile, same threads)
     char* y;            // [M_pad][N] line format
     float descale;      // 2^-e
     int M_pad, N, K;    // M_pad % 256 == 0, N % 256 == 0, K % 32 == 0
     int relu;
+    int debug;          // bring-up/ablation bits (0 in production), see dense_kernel_pp.h
+    unsigned long long* trace;  // optional s_memtime trace [grid][8 waves][64], nullptr in production
 };
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
@@ -130,14 +133,14 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel(DenseParams p) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[it][jt][e] = 0.0f;
 
-    const int nk = p.K / 32;
-    issue(0, 0);
+    const int nk = (p.debug & 2) ? 0 : p.K / 32;
+    if (!(p.debug & 4)) issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         // one barrier per k-step: (a) this wave's and every other wave's DMA of stage kt has
         // landed (the compiler drains vmcnt before the barrier), (b) everybody is done reading
         // the other buffer, so the next stage may be streamed into it while we compute.
         __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nk && !(p.debug & 4)) issue(kt + 1, (kt + 1) & 1);
         const char* sb = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -170,6 +173,17 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel(DenseParams p) 
     // i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (weight row): 4 consecutive n per register quad.
     // Each wave transposes its tile through a private 16 KiB LDS region (32 persons x 512 B, 16-B
     // chunks XOR-swizzled by the person index) and writes full 128-B lines with 16-B stores.
+    if (p.debug & 1) {  // ablation: keep the accumulators live, store (almost) nothing
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s += acc[it][jt][e];
+        if (s == 123456.789f) p.y[tid] = 1;
+        return;
+    }
     char* region = smem + w * 16384;
     const int ml = lane & 31;
     const size_t yrowb = (size_t)p.N * 4;

@@ -1,0 +1,371 @@
+// dense_kernel_pp.h -- second generation of the dense layer: persistent workgroups + ping-pong
+// main loop + fully asynchronous epilogue.  Same math, tile shape (256 n x 256 m), memory format,
+// LDS stage layout and fragment addressing as dense_kernel.h; what changes is the schedule.
+//
+// Why (measured on MI355X, profiles/r01_ablation.md): with one workgroup-wide barrier per k-step both
+// waves of a SIMD sit in the same phase and the MFMA pipe idles while they wait for LDS; the epilogue's
+// HBM stores and residual loads overlap with nothing; every ordinary vector load in the epilogue makes
+// hipcc drain vmcnt(0) (stores included) because LDS-DMA is in flight; and an LDS-DMA instruction costs
+// its wave ~100 cycles of issue time, so eight of them in one phase make that phase twice as long as
+// the 768 MFMA cycles it is supposed to hide behind.
+//
+//  * persistent: grid = min(tiles, CUs); a workgroup walks tiles b, b+grid, ...  Stores are
+//    fire-and-forget, so the 256 KiB a tile writes drain while the next tile computes, and the next
+//    tile's first stage is requested BEFORE the epilogue runs.
+//  * ping-pong: the 8 waves form two groups (waves 0-3 / 4-7 = the two waves of each SIMD).  A wave
+//    alternates an L phase (12 ds_read_b128 of one k16 half-step + exactly 4 LDS-DMA instructions)
+//    and a C phase (its 24 MFMAs); group 1 runs one phase behind group 0, so on every SIMD one wave
+//    computes while the other reads LDS and feeds the DMA engine.  Phases are separated by raw
+//    s_barrier; all vmcnt waits are counted ones placed by hand (vmcnt retires in order).
+//  * epilogue per 32x32 MFMA tile through a private 4 KiB LDS scratch per wave (the 32 KiB the two
+//    stage buffers leave free).  No ordinary vector load: bias comes through the scalar path
+//    (s_load), residual lines by LDS-DMA into the stage-1 buffer, which is idle during the epilogue.
+#pragma once
+#include "dense_kernel.h"
+
+namespace mlk {
+
+constexpr int PP_LDS = DENSE_LDS + 8 * 4096;  // 160 KiB: 2 stages + 8 x 4 KiB epilogue scratch
+
+// debug bits (DenseParams::debug, env ML_DENSE_DEBUG; 0 in production):
+//   1 skip the epilogue (accumulators kept live)     2 skip the main loop      4 no stage DMA
+//   64 half the stage DMA (timing only)
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NSPLIT, bool RELU, bool RES>
+__global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = w >> 2;  // waves w and w+4 share a SIMD
+    const int wn = w & 1;    // 2 waves along n (128 weight rows each)
+    const int wm = w >> 1;   // 4 waves along m (64 persons each)
+
+    const int NT = p.N / BN;
+    const int ntiles = (p.M_pad / BM) * NT;
+    const int q = ntiles >> 3, r8 = ntiles & 7;
+    const size_t rowb = (size_t)p.K * 4;
+    const size_t yrowb = (size_t)p.N * 4;
+    const int nk = (p.debug & 2) ? 0 : p.K / 32;
+    const bool loads = !(p.debug & 4);
+
+    // ---- LDS-DMA duty: per stage a wave fetches 32 rows of X and 32 rows of W (4 instructions of 8
+    // rows each):   group 0: X rows   0..127 (wave j: 32j..) and W rows 128..255
+    //               group 1: X rows 128..255                 and W rows   0..127
+    // lane -> (row = base + lane/8, chunk pos = lane%8), source chunk = pos ^ ((row>>1)&7), which only
+    // depends on the parity of the instruction index (the LDS destination is lane-linear).
+    const int jw = w & 3;
+    const int xbase = (grp ? 128 : 0) + jw * 32, wbase = (grp ? 0 : 128) + jw * 32;
+    const unsigned goff_e = (unsigned)((lane >> 3) * (int)rowb + (((lane & 7) ^ (lane >> 4)) * 16));
+    const unsigned goff_o = (unsigned)((lane >> 3) * (int)rowb + (((lane & 7) ^ (4 + (lane >> 4))) * 16));
+    const unsigned row8 = (unsigned)(8 * (int)rowb);
+    auto issue4 = [&](const char* tile, int base, int lds_off, int kt) {
+        char* sb = smem + (kt & 1) * STAGE_BYTES + lds_off + base * LINE;
+        const char* src = tile + (size_t)base * rowb + (unsigned)kt * LINE;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            if ((p.debug & 64) && q4 >= 2) break;
+            glds16(src + ((q4 & 1) ? goff_o : goff_e) + q4 * row8, sb + q4 * 8 * LINE);
+        }
+    };
+
+    // ---- fragment addressing (as dense_kernel.h)
+    const int sw = (lane >> 1) & 7;
+    const int h = lane >> 5;
+    const int ml = lane & 31;
+    const int wrow = (wn * 128 + ml) * LINE;
+    const int xrow = TILE_BYTES + (wm * 64 + ml) * LINE;
+    int coff[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        coff[kk][0] = (((kk * 2 + h)) ^ sw) * 16;
+        coff[kk][1] = (((kk * 2 + h + 4)) ^ sw) * 16;
+    }
+    char* const scr = smem + DENSE_LDS + w * 4096;          // epilogue scratch of this wave
+    char* const resbuf = smem + STAGE_BYTES + w * 8192;      // residual landing zone (stage-1 buffer)
+
+    // virtual block id -> tile: the XCD-aware bijective map of dense_kernel.h
+    auto tile_of = [&](int vb, int& m0, int& n0) {
+        const int xcd = vb & 7, idx = vb >> 3;
+        const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+        const int mt = tile / NT, nt = tile - mt * NT;
+        m0 = mt * BM;
+        n0 = nt * BN;
+    };
+
+    int vb = blockIdx.x;
+    if (vb >= ntiles) return;
+    // optional timeline (bring-up builds only, -DML_DENSE_TRACE): slot ts of this wave <- s_memtime
+#ifdef ML_DENSE_TRACE
+    unsigned long long* const trc = p.trace ? p.trace + ((size_t)blockIdx.x * 8 + w) * 64 : nullptr;
+    int tslot = 0;
+    auto stamp = [&]() {
+        if (trc && tslot < 64) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) trc[tslot] = t;
+            ++tslot;
+        }
+    };
+#else
+    auto stamp = [&]() {};
+#endif
+    stamp();
+    int m0, n0;
+    tile_of(vb, m0, n0);
+    const char* wtile = p.w + (size_t)n0 * rowb;
+    const char* xtile = p.x + (size_t)m0 * rowb;
+    auto issueX = [&](int kt) { issue4(xtile, xbase, TILE_BYTES, kt); };
+    auto issueW = [&](int kt) { issue4(wtile, wbase, 0, kt); };
+    if (nk > 0 && loads) {
+        issueX(0);
+        issueW(0);
+    }
+    bool first = true;
+
+    while (true) {
+        // accumulators start at bias * 2^e (pre-scaled on the host, exact), so the epilogue needs no bias
+        // and no load: (bias*2^e + sum) * 2^-e.  Register r of MFMA tile `it` is weight row
+        // n = nbase + 32*it + (r&3) + 8*(r>>2) + 4*(lane>>5): one 16-byte load per (it, r>>2), straight into
+        // the accumulator registers (the vmcnt(0) hipcc puts behind them is harmless here: the stage-0
+        // DMA they queue behind was requested a whole epilogue ago).
+        f32x16 acc[4][2];
+        {
+            const char* bs = (const char*)(p.bias_scaled + n0 + wn * 128);  // wave-uniform
+            int il = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(il));  // lane id recomputed here: nothing lane-dependent stays live for this
+            const unsigned hoff = (unsigned)(il >> 5) * 16u;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *(const f32x4*)(bs + (it * 32 + g * 8) * 4 + hoff);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[it][0][g * 4 + e] = b4[e];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc[it][1] = acc[it][0];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // stage 0 of this tile was requested before the previous tile's epilogue stores (32 per wave);
+        // vmcnt retires in order, so "at most 32 outstanding" means that DMA has landed.
+        if (first) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        }
+        first = false;
+        stamp();      // [tile*6 + 1] stage 0 landed (this wave)
+        pp_barrier();
+        stamp();      // [+2] everybody's stage 0 landed
+
+        half8 whi[4], wlo[4], xhi[2], xlo[2];
+        auto load_frags = [&](const char* sb, int kk) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                whi[it] = *(const half8*)(sb + wrow + it * 32 * LINE + coff[kk][0]);
+                if (NSPLIT == 3) wlo[it] = *(const half8*)(sb + wrow + it * 32 * LINE + coff[kk][1]);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                xhi[jt] = *(const half8*)(sb + xrow + jt * 32 * LINE + coff[kk][0]);
+                if (NSPLIT == 3) xlo[jt] = *(const half8*)(sb + xrow + jt * 32 * LINE + coff[kk][1]);
+            }
+        };
+        auto compute = [&]() {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    if (NSPLIT == 3) {
+                        acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[it], xlo[jt], acc[it][jt], 0, 0, 0);
+                        acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[it], xhi[jt], acc[it][jt], 0, 0, 0);
+                    }
+                    acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[it], xhi[jt], acc[it][jt], 0, 0, 0);
+                }
+        };
+
+        // Phase p (after the tile-start barrier): group 0 reads half-step h in phase 2h and computes it in
+        // 2h+1; group 1 does the same one phase later.  Stage s (half-steps 2s, 2s+1) is read in phases
+        // 4s..4s+3 and its buffer previously held stage s-2, last read in phase 4s-5.  Its four quarters
+        // are requested in four consecutive L phases:
+        //   X rows 128.. : group 1, end of phase 4s-5 (after its own last reads of stage s-2)   window 5
+        //   X rows   0.. : group 0, phase 4s-4                                                  window 4
+        //   W rows   0.. : group 1, phase 4s-3                                                  window 3
+        //   W rows 128.. : group 0, phase 4s-2                                                  window 2
+        // and everything of stage s has landed by the end of phase 4s-1 (counted waits below).
+        if (grp == 0) {
+            for (int t = 0; t < nk; ++t) {
+                const char* sb = smem + (t & 1) * STAGE_BYTES;
+                const bool pre = loads && t + 1 < nk;
+                if (pre) issueX(t + 1);                        // phase 4t
+                load_frags(sb, 0);
+                pp_barrier();
+                compute();                                     // phase 4t+1
+                pp_barrier();
+                if (pre) issueW(t + 1);                        // phase 4t+2
+                load_frags(sb, 1);
+                pp_barrier();
+                compute();                                     // phase 4t+3
+                if (pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (t < 2) stamp();                            // [+3], [+4] end of k-step 0 / 1 incl. DMA wait
+                pp_barrier();
+            }
+            pp_barrier();  // group 1's last compute phase
+        } else {
+            if (loads && nk > 1) issueX(1);                    // phase 0 (this group has nothing else to do in it)
+            pp_barrier();
+            for (int t = 0; t < nk; ++t) {
+                const char* sb = smem + (t & 1) * STAGE_BYTES;
+                const bool pre = loads && t + 1 < nk;
+                if (pre) issueW(t + 1);                        // phase 4t+1
+                load_frags(sb, 0);
+                pp_barrier();
+                compute();                                     // phase 4t+2
+                pp_barrier();
+                load_frags(sb, 1);                             // phase 4t+3
+                const bool nxt = loads && t + 2 < nk;
+                if (nxt) {
+                    // stage t is now completely read (group 0 finished it a phase ago, our own reads are
+                    // drained here): its X rows 128.. can already be overwritten with stage t+2
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    issueX(t + 2);
+                }
+                if (pre) {
+                    if (nxt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (t < 2) stamp();
+                pp_barrier();
+                compute();                                     // phase 4t+4
+                pp_barrier();
+            }
+        }
+        // every wave has passed the same number of barriers; nobody reads the stage buffers any more
+        stamp();      // [+5] main loop done
+
+        // ---- epilogue of the finished tile, one 32 (n) x 32 (m) MFMA tile per pass
+        const int cur_m0 = m0, cur_n0 = n0;
+        const int nbase = cur_n0 + wn * 128;
+        auto line0_of = [&](int pass) {
+            const int jt = pass >> 2, it = pass & 3;
+            return (size_t)(cur_m0 + wm * 64 + jt * 32) * yrowb + (size_t)(nbase + it * 32) * 4;
+        };
+        // DMA of one pass' residual tile (32 rows x 128 B): lane -> (row = id/8, pos = id%8), source chunk
+        // pos ^ (row&7) so that the LDS image carries the same swizzle as the output scratch
+        // (addresses = wave-uniform 64-bit base + one 32-bit lane offset, made opaque per tile so that hipcc
+        // neither hoists 32 per-lane 64-bit addresses out of the tile loop nor spills them)
+        // lane id recomputed and made opaque: every lane-dependent epilogue address is derived from it HERE,
+        // per tile, instead of being hoisted out of the tile loop and kept live through the main loop
+        int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(elane));
+        const int eml = elane & 31, eh = elane >> 5;
+        const unsigned res_goff = (unsigned)((elane >> 3) * (int)yrowb + (((elane & 7) ^ ((elane >> 3) & 7)) * 16));
+        const unsigned st_off = (unsigned)((elane >> 3) * (int)yrowb + ((elane & 7) * 16));
+        const int scr_row = eml * LINE + eh * 8;                       // + ((chunk ^ (eml&7)) * 16)
+        const int rd_off = (elane >> 3) * LINE + (((elane & 7) ^ ((elane >> 3) & 7)) * 16);  // + qq*1024
+        auto fetch_res = [&](int pass) {
+            const char* src = p.res + line0_of(pass);
+            char* dst = resbuf + (pass & 1) * 4096;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) glds16(src + (size_t)(qq * 8) * yrowb + res_goff, dst + qq * 1024);
+        };
+        const bool has_res = RES && !(p.debug & 1);
+        if (has_res) fetch_res(0);  // ahead of the next tile's DMA so that it does not queue behind it
+
+        // ---- next tile: request its first stage now, it lands while the epilogue runs
+        vb += gridDim.x;
+        const bool more = vb < ntiles;
+        const bool pref = more && nk > 0 && loads;
+        if (more) {
+            tile_of(vb, m0, n0);
+            wtile = p.w + (size_t)n0 * rowb;
+            xtile = p.x + (size_t)m0 * rowb;
+            if (pref) {
+                issueX(0);
+                issueW(0);
+            }
+        }
+
+        if (p.debug & 1) {
+            float s = 0.f;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s += acc[it][jt][e];
+            if (s == 123456.789f) p.y[tid] = 1;
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int jt = pass >> 2, it = pass & 3;
+                const size_t line0 = line0_of(pass);
+                half4 rh[4], rl[4];
+                if (RES) {
+                    const char* rb = resbuf + (pass & 1) * 4096;
+                    if (pass + 1 < 8) fetch_res(pass + 1);  // one pass ahead, ahead of this pass's stores
+                    // wait for this pass' residual DMA: count the younger vector-memory operations
+                    if (pass == 0) {
+                        if (pref) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // 8 stage DMA + 4 res DMA
+                        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    } else if (pass < 7) {
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 4 stores + 4 res DMA
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // 4 stores
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        rh[g] = *(const half4*)(rb + scr_row + ((g ^ (eml & 7)) * 16));
+                        rl[g] = *(const half4*)(rb + scr_row + (((g + 4) ^ (eml & 7)) * 16));
+                    }
+                }
+                half4 oh[4], ol[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[it][jt][g * 4 + e] * p.descale;
+                        if (RELU) v = __builtin_fmaxf(v, 0.0f);
+                        if (RES) v += (float)rh[g][e] + (float)rl[g][e];
+                        _Float16 a, b;
+                        split_f16(v, a, b);
+                        oh[g][e] = a;
+                        ol[g][e] = b;
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *(half4*)(scr + scr_row + ((g ^ (eml & 7)) * 16)) = oh[g];
+                    *(half4*)(scr + scr_row + (((g + 4) ^ (eml & 7)) * 16)) = ol[g];
+                }
+                __builtin_amdgcn_wave_barrier();
+                f32x4 d[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) d[qq] = *(const f32x4*)(scr + rd_off + qq * 1024);
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)  // rows 8qq + lane/8, chunk lane%8
+                    *(f32x4*)(p.y + line0 + (size_t)(qq * 8) * yrowb + st_off) = d[qq];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);  // keep the passes apart: interleaving them costs registers
+                // the scratch is rewritten by the next pass only after these reads returned (in-order LDS);
+                // the residual buffer of this pass is re-filled by the DMA issued at the top of the next pass
+            }
+        }
+        stamp();      // [+6] epilogue issued
+        if (!more) break;
+    }
+}
+
+}  // namespace mlk

@@ -11,12 +11,14 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "dense_kernel.h"
+#include "dense_kernel_pp.h"
 #include "geom_kernels.h"
 #include "geom_ops.h"
 
@@ -113,6 +115,7 @@ struct DenseLayer {
     std::vector<uint16_t> packed;  // host image of d_w (kept only for host-only models)
     char* d_w = nullptr;      // device, line format (n, kpad), pre-scaled
     float* d_b = nullptr;     // device fp32 (n)
+    float* d_bs = nullptr;    // device fp32 (n): bias * 2^scale_pow2
     int src = 0, dst = 0;     // activation buffer ids: 0 = input lines, 1 = A, 2 = B
     int res = -1;             // residual buffer id or -1
 };
@@ -276,6 +279,11 @@ int upload_layer(ml_loco* h, DenseLayer& L) {
     if (rc) return rc;
     HIP_TRY(hipMemcpy(L.d_w, L.packed.data(), bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(L.d_b, L.b.data(), (size_t)L.n * 4, hipMemcpyHostToDevice));
+    rc = dev_alloc(h, &L.d_bs, (int64_t)L.n * 4);
+    if (rc) return rc;
+    std::vector<float> bs(L.n);
+    for (int i = 0; i < L.n; ++i) bs[i] = std::ldexp(L.b[i], L.scale_pow2);
+    HIP_TRY(hipMemcpy(L.d_bs, bs.data(), (size_t)L.n * 4, hipMemcpyHostToDevice));
     std::vector<uint16_t>().swap(L.packed);
     return ML_OK;
 }
@@ -333,12 +341,91 @@ mlk::Kinv make_kinv(const float* k) {
     return ki;
 }
 
-int launch_dense(int precision, const mlk::DenseParams& p, hipStream_t st) {
-    const int grid = (p.M_pad / mlk::BM) * (p.N / mlk::BN);
-    if (precision == ML_PREC_F16X2)
-        hipLaunchKernelGGL(mlk::dense_kernel<3>, dim3(grid), dim3(mlk::DENSE_THREADS), 0, st, p);
-    else
-        hipLaunchKernelGGL(mlk::dense_kernel<1>, dim3(grid), dim3(mlk::DENSE_THREADS), 0, st, p);
+int dense_debug_bits() {
+    static int bits = -1;
+    if (bits < 0) {
+        const char* e = getenv("ML_DENSE_DEBUG");
+        bits = e ? atoi(e) : 0;
+    }
+    return bits;
+}
+
+int dense_variant() {
+    // ML_DENSE_VARIANT=1 selects the first-generation kernel (one tile per workgroup, one barrier
+    // per k-step); default is the persistent ping-pong kernel.
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ML_DENSE_VARIANT");
+        v = e ? atoi(e) : 2;
+    }
+    return v;
+}
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// ML_DENSE_TRACE=<file>: every pp dense launch records per-wave s_memtime stamps, which are appended
+// to the file after a stream sync (bring-up tool; serialises the stream).
+int trace_after_launch(unsigned long long* buf, size_t n, int grid, const mlk::DenseParams& p, hipStream_t st) {
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<unsigned long long> host(n);
+    HIP_TRY(hipMemcpy(host.data(), buf, n * 8, hipMemcpyDeviceToHost));
+    FILE* f = fopen(getenv("ML_DENSE_TRACE"), "ab");
+    if (f) {
+        long long hdr[8] = {0x54524143, grid, p.M_pad, p.N, p.K, p.res ? 1 : 0, (long long)n, 0};
+        fwrite(hdr, 8, 8, f);
+        fwrite(host.data(), 8, n, f);
+        fclose(f);
+    }
+    return ML_OK;
+}
+
+int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st) {
+    mlk::DenseParams p = p_in;
+    p.debug = dense_debug_bits();
+    p.trace = nullptr;
+
+    const int tiles = (p.M_pad / mlk::BM) * (p.N / mlk::BN);
+    if (dense_variant() == 1) {
+        if (precision == ML_PREC_F16X2)
+            hipLaunchKernelGGL(mlk::dense_kernel<3>, dim3(tiles), dim3(mlk::DENSE_THREADS), 0, st, p);
+        else
+            hipLaunchKernelGGL(mlk::dense_kernel<1>, dim3(tiles), dim3(mlk::DENSE_THREADS), 0, st, p);
+    } else {
+        const int grid = tiles < num_cus() ? tiles : num_cus();
+        static unsigned long long* trace_buf = nullptr;
+        const size_t trace_n = (size_t)num_cus() * 8 * 64;
+        if (getenv("ML_DENSE_TRACE")) {
+            if (!trace_buf) HIP_TRY(hipMalloc((void**)&trace_buf, trace_n * 8));
+            HIP_TRY(hipMemsetAsync(trace_buf, 0, trace_n * 8, st));
+            p.trace = trace_buf;
+        }
+#define ML_PP(NS, RL, RS) hipLaunchKernelGGL((mlk::dense_kernel_pp<NS, RL, RS>), dim3(grid), dim3(mlk::DENSE_THREADS), 0, st, p)
+#define ML_PP_NS(NS)                                              \
+    do {                                                          \
+        if (p.relu) {                                             \
+            if (p.res) ML_PP(NS, true, true);                     \
+            else ML_PP(NS, true, false);                          \
+        } else {                                                  \
+            if (p.res) ML_PP(NS, false, true);                    \
+            else ML_PP(NS, false, false);                         \
+        }                                                         \
+    } while (0)
+        if (precision == ML_PREC_F16X2) ML_PP_NS(3);
+        else ML_PP_NS(1);
+#undef ML_PP_NS
+#undef ML_PP
+        if (p.trace) return trace_after_launch(trace_buf, trace_n, grid, p, st);
+    }
     HIP_TRY(hipGetLastError());
     return ML_OK;
 }
@@ -372,37 +459,61 @@ int launch_heads(const Head& hd, const char* act, int H, float* raw, int raw_str
     return ML_OK;
 }
 
+int chunk_rows_env() {
+    // ML_CHUNK_ROWS=n (multiple of 256): walk the batch in row chunks through ALL layers so that the
+    // two activation buffers of a chunk (2 x n x hidden x 4 B) stay resident in the 256 MiB Infinity
+    // Cache between layers.  0 = whole batch per layer.
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ML_CHUNK_ROWS");
+        v = e ? atoi(e) : 0;
+        if (v < 0) v = 0;
+        v = v / 256 * 256;
+    }
+    return v;
+}
+
 // Runs the dense chain + heads on `rows` network rows whose line-format input already sits in
 // buf[0]; leaves raw (rows, out_f) fp32 in raw_out.
 int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st) {
-    const int64_t m_pad = round_up64(rows, 256);
-    for (size_t li = 0; li < h->layers.size(); ++li) {
-        const DenseLayer& L = h->layers[li];
-        mlk::DenseParams p;
-        p.x = h->buf[L.src];
-        p.w = L.d_w;
-        p.bias = L.d_b;
-        p.res = L.res >= 0 ? h->buf[L.res] : nullptr;
-        p.y = h->buf[L.dst];
-        p.descale = std::ldexp(1.0f, -L.scale_pow2);
-        p.M_pad = (int)m_pad;
-        p.N = L.n;
-        p.K = L.kpad;
-        p.relu = L.relu;
-        const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
-        if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
-        int rc = launch_dense(h->precision, p, st);
-        if (rc) return rc;
-        if (timed) {
-            HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));
-            h->ev_layer[h->ev_used] = (int)li;
-            h->ev_used++;
-        }
-        for (const Head& hd : h->heads)
-            if (hd.after_layer == (int)li) {
-                rc = launch_heads(hd, h->buf[hd.src], h->hidden, raw_out, h->out_f, rows, st);
-                if (rc) return rc;
+    const int64_t m_pad_all = round_up64(rows, 256);
+    const int64_t chunk = chunk_rows_env() > 0 ? chunk_rows_env() : m_pad_all;
+    for (int64_t r0 = 0; r0 < m_pad_all; r0 += chunk) {
+        const int64_t m_pad = (m_pad_all - r0 < chunk) ? (m_pad_all - r0) : chunk;
+        const int64_t rows_here = (rows - r0 < m_pad) ? (rows - r0) : m_pad;
+        for (size_t li = 0; li < h->layers.size(); ++li) {
+            const DenseLayer& L = h->layers[li];
+            auto at = [&](int b) { return h->buf[b] + r0 * (int64_t)(b == 0 ? h->k0pad : h->hidden) * 4; };
+            mlk::DenseParams p;
+            p.x = at(L.src);
+            p.w = L.d_w;
+            p.bias = L.d_b;
+            p.bias_scaled = L.d_bs;
+            p.res = L.res >= 0 ? at(L.res) : nullptr;
+            p.y = at(L.dst);
+            p.descale = std::ldexp(1.0f, -L.scale_pow2);
+            p.M_pad = (int)m_pad;
+            p.N = L.n;
+            p.K = L.kpad;
+            p.relu = L.relu;
+            p.debug = 0;
+            p.trace = nullptr;
+            const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
+            if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
+            int rc = launch_dense(h->precision, p, st);
+            if (rc) return rc;
+            if (timed) {
+                HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));
+                h->ev_layer[h->ev_used] = (int)li;
+                h->ev_used++;
             }
+            if (rows_here > 0)
+                for (const Head& hd : h->heads)
+                    if (hd.after_layer == (int)li) {
+                        rc = launch_heads(hd, at(hd.src), h->hidden, raw_out + r0 * h->out_f, h->out_f, rows_here, st);
+                        if (rc) return rc;
+                    }
+        }
     }
     return ML_OK;
 }
@@ -611,6 +722,7 @@ int ml_loco_destroy(ml_loco* h) {
     for (auto& L : h->layers) {
         dev_free(L.d_w);
         dev_free(L.d_b);
+        dev_free(L.d_bs);
     }
     for (auto& hd : h->heads) {
         dev_free(hd.d_w);
@@ -860,6 +972,7 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
         p.x = xl;
         p.w = L.d_w;
         p.bias = L.d_b;
+        p.bias_scaled = L.d_bs;
         p.res = rl;
         p.y = res_dev ? rl : yl;  // exercises the in-place residual form the model uses
         p.descale = std::ldexp(1.0f, -L.scale_pow2);
@@ -867,6 +980,8 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
         p.N = n;
         p.K = L.kpad;
         p.relu = relu;
+        p.debug = 0;
+        p.trace = nullptr;
         rc = launch_dense(precision, p, st);
         if (!rc) {
             const int64_t groups = m * (n / 8);
@@ -881,6 +996,7 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
     dev_free(rl);
     dev_free(L.d_w);
     dev_free(L.d_b);
+    dev_free(L.d_bs);
     return rc;
 }
 
