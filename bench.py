@@ -51,6 +51,17 @@ def cpu_baseline(sd, kps_np, kk, budget_s):
                       "(torch CPU fp32, %d threads), %.1f s" % (reps, n, threads, t_tot)}
 
 
+def traffic_from_profiles(args):
+    """HBM bytes per dense launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
+    collected with rocprofv3 in separate runs of this very command; PMC cannot be read live).  None if the
+    committed measurement does not cover this configuration."""
+    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    if args.workload != 'mono' or args.precision != 'f16x2' or args.batch != 65536 or args.no_merge \
+            or not os.path.exists(path):
+        return None
+    return json.load(open(path))['hbm_bytes_per_launch']
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -154,8 +165,8 @@ def main():
             achieved = alg_flop / dense_s / 1e12
             line["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16_DENSE, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS_F16_DENSE, 4), "traffic": None,
-                "kernel": "mlk::dense_kernel<%d>" % (3 if args.precision == 'f16x2' else 1),
+                "frac": round(achieved / PEAK_TFLOPS_F16_DENSE, 4), "traffic": traffic_from_profiles(args),
+                "kernel": "mlk::dense_kernel_pp<%d,*,*>" % (3 if args.precision == 'f16x2' else 1),
                 "launches": prof['launches'], "avg_launch_ms": round(prof['total_ms'] / prof['launches'], 5),
                 "per_layer_avg_ms": [round(a / max(n, 1), 5) for a, n in zip(prof['per_layer_ms'], prof['per_layer_n'])],
                 "note": "achieved = algorithmic FLOP of the reference layer structure (%d/row) / summed dense-kernel "

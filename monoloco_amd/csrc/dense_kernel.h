@@ -50,6 +50,9 @@ struct DenseParams {
     int relu;
     int debug;          // bring-up/ablation bits (0 in production), see dense_kernel_pp.h
     unsigned long long* trace;  // optional s_memtime trace [grid][8 waves][64], nullptr in production
+    // fused head (dense_kernel_pp<.., HEAD>): out[m][o] partial sums instead of the activation tile
+    const float* head_w;   // [HEAD][N] fp32
+    float* head_part;      // [2*N/256][M_pad][16] fp32 partial dot products (per 128-column slice)
 };
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {

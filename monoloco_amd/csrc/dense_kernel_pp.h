@@ -20,6 +20,10 @@
 //  * epilogue per 32x32 MFMA tile through a private 4 KiB LDS scratch per wave (the 32 KiB the two
 //    stage buffers leave free).  No ordinary vector load: bias comes through the scalar path
 //    (s_load), residual lines by LDS-DMA into the stage-1 buffer, which is idle during the epilogue.
+//  * HEAD > 0 (the layer feeding w_fin, reference architectures.py:64-67): the activation tile is not
+//    stored at all; each wave multiplies its relu'd 128-column slice with the HEAD x 128 slice of the
+//    head weights (staged in its part of the idle stage-1 buffer), combines the two lane halves and
+//    writes HEAD partial sums per person; head_reduce_kernel adds the 2*N/256 slices and the bias.
 #pragma once
 #include "dense_kernel.h"
 
@@ -38,7 +42,7 @@ __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NSPLIT, bool RELU, bool RES>
+template <int NSPLIT, bool RELU, bool RES, int HEAD>
 __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
 
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
         issueW(0);
     }
     bool first = true;
+    int staged_n0 = -1;
 
     while (true) {
         // accumulators start at bias * 2^e (pre-scaled on the host, exact), so the epilogue needs no bias
@@ -158,10 +163,12 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
 
         // stage 0 of this tile was requested before the previous tile's epilogue stores (32 per wave);
         // vmcnt retires in order, so "at most 32 outstanding" means that DMA has landed.
+        // (HEAD epilogues issue 2*ceil(HEAD/4) partial-sum stores instead)
+        constexpr int EPI_VMEM = HEAD > 0 ? 2 * ((HEAD + 3) / 4) : 32;
         if (first) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EPI_VMEM) : "memory");
         }
         first = false;
         stamp();      // [tile*6 + 1] stage 0 landed (this wave)
@@ -203,37 +210,27 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
         //   W rows   0.. : group 1, phase 4s-3                                                  window 3
         //   W rows 128.. : group 0, phase 4s-2                                                  window 2
         // and everything of stage s has landed by the end of phase 4s-1 (counted waits below).
-        if (grp == 0) {
-            for (int t = 0; t < nk; ++t) {
-                const char* sb = smem + (t & 1) * STAGE_BYTES;
-                const bool pre = loads && t + 1 < nk;
-                if (pre) issueX(t + 1);                        // phase 4t
-                load_frags(sb, 0);
-                pp_barrier();
-                compute();                                     // phase 4t+1
-                pp_barrier();
-                if (pre) issueW(t + 1);                        // phase 4t+2
-                load_frags(sb, 1);
-                pp_barrier();
-                compute();                                     // phase 4t+3
-                if (pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (t < 2) stamp();                            // [+3], [+4] end of k-step 0 / 1 incl. DMA wait
-                pp_barrier();
-            }
-            pp_barrier();  // group 1's last compute phase
-        } else {
-            if (loads && nk > 1) issueX(1);                    // phase 0 (this group has nothing else to do in it)
+        // One loop body for both groups (two copies would get two register assignments and 128 accumulator
+        // copies at the merge); the groups differ only in the wave-uniform DMA issue / wait statements.
+        if (grp == 1) {
+            if (loads && nk > 1) issueX(1);                    // phase 0 (group 1 has nothing else to do in it)
             pp_barrier();
-            for (int t = 0; t < nk; ++t) {
-                const char* sb = smem + (t & 1) * STAGE_BYTES;
-                const bool pre = loads && t + 1 < nk;
-                if (pre) issueW(t + 1);                        // phase 4t+1
-                load_frags(sb, 0);
-                pp_barrier();
-                compute();                                     // phase 4t+2
-                pp_barrier();
-                load_frags(sb, 1);                             // phase 4t+3
-                const bool nxt = loads && t + 2 < nk;
+        }
+        for (int t = 0; t < nk; ++t) {
+            const char* sb = smem + (t & 1) * STAGE_BYTES;
+            const bool pre = loads && t + 1 < nk;
+            const bool nxt = loads && t + 2 < nk;
+            if (pre) {                                         // G0: phase 4t     G1: phase 4t+1
+                if (grp == 0) issueX(t + 1);
+                else issueW(t + 1);
+            }
+            load_frags(sb, 0);
+            pp_barrier();
+            compute();                                         // G0: phase 4t+1   G1: phase 4t+2
+            pp_barrier();
+            if (pre && grp == 0) issueW(t + 1);                // G0: phase 4t+2
+            load_frags(sb, 1);                                 //                  G1: phase 4t+3
+            if (grp == 1) {
                 if (nxt) {
                     // stage t is now completely read (group 0 finished it a phase ago, our own reads are
                     // drained here): its X rows 128.. can already be overwritten with stage t+2
@@ -246,11 +243,16 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 if (t < 2) stamp();
-                pp_barrier();
-                compute();                                     // phase 4t+4
-                pp_barrier();
             }
+            pp_barrier();
+            compute();                                         // G0: phase 4t+3   G1: phase 4t+4
+            if (grp == 0) {
+                if (pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (t < 2) stamp();                            // [+3], [+4] end of k-step 0 / 1 incl. DMA wait
+            }
+            pp_barrier();
         }
+        if (grp == 0) pp_barrier();  // group 1's last compute phase
         // every wave has passed the same number of barriers; nobody reads the stage buffers any more
         stamp();      // [+5] main loop done
 
@@ -282,6 +284,27 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
         };
         const bool has_res = RES && !(p.debug & 1);
         if (has_res) fetch_res(0);  // ahead of the next tile's DMA so that it does not queue behind it
+        if (HEAD > 0) {
+            // this wave's slice of the head weights, hw[o][128] = head_w[o][nbase .. nbase+127].  Rows 0..7 live
+            // in the wave's 4 KiB epilogue scratch (not needed for a transpose in this mode) and are re-staged
+            // only when the column tile changes (it does not for the usual grids); a 9th row (stereo) goes to
+            // the idle stage-1 buffer every tile.  Ordinary loads: issued BEFORE the next tile's DMA is
+            // requested, so the vmcnt(0) hipcc puts behind them has nothing young to wait for.
+            if (cur_n0 != staged_n0) {
+                for (int idx = elane; idx < (HEAD < 8 ? HEAD : 8) * 32; idx += 64) {
+                    const int o = idx >> 5, c4 = idx & 31;
+                    *(f32x4*)((float*)scr + o * 128 + c4 * 4) = *(const f32x4*)(p.head_w + (size_t)o * p.N + nbase + c4 * 4);
+                }
+                staged_n0 = cur_n0;
+            }
+            if (HEAD > 8) {
+                for (int idx = elane; idx < (HEAD - 8) * 32; idx += 64) {
+                    const int o = 8 + (idx >> 5), c4 = idx & 31;
+                    *(f32x4*)((float*)resbuf + (o - 8) * 128 + c4 * 4) = *(const f32x4*)(p.head_w + (size_t)o * p.N + nbase + c4 * 4);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
 
         // ---- next tile: request its first stage now, it lands while the epilogue runs
         vb += gridDim.x;
@@ -306,6 +329,45 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
 #pragma unroll
                     for (int e = 0; e < 16; ++e) s += acc[it][jt][e];
             if (s == 123456.789f) p.y[tid] = 1;
+        } else if (HEAD > 0) {
+            const int slice = (cur_n0 / BN) * 2 + wn;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                float part[HEAD > 0 ? HEAD : 1];
+#pragma unroll
+                for (int o = 0; o < HEAD; ++o) part[o] = 0.0f;
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[it][jt][g * 4 + e] * p.descale;
+                            if (RELU) v[e] = __builtin_fmaxf(v[e], 0.0f);
+                        }
+#pragma unroll
+                        for (int o = 0; o < HEAD; ++o) {
+                            const float* hwo = (o < 8 ? (const float*)scr + o * 128 : (const float*)resbuf + (o - 8) * 128);
+                            const f32x4 w4 = *(const f32x4*)(hwo + it * 32 + g * 8 + eh * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) part[o] = __builtin_fmaf(v[e], w4[e], part[o]);
+                        }
+                    }
+#pragma unroll
+                for (int o = 0; o < HEAD; ++o) part[o] += __shfl_xor(part[o], 32, 64);
+                if (eh == 0) {
+                    float* dst = p.head_part + ((size_t)slice * p.M_pad + (cur_m0 + wm * 64 + jt * 32 + eml)) * 16;
+#pragma unroll
+                    for (int o4 = 0; o4 < (HEAD + 3) / 4; ++o4) {
+                        f32x4 q4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) q4[e] = (o4 * 4 + e < HEAD) ? part[o4 * 4 + e] : 0.0f;
+                        *(f32x4*)(dst + o4 * 4) = q4;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
 #pragma unroll
             for (int pass = 0; pass < 8; ++pass) {

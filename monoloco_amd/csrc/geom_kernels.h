@@ -275,6 +275,22 @@ __global__ __launch_bounds__(256) void heads_kernel(const char* __restrict__ act
 }
 
 // ------------------------------------------------------------------------------------------
+// second half of the fused w_fin head (dense_kernel_pp<.., HEAD>): raw[row][col0 + o] = bias[o] +
+// sum over the nparts 128-column slices of part[slice][row][o].  One thread per (row, o).
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ part, int nparts, int64_t m_pad,
+                                                         int64_t m, int nh, const float* __restrict__ bh,
+                                                         float* __restrict__ raw, int raw_stride, int col0) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= m * 16) return;
+    const int64_t row = id >> 4;
+    const int o = (int)(id & 15);
+    if (o >= nh) return;
+    float s = bh[o];
+    for (int sl = 0; sl < nparts; ++sl) s += part[((int64_t)sl * m_pad + row) * 16 + o];
+    raw[row * raw_stride + col0 + o] = s;
+}
+
+// ------------------------------------------------------------------------------------------
 // stereo: per left person the first right index whose aux logit (last column) is maximal, and a
 // global count of left persons with tied maxima (the reference keeps every tied row,
 // process.py:325-326; the host re-does those rare cases).

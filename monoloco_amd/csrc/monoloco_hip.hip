@@ -152,6 +152,7 @@ struct ml_loco {
     float* d_xr = nullptr;
     float* d_cl = nullptr;      // stereo: left centres
     int32_t* d_rowidx = nullptr;
+    float* d_part = nullptr;    // fused-head partial sums [2*hidden/256][cap_rows][16]
     int64_t cap_side = 0;
     int64_t dev_bytes = 0;
     // optional per-launch timing of the dense kernel (ml_loco_profile_*): HIP events recorded on
@@ -297,7 +298,8 @@ int free_workspace(ml_loco* h) {
     dev_free(h->d_centre);
     dev_free(h->d_raw);
     dev_free(h->d_rowidx);
-    h->d_xf32 = h->d_centre = h->d_raw = nullptr;
+    dev_free(h->d_part);
+    h->d_xf32 = h->d_centre = h->d_raw = h->d_part = nullptr;
     h->d_rowidx = nullptr;
     h->cap_rows = 0;
     return ML_OK;
@@ -316,6 +318,7 @@ int ensure_rows(ml_loco* h, int64_t rows) {
     if ((rc = dev_alloc(h, &h->d_centre, need * 2 * 4))) return rc;
     if ((rc = dev_alloc(h, &h->d_raw, need * (int64_t)h->out_f * 4))) return rc;
     if ((rc = dev_alloc(h, &h->d_rowidx, need * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_part, (int64_t)(2 * h->hidden / 256) * need * 16 * 4))) return rc;
     h->cap_rows = need;
     return ML_OK;
 }
@@ -389,7 +392,7 @@ int trace_after_launch(unsigned long long* buf, size_t n, int grid, const mlk::D
     return ML_OK;
 }
 
-int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st) {
+int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0) {
     mlk::DenseParams p = p_in;
     p.debug = dense_debug_bits();
     p.trace = nullptr;
@@ -409,15 +412,18 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st) {
             HIP_TRY(hipMemsetAsync(trace_buf, 0, trace_n * 8, st));
             p.trace = trace_buf;
         }
-#define ML_PP(NS, RL, RS) hipLaunchKernelGGL((mlk::dense_kernel_pp<NS, RL, RS>), dim3(grid), dim3(mlk::DENSE_THREADS), 0, st, p)
+#define ML_PP(NS, RL, RS, HD) \
+    hipLaunchKernelGGL((mlk::dense_kernel_pp<NS, RL, RS, HD>), dim3(grid), dim3(mlk::DENSE_THREADS), 0, st, p)
 #define ML_PP_NS(NS)                                              \
     do {                                                          \
-        if (p.relu) {                                             \
-            if (p.res) ML_PP(NS, true, true);                     \
-            else ML_PP(NS, true, false);                          \
+        if (head_nh == 8) ML_PP(NS, true, false, 8);              \
+        else if (head_nh == 9) ML_PP(NS, true, false, 9);         \
+        else if (p.relu) {                                        \
+            if (p.res) ML_PP(NS, true, true, 0);                  \
+            else ML_PP(NS, true, false, 0);                       \
         } else {                                                  \
-            if (p.res) ML_PP(NS, false, true);                    \
-            else ML_PP(NS, false, false);                         \
+            if (p.res) ML_PP(NS, false, true, 0);                 \
+            else ML_PP(NS, false, false, 0);                      \
         }                                                         \
     } while (0)
         if (precision == ML_PREC_F16X2) ML_PP_NS(3);
@@ -498,18 +504,36 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st) {
             p.relu = L.relu;
             p.debug = 0;
             p.trace = nullptr;
+            p.head_w = nullptr;
+            p.head_part = nullptr;
+            // the w_fin head rides in the epilogue of the layer that feeds it (persistent kernel, relu, no residual)
+            const Head* fused = nullptr;
+            for (const Head& hd : h->heads)
+                if (hd.after_layer == (int)li && (hd.nh == 8 || hd.nh == 9) && dense_variant() != 1 && L.relu && L.res < 0 &&
+                    chunk == m_pad_all && !dense_debug_bits())
+                    fused = &hd;
+            if (fused) {
+                p.head_w = fused->d_w;
+                p.head_part = h->d_part;
+            }
             const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
             if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
-            int rc = launch_dense(h->precision, p, st);
+            int rc = launch_dense(h->precision, p, st, fused ? fused->nh : 0);
             if (rc) return rc;
             if (timed) {
                 HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));
                 h->ev_layer[h->ev_used] = (int)li;
                 h->ev_used++;
             }
+            if (fused && rows_here > 0) {
+                hipLaunchKernelGGL(mlk::head_reduce_kernel, dim3((unsigned)((rows_here * 16 + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)h->d_part, 2 * h->hidden / 256, m_pad, rows_here, fused->nh,
+                                   (const float*)fused->d_b, raw_out + r0 * h->out_f, h->out_f, fused->col0);
+                HIP_TRY(hipGetLastError());
+            }
             if (rows_here > 0)
                 for (const Head& hd : h->heads)
-                    if (hd.after_layer == (int)li) {
+                    if (hd.after_layer == (int)li && &hd != fused) {
                         rc = launch_heads(hd, at(hd.src), h->hidden, raw_out + r0 * h->out_f, h->out_f, rows_here, st);
                         if (rc) return rc;
                     }
@@ -982,6 +1006,8 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
         p.relu = relu;
         p.debug = 0;
         p.trace = nullptr;
+        p.head_w = nullptr;
+        p.head_part = nullptr;
         rc = launch_dense(precision, p, st);
         if (!rc) {
             const int64_t groups = m * (n / 8);
