@@ -155,6 +155,17 @@ int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const
                            float* raw_all_dev, float* out_dev, float* xyzds_dev,
                            int32_t* best_dev, int32_t* ties_dev, void* stream);
 
+/* ---- MC-dropout epistemic uncertainty: stands in for Loco.epistemic_uncertainty (net.py:135-161) ---- */
+/* n_dropout stochastic forwards of the mono model with dropout (probability p_dropout) active at the two
+ * top-level sites only (net.py:141, architectures.py:53,66); per pass n_samples (reference: 100) draws of
+ * Laplace(d, |exp(s) d|) with the same seed every pass (process.py:103,119-120); epi_dev (m) receives the
+ * unbiased standard deviation over all n_dropout*n_samples draws.  Counter-based RNG: statistically, not
+ * bitwise, equal to the reference's torch stream.  raw_passes_dev (n_dropout, m, out_features) optionally
+ * receives every pass' raw network output.  Allocates a 16*m byte scratch with hipMallocAsync. */
+int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host, int n_dropout,
+                           float p_dropout, int n_samples, uint32_t seed, float* epi_dev, float* raw_passes_dev,
+                           void* stream);
+
 /* ---- measurement: per-launch timing of the dense (MFMA) kernel ----------------------- */
 /* After ml_loco_profile_begin, every dense-kernel launch made through this handle is bracketed by
  * a pair of HIP events recorded on the launch stream (up to max_launches launches).

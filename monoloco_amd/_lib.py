@@ -6,7 +6,7 @@ fallback: if the library is missing or a call fails, a ``MonolocoHipError`` is r
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint16, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint16, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libmonoloco_hip.so')
@@ -49,6 +49,7 @@ SIGNATURES = {
     'ml_loco_forward_mono': (c_int, [_P, _P, c_int64, POINTER(c_float), _P, _P, _P, _P, _P]),
     'ml_loco_forward_stereo': (c_int, [_P, _P, c_int64, _P, c_int64, POINTER(c_float), _P, _P, _P, _P,
                                        _P, _P, _P]),
+    'ml_loco_epistemic_mono': (c_int, [_P, _P, c_int64, POINTER(c_float), c_int, c_float, c_int, c_uint32, _P, _P, _P]),
     'ml_loco_profile_begin': (c_int, [_P, c_int]),
     'ml_loco_profile_end': (c_int, [_P, POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_int]),
     'ml_debug_linear': (c_int, [_P, c_int64, c_int, POINTER(c_float), POINTER(c_float), c_int, c_int, _P, _P,

@@ -21,6 +21,7 @@
 #include "dense_kernel_pp.h"
 #include "geom_kernels.h"
 #include "geom_ops.h"
+#include "mc_kernels.h"
 
 namespace {
 
@@ -481,7 +482,13 @@ int chunk_rows_env() {
 
 // Runs the dense chain + heads on `rows` network rows whose line-format input already sits in
 // buf[0]; leaves raw (rows, out_f) fp32 in raw_out.
-int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st) {
+// MC-dropout: active when mc_p > 0 -- dropout after dense layer 0 and on the input of the w_fin head
+struct McPass {
+    float p = 0.f;
+    uint32_t seed = 0;
+};
+
+int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass mc = McPass()) {
     const int64_t m_pad_all = round_up64(rows, 256);
     const int64_t chunk = chunk_rows_env() > 0 ? chunk_rows_env() : m_pad_all;
     for (int64_t r0 = 0; r0 < m_pad_all; r0 += chunk) {
@@ -510,7 +517,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st) {
             const Head* fused = nullptr;
             for (const Head& hd : h->heads)
                 if (hd.after_layer == (int)li && (hd.nh == 8 || hd.nh == 9) && dense_variant() != 1 && L.relu && L.res < 0 &&
-                    chunk == m_pad_all && !dense_debug_bits())
+                    chunk == m_pad_all && !dense_debug_bits() && mc.p <= 0.f)
                     fused = &hd;
             if (fused) {
                 p.head_w = fused->d_w;
@@ -530,6 +537,19 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st) {
                                    (const float*)h->d_part, 2 * h->hidden / 256, m_pad, rows_here, fused->nh,
                                    (const float*)fused->d_b, raw_out + r0 * h->out_f, h->out_f, fused->col0);
                 HIP_TRY(hipGetLastError());
+            }
+            if (mc.p > 0.f) {
+                // top-level dropout sites only (reference net.py:141): after relu(bn1) = output of layer 0, and
+                // after relu(bn3) = the input of the w_fin head
+                bool site = (li == 0);
+                for (const Head& hd : h->heads)
+                    if (hd.after_layer == (int)li && hd.nh > 1) site = true;
+                if (site) {
+                    const int64_t groups = m_pad * (L.n / 8);
+                    hipLaunchKernelGGL(mlk::dropout_lines_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
+                                       at(L.dst), m_pad, L.n, mc.p, mc.seed, (uint32_t)li);
+                    HIP_TRY(hipGetLastError());
+                }
             }
             if (rows_here > 0)
                 for (const Head& hd : h->heads)
@@ -918,6 +938,49 @@ int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const
                        (const int32_t*)h->d_rowidx, ml, h->d_cl, ki, box_conf_dev, out_dev, xyzds_dev);
     HIP_TRY(hipGetLastError());
     return ML_OK;
+}
+
+// ---------------------------------------------------------------- MC-dropout epistemic uncertainty
+int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host, int n_dropout,
+                           float p_dropout, int n_samples, uint32_t seed, float* epi_dev, float* raw_passes_dev,
+                           void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->in_f != mlk::NIN) return fail(ML_ERR_SHAPE, "epistemic uncertainty is defined for the mono nets (net.py:139)");
+    if (m == 0) return ML_OK;
+    if (m < 0 || !kps_dev || !kinv_host || !epi_dev || n_dropout <= 0 || n_samples <= 0 || !(p_dropout > 0.f) ||
+        !(p_dropout < 1.f))
+        return fail(ML_ERR_ARG, "bad argument");
+    if ((rc = ensure_rows(h, m))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    double* acc = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&acc, (size_t)m * 2 * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)m * 2 * sizeof(double), st));
+    const int64_t m_pad = round_up64(m, 256);
+    const mlk::Kinv ki = make_kinv(kinv_host);
+    const unsigned grid_m = (unsigned)((m + 255) / 256);
+    for (int pass = 0; pass < n_dropout && !rc; ++pass) {
+        // the stochastic forward consumes the input lines afresh every pass (buffer A is overwritten)
+        hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(m_pad / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
+                           (float*)nullptr, (float*)nullptr, h->buf[0], h->k0pad, m_pad, 0);
+        McPass mc;
+        mc.p = p_dropout;
+        mc.seed = seed * 7919u + (uint32_t)pass + 1u;
+        rc = run_network(h, m, h->d_raw, st, mc);
+        if (rc) break;
+        if (raw_passes_dev)
+            HIP_TRY(hipMemcpyAsync(raw_passes_dev + (size_t)pass * m * h->out_f, h->d_raw, (size_t)m * h->out_f * 4,
+                                   hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(mlk::mc_accumulate_kernel, dim3(grid_m), dim3(256), 0, st, (const float*)h->d_raw, h->out_f, m,
+                           n_samples, seed, acc, acc + m);
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(mlk::mc_finish_kernel, dim3(grid_m), dim3(256), 0, st, (const double*)acc, (const double*)(acc + m),
+                           m, (double)n_dropout * (double)n_samples, epi_dev);
+        if (hipGetLastError() != hipSuccess) rc = fail(ML_ERR_HIP, "mc kernel launch failed");
+    }
+    (void)hipFreeAsync(acc, st);
+    return rc;
 }
 
 // ---------------------------------------------------------------- test hooks

@@ -221,6 +221,19 @@ class LocoEngine:
                                                      _ptr(best), _ptr(ties), _stream(dev)))
         return dict(out=out, xyzds=xyzds, best=best, ties=ties, raw_all=raw_all)
 
+    def epistemic_mono(self, kps, kinv, n_dropout, p_dropout=0.2, n_samples=100, seed=1, want_passes=False):
+        """MC-dropout spread of the distance (reference net.py:135-161) -> (m,) device tensor
+        [, (n_dropout, m, out) raw outputs of every stochastic pass]."""
+        dev = self.device
+        kps = _dev_f32(kps, dev)
+        m = kps.shape[0]
+        epi = torch.empty((m,), dtype=torch.float32, device=dev)
+        passes = torch.empty((n_dropout, m, self.out_features), dtype=torch.float32, device=dev) if want_passes else None
+        with torch.cuda.device(dev):
+            check(_lib.load().ml_loco_epistemic_mono(self._h, _ptr(kps), m, fptr(kinv), int(n_dropout), float(p_dropout),
+                                                     int(n_samples), int(seed), _ptr(epi), _ptr(passes), _stream(dev)))
+        return (epi, passes) if want_passes else epi
+
     # -- measurement
     def profile_begin(self, max_launches=65536):
         check(_lib.load().ml_loco_profile_begin(self._h, int(max_launches)))

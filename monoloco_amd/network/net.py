@@ -84,9 +84,12 @@ class Loco:
                 dic_out = packed_to_dict(out, 10)
             n_out = kps.shape[0]
         if self.n_dropout > 0 and self.net != 'monstereo':
-            raise NotImplementedError("MC-dropout epistemic uncertainty (reference net.py:135-161) is a 'next' row "
-                                      "of the hot-path scope; run with n_dropout=0")
-        dic_out['epi'] = [0.] * n_out
+            # combined aleatoric + epistemic spread by MC-dropout (reference net.py:126-128,135-161): a tensor
+            dic_out['epi'] = self.engine.epistemic_mono(kps, kinv, self.n_dropout,
+                                                        p_dropout=getattr(self.model, 'p_dropout', 0.2),
+                                                        n_samples=self.N_SAMPLES).cpu()
+        else:
+            dic_out['epi'] = [0.] * n_out
         return dic_out
 
     @staticmethod

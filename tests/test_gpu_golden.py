@@ -239,3 +239,48 @@ def test_full_batch_properties(hip_lib, cuda_device):
     assert (xyzds[idx].cpu() - ref['xyzds']).abs().max().item() <= TOL
     assert (raw[idx].cpu() - ref['raw']).abs().max().item() <= TOL
     eng.close()
+
+
+def test_mc_dropout_epistemic(hip_lib, cuda_device, gold):
+    """Loco(n_dropout > 0): MC-dropout spread of the distance (reference net.py:135-161).  The RNG is not
+    torch's, so parity is statistical.  The reference draws its 100 Laplace samples with the same seed on
+    every pass, so each person's value is dominated by the luck of those 100 draws (0.3x..1.8x the ideal
+    sigma with torch's stream); what can be compared is (a) the statistics of the stochastic passes
+    themselves against the oracle's torch-dropout passes, (b) the estimator against its closed form
+    Var(mu) + 2 E[b^2] evaluated on the same passes, (c) the p -> 0 limit, (d) reproducibility."""
+    from monoloco_amd import engine
+    from monoloco_amd.network import Loco
+    from oracle import monoloco_oracle as O
+    sd = _weights('B', 'mono')
+    kps = torch.tensor(gold['mono_kps'][:256])
+    net = Loco(model=_model('B', 'mono'), mode='mono', device=cuda_device, n_dropout=20, p_dropout=0.2)
+    dic = net.forward(kps, synth.KITTI_K)
+    epi = dic['epi']
+    assert isinstance(epi, torch.Tensor) and epi.shape == (256,) and epi.device.type == 'cpu'
+    assert torch.isfinite(epi).all() and (epi > 0).all()
+    eng = engine.LocoEngine(sd, device=cuda_device)
+    kinv = engine.inverse_intrinsics(synth.KITTI_K)
+    n_pass = 300
+    epi, passes = eng.epistemic_mono(kps, kinv, n_pass, 0.2, want_passes=True)
+    epi, passes = epi.cpu(), passes.cpu()
+    x = O.preprocess_monoloco(kps, synth.KITTI_K)
+    torch.manual_seed(0)
+    ref_passes = torch.stack([O.loco_forward_mc(sd, x, 0.2) for _ in range(n_pass)])
+    for col in (2, 3):  # d and log-b: same mean and spread over the passes as torch's dropout gives
+        a, b = passes[:, :, col], ref_passes[:, :, col]
+        r = a.std(0) / b.std(0)
+        z = (a.mean(0) - b.mean(0)).abs() / (b.std(0) / n_pass ** 0.5)
+        assert abs(r.median().item() - 1) < 0.03 and r.min() > 0.7 and r.max() < 1.4, (r.median(), r.min(), r.max())
+        assert z.max() < 6.0, z.max()
+    mu, bb = passes[:, :, 2], (torch.exp(passes[:, :, 3]) * passes[:, :, 2]).abs()
+    ideal = torch.sqrt(mu.var(0) + 2 * (bb ** 2).mean(0))
+    rr = epi / ideal
+    print("MC-dropout: HIP estimate / closed form on its passes: median %.3f range %.2f..%.2f" % (rr.median(), rr.min(), rr.max()))
+    assert abs(rr.median().item() - 1) < 0.06 and rr.min() > 0.5 and rr.max() < 1.7
+    # p -> 0: every pass identical: epi = |bi| * std(fixed standard Laplace draws) ~ sqrt(2) |bi|
+    bi = dic['bi'][:, 0]
+    e0 = eng.epistemic_mono(kps, kinv, 3, p_dropout=1e-7).cpu()
+    r0 = e0 / bi.abs()
+    assert abs(r0.mean().item() - 2 ** 0.5) < 0.06 and r0.min() > 0.8 and r0.max() < 2.4
+    assert torch.equal(e0, eng.epistemic_mono(kps, kinv, 3, p_dropout=1e-7).cpu())  # counter-based RNG
+    eng.close()
