@@ -166,6 +166,32 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
                            float p_dropout, int n_samples, uint32_t seed, float* epi_dev, float* raw_passes_dev,
                            void* stream);
 
+/* ---- training step: stands in for one iteration of Trainer.train (monoloco/train/trainer.py:150-161) ---- */
+typedef struct ml_trainer ml_trainer;
+/* LocoModel(in_features, out_features, hidden, p_dropout, num_stage) in train mode (trainer.py:115-123) with
+ * Adam(lr) + StepLR(step_size = sched_step BATCHES, gamma = sched_gamma) (trainer.py:128-131, :160-161) and
+ * clip_grad_norm_(3) (:159).  Parameters start at zero: feed them with ml_trainer_set_tensor.  seed drives the
+ * dropout masks (counter-based RNG; p_dropout = 0 gives the deterministic path used for parity). */
+int ml_trainer_create(int in_features, int hidden, int out_features, int num_stage, float p_dropout, float lr,
+                      float sched_gamma, int sched_step, uint32_t seed, ml_trainer** out);
+/* state_dict access by the reference's keys (parameters and BatchNorm running statistics). */
+int ml_trainer_set_tensor(ml_trainer* t, const char* key, const float* host_data, int64_t numel);
+int ml_trainer_get_tensor(ml_trainer* t, const char* key, float* host_data, int64_t numel);
+/* gradient of the last step (after clipping when the step updated), parameters only */
+int ml_trainer_get_grad(ml_trainer* t, const char* key, float* host_data, int64_t numel);
+/* One step on a batch resident on the device: x_dev (m, in_features), labels_dev (m, label_cols) with the
+ * reference's label columns theta, psi, z, d, h, w, l, sin, cos, yaw(, aux) (process.py:293-301).  Forward in
+ * train mode (batch-statistics BatchNorm, running-stat update with momentum 0.1, dropout), MultiTaskLoss
+ * (losses.py:59-73: LaplacianLoss on d :112-131, L1 on x, y, h, w, l, ori, BCE-with-logits on aux for 10 outputs),
+ * backward; if update != 0: clip, Adam, advance the per-batch StepLR.  losses_host[0] = total, [1..8] = the task
+ * means d, x, y, h, w, l, ori, aux.  raw_out_dev (m, out_features) optionally receives the train-mode outputs.
+ * Synchronises the stream before returning (the reference syncs with .item() too). */
+int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m,
+                    int update, double* losses_host, float* raw_out_dev, void* stream);
+int64_t ml_trainer_num_steps(const ml_trainer* t);
+int ml_trainer_destroy(ml_trainer* t);
+const char* ml_train_last_error(void);
+
 /* ---- measurement: per-launch timing of the dense (MFMA) kernel ----------------------- */
 /* After ml_loco_profile_begin, every dense-kernel launch made through this handle is bracketed by
  * a pair of HIP events recorded on the launch stream (up to max_launches launches).

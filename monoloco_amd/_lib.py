@@ -50,6 +50,14 @@ SIGNATURES = {
     'ml_loco_forward_stereo': (c_int, [_P, _P, c_int64, _P, c_int64, POINTER(c_float), _P, _P, _P, _P,
                                        _P, _P, _P]),
     'ml_loco_epistemic_mono': (c_int, [_P, _P, c_int64, POINTER(c_float), c_int, c_float, c_int, c_uint32, _P, _P, _P]),
+    'ml_trainer_create': (c_int, [c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_uint32, POINTER(_P)]),
+    'ml_trainer_set_tensor': (c_int, [_P, c_char_p, POINTER(c_float), c_int64]),
+    'ml_trainer_get_tensor': (c_int, [_P, c_char_p, POINTER(c_float), c_int64]),
+    'ml_trainer_get_grad': (c_int, [_P, c_char_p, POINTER(c_float), c_int64]),
+    'ml_trainer_step': (c_int, [_P, _P, _P, c_int, c_int64, c_int, POINTER(c_double), _P, _P]),
+    'ml_trainer_num_steps': (c_int64, [_P]),
+    'ml_trainer_destroy': (c_int, [_P]),
+    'ml_train_last_error': (c_char_p, []),
     'ml_loco_profile_begin': (c_int, [_P, c_int]),
     'ml_loco_profile_end': (c_int, [_P, POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_int]),
     'ml_debug_linear': (c_int, [_P, c_int64, c_int, POINTER(c_float), POINTER(c_float), c_int, c_int, _P, _P,
@@ -87,9 +95,9 @@ def load():
     return lib
 
 
-def check(code):
+def check(code, train=False):
     if code != 0:
-        msg = load().ml_last_error()
+        msg = load().ml_train_last_error() if train else load().ml_last_error()
         raise MonolocoHipError("monoloco_hip error %d: %s" % (code, msg.decode() if msg else '?'))
 
 

@@ -1,0 +1,381 @@
+// train.hip -- C ABI of the training step of LocoModel on gfx950 (BASELINE config 5).
+// Stands in for one iteration of the reference's training loop (monoloco/train/trainer.py:150-161):
+//   model.train() forward (batch-stat BatchNorm + running-stat update, dropout)  architectures.py:48-102
+//   MultiTaskLoss                                                               losses.py:59-73, 112-131
+//   backward, clip_grad_norm_(3), Adam, per-batch StepLR                        trainer.py:157-161, 128-131
+// fp32 throughout (exact-fp32 MFMA), reductions in fp64.  Kernels: train_kernels.h.
+#include "../../include/monoloco_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "train_kernels.h"
+
+namespace {
+
+thread_local char t_err[512] = "";
+int tfail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define T_TRY(expr)                                                                          \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return tfail(ML_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct Slot {
+    int64_t off = 0, numel = 0;
+    bool is_param = true;  // false: BN running statistic
+};
+
+}  // namespace
+
+extern "C" const char* ml_train_last_error(void) { return t_err; }
+
+struct ml_trainer {
+    int in_f, H, C, S;
+    float p_drop, lr0, gamma;
+    int sched_step;
+    uint32_t seed;
+    int64_t step = 0;
+    std::map<std::string, Slot> slots;
+    int64_t n_param = 0, n_stat = 0;
+    float *w = nullptr, *g = nullptr, *m1 = nullptr, *m2 = nullptr, *stat = nullptr;
+    // activation workspace (rows cap)
+    int64_t cap = 0;
+    std::vector<float*> bufs;  // all (cap x H) fp32 buffers
+    float *d_out = nullptr, *d_dout = nullptr, *d_y2aux = nullptr;
+    float *bn_mean = nullptr, *bn_invstd = nullptr;  // (nbn x H)
+    double* d_red = nullptr;                          // scratch for fp64 reductions (2*H + 16)
+    int nbn = 0;
+};
+
+namespace {
+
+int add_slot(ml_trainer* t, const std::string& key, int64_t numel, bool is_param) {
+    Slot s;
+    s.numel = numel;
+    s.is_param = is_param;
+    s.off = is_param ? t->n_param : t->n_stat;
+    (is_param ? t->n_param : t->n_stat) += numel;
+    t->slots[key] = s;
+    return 0;
+}
+void add_linear(ml_trainer* t, const std::string& n, int out, int in) {
+    add_slot(t, n + ".weight", (int64_t)out * in, true);
+    add_slot(t, n + ".bias", out, true);
+}
+void add_bn(ml_trainer* t, const std::string& n, int h) {
+    add_slot(t, n + ".weight", h, true);
+    add_slot(t, n + ".bias", h, true);
+    add_slot(t, n + ".running_mean", h, false);
+    add_slot(t, n + ".running_var", h, false);
+}
+float* P(ml_trainer* t, const std::string& k) { return t->w + t->slots[k].off; }
+float* G(ml_trainer* t, const std::string& k) { return t->g + t->slots[k].off; }
+float* ST(ml_trainer* t, const std::string& k) { return t->stat + t->slots[k].off; }
+
+int gemm(hipStream_t st, const float* a, long sai, long sak, const float* b, long sbk, long sbj, const float* bias, float* c,
+         int ldc, int M, int N, int K, int accumulate) {
+    mlt::GemmParams p;
+    p.a = a; p.b = b; p.bias = bias; p.c = c;
+    p.M = M; p.N = N; p.K = K;
+    p.sai = sai; p.sak = sak; p.sbk = sbk; p.sbj = sbj;
+    p.ldc = ldc; p.accumulate = accumulate;
+    dim3 grid((N + mlt::GBN - 1) / mlt::GBN, (M + mlt::GBM - 1) / mlt::GBM);
+    hipLaunchKernelGGL(mlt::sgemm_kernel, grid, dim3(256), 0, st, p);
+    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "sgemm launch failed");
+    return 0;
+}
+// y (m x n) = x (m x k) . W^T + b           (nn.Linear forward)
+int linear_fwd(hipStream_t st, const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int m, int n, int k) {
+    return gemm(st, x, ldx, 1, W, 1, k, b, y, ldy, m, n, k, 0);
+}
+// dx (m x k) (+)= dy (m x n) . W
+int linear_bwd_data(hipStream_t st, const float* dy, int lddy, const float* W, float* dx, int lddx, int m, int n, int k, int acc) {
+    return gemm(st, dy, lddy, 1, W, k, 1, nullptr, dx, lddx, m, k, n, acc);
+}
+// dW (n x k) = dy^T (n x m) . x (m x k)
+int linear_bwd_weight(hipStream_t st, const float* dy, int lddy, const float* x, int ldx, float* dW, int m, int n, int k) {
+    return gemm(st, dy, 1, lddy, x, ldx, 1, nullptr, dW, k, n, k, m, 0);
+}
+
+unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// column sums (fp64) of z (m x n) and of z*w2 (or z*z) into t->d_red[0..n) and [n..2n)
+int col_stats(ml_trainer* t, hipStream_t st, const float* z, const float* w2, int64_t m, int n) {
+    T_TRY(hipMemsetAsync(t->d_red, 0, (size_t)2 * n * sizeof(double), st));
+    int gy = (int)((m + 255) / 256);
+    if (gy > 64) gy = 64;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(mlt::col_stats_kernel, dim3((n + 63) / 64, gy), dim3(256), 0, st, z, w2, m, n, t->d_red, t->d_red + n);
+    return 0;
+}
+
+struct Block {  // Linear + BatchNorm + ReLU + Dropout
+    std::string lin, bn;
+    int bn_idx;
+    int in_dim;
+    const float* x = nullptr;  // input activations (m x in_dim)
+    float* z = nullptr;        // pre-BN (m x H)
+    float* y = nullptr;        // output (m x H) (residual already added if any)
+    uint32_t site;
+};
+
+int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* residual) {
+    const int H = t->H;
+    int rc = linear_fwd(st, b.x, b.in_dim, P(t, b.lin + ".weight"), P(t, b.lin + ".bias"), b.z, H, (int)m, H, b.in_dim);
+    if (rc) return rc;
+    if ((rc = col_stats(t, st, b.z, nullptr, m, H))) return rc;
+    float* mean = t->bn_mean + (size_t)b.bn_idx * H;
+    float* inv = t->bn_invstd + (size_t)b.bn_idx * H;
+    hipLaunchKernelGGL(mlt::bn_finalize_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red,
+                       (const double*)(t->d_red + H), m, H, 1e-5f, 0.1f, mean, inv, ST(t, b.bn + ".running_mean"),
+                       ST(t, b.bn + ".running_var"));
+    hipLaunchKernelGGL(mlt::bn_relu_drop_kernel, dim3(nblk(m * H)), dim3(256), 0, st, (const float*)b.z, m, H,
+                       (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
+                       (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site, residual, b.y);
+    return 0;
+}
+
+// dout: gradient wrt the block output (m x H), overwritten with dz; xhat: scratch (m x H).  Produces the
+// parameter gradients of the block; the caller propagates dz through the Linear to the block input.
+int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, float* xhat) {
+    const int H = t->H;
+    float* mean = t->bn_mean + (size_t)b.bn_idx * H;
+    float* inv = t->bn_invstd + (size_t)b.bn_idx * H;
+    hipLaunchKernelGGL(mlt::relu_drop_bwd_kernel, dim3(nblk(m * H)), dim3(256), 0, st, dout, (const float*)b.z, m, H,
+                       (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
+                       (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site, xhat);
+    int rc = col_stats(t, st, dout, xhat, m, H);  // sum(dy), sum(dy*xhat)
+    if (rc) return rc;
+    hipLaunchKernelGGL(mlt::bn_bwd_kernel, dim3(nblk(m * H)), dim3(256), 0, st, dout, (const float*)xhat, m, H,
+                       (const double*)t->d_red, (const double*)(t->d_red + H), (const float*)P(t, b.bn + ".weight"),
+                       (const float*)inv, G(t, b.bn + ".weight"), G(t, b.bn + ".bias"));
+    // Linear: db = sum(dz), dW = dz^T x
+    if ((rc = col_stats(t, st, dout, nullptr, m, H))) return rc;
+    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red, H,
+                       G(t, b.lin + ".bias"));
+    return linear_bwd_weight(st, dout, H, b.x, b.in_dim, G(t, b.lin + ".weight"), (int)m, H, b.in_dim);
+}
+
+int ensure_cap(ml_trainer* t, int64_t m) {
+    if (m <= t->cap) return 0;
+    T_TRY(hipDeviceSynchronize());
+    for (float* p : t->bufs) (void)hipFree(p);
+    t->bufs.clear();
+    if (t->d_out) (void)hipFree(t->d_out);
+    if (t->d_dout) (void)hipFree(t->d_dout);
+    const int nb = 4 * t->S + 8;  // a_s (S+1), t_s (S), z (2S+2), y2, y3, xhat, 2 gradient buffers
+    for (int i = 0; i < nb; ++i) {
+        float* p = nullptr;
+        T_TRY(hipMalloc((void**)&p, (size_t)m * t->H * 4));
+        t->bufs.push_back(p);
+    }
+    T_TRY(hipMalloc((void**)&t->d_out, (size_t)m * t->C * 4));
+    T_TRY(hipMalloc((void**)&t->d_dout, (size_t)m * t->C * 4));
+    t->cap = m;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ml_trainer_create(int in_features, int hidden, int out_features, int num_stage, float p_dropout, float lr,
+                      float sched_gamma, int sched_step, uint32_t seed, ml_trainer** out) {
+    if (!out) return tfail(ML_ERR_ARG, "out is null");
+    if (in_features <= 0 || hidden <= 0 || hidden > 8192 || (out_features != 9 && out_features != 10) || num_stage < 0 ||
+        num_stage > 16 || !(p_dropout >= 0.f && p_dropout < 1.f) || sched_step <= 0)
+        return tfail(ML_ERR_SHAPE, "unsupported trainer shape / hyper-parameters");
+    ml_trainer* t = new (std::nothrow) ml_trainer();
+    if (!t) return tfail(ML_ERR_HIP, "out of host memory");
+    t->in_f = in_features; t->H = hidden; t->C = out_features; t->S = num_stage;
+    t->p_drop = p_dropout; t->lr0 = lr; t->gamma = sched_gamma; t->sched_step = sched_step; t->seed = seed;
+    add_linear(t, "w1", hidden, in_features);
+    add_bn(t, "batch_norm1", hidden);
+    for (int s = 0; s < num_stage; ++s) {
+        const std::string p = "linear_stages." + std::to_string(s) + ".";
+        add_linear(t, p + "w1", hidden, hidden);
+        add_bn(t, p + "batch_norm1", hidden);
+        add_linear(t, p + "w2", hidden, hidden);
+        add_bn(t, p + "batch_norm2", hidden);
+    }
+    add_linear(t, "w2", hidden, hidden);
+    add_linear(t, "w3", hidden, hidden);
+    add_bn(t, "batch_norm3", hidden);
+    add_linear(t, "w_aux", 1, hidden);
+    add_linear(t, "w_fin", out_features - 1, hidden);
+    t->nbn = 2 * num_stage + 2;
+    T_TRY(hipMalloc((void**)&t->w, (size_t)t->n_param * 4));
+    T_TRY(hipMalloc((void**)&t->g, (size_t)t->n_param * 4));
+    T_TRY(hipMalloc((void**)&t->m1, (size_t)t->n_param * 4));
+    T_TRY(hipMalloc((void**)&t->m2, (size_t)t->n_param * 4));
+    T_TRY(hipMalloc((void**)&t->stat, (size_t)t->n_stat * 4));
+    T_TRY(hipMalloc((void**)&t->bn_mean, (size_t)t->nbn * hidden * 4));
+    T_TRY(hipMalloc((void**)&t->bn_invstd, (size_t)t->nbn * hidden * 4));
+    T_TRY(hipMalloc((void**)&t->d_red, (size_t)(2 * hidden + 32) * sizeof(double)));
+    T_TRY(hipMemset(t->w, 0, (size_t)t->n_param * 4));
+    T_TRY(hipMemset(t->g, 0, (size_t)t->n_param * 4));
+    T_TRY(hipMemset(t->m1, 0, (size_t)t->n_param * 4));
+    T_TRY(hipMemset(t->m2, 0, (size_t)t->n_param * 4));
+    T_TRY(hipMemset(t->stat, 0, (size_t)t->n_stat * 4));
+    *out = t;
+    return ML_OK;
+}
+
+int ml_trainer_destroy(ml_trainer* t) {
+    if (!t) return ML_OK;
+    (void)hipDeviceSynchronize();
+    for (float* p : t->bufs) (void)hipFree(p);
+    void* ptrs[] = {t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete t;
+    return ML_OK;
+}
+
+static int xfer(ml_trainer* t, const char* key, float* host, const float* chost, int64_t numel, int what) {
+    if (!t || !key) return tfail(ML_ERR_ARG, "null argument");
+    const std::string k(key);
+    const std::string nbt = "num_batches_tracked";
+    if (k.size() >= nbt.size() && k.compare(k.size() - nbt.size(), nbt.size(), nbt) == 0) return ML_OK;
+    auto it = t->slots.find(k);
+    if (it == t->slots.end()) return tfail(ML_ERR_ARG, "unknown tensor '%s'", key);
+    if (it->second.numel != numel) return tfail(ML_ERR_ARG, "tensor '%s' has %lld elements, expected %lld", key,
+                                                (long long)numel, (long long)it->second.numel);
+    float* base = what == 2 ? t->g : (it->second.is_param ? t->w : t->stat);
+    if (what == 2 && !it->second.is_param) return tfail(ML_ERR_ARG, "'%s' is a buffer, it has no gradient", key);
+    T_TRY(hipDeviceSynchronize());
+    if (what == 0) T_TRY(hipMemcpy(base + it->second.off, chost, (size_t)numel * 4, hipMemcpyHostToDevice));
+    else T_TRY(hipMemcpy(host, base + it->second.off, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    return ML_OK;
+}
+int ml_trainer_set_tensor(ml_trainer* t, const char* key, const float* host_data, int64_t numel) {
+    return xfer(t, key, nullptr, host_data, numel, 0);
+}
+int ml_trainer_get_tensor(ml_trainer* t, const char* key, float* host_data, int64_t numel) {
+    return xfer(t, key, host_data, nullptr, numel, 1);
+}
+int ml_trainer_get_grad(ml_trainer* t, const char* key, float* host_data, int64_t numel) {
+    return xfer(t, key, host_data, nullptr, numel, 2);
+}
+int64_t ml_trainer_num_steps(const ml_trainer* t) { return t ? t->step : 0; }
+
+int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m,
+                    int update, double* losses_host, float* raw_out_dev, void* stream) {
+    if (!t || !x_dev || !labels_dev || m <= 1 || label_cols < 10) return tfail(ML_ERR_ARG, "bad argument");
+    if (t->C == 10 && label_cols < 11) return tfail(ML_ERR_ARG, "stereo labels need 11 columns");
+    int rc = ensure_cap(t, m);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int H = t->H, S = t->S, C = t->C;
+    // buffer plan
+    int bi = 0;
+    auto nb = [&]() { return t->bufs[bi++]; };
+    std::vector<float*> a(S + 1), tt(S), za(S), zb(S);
+    for (auto& p : a) p = nb();
+    for (auto& p : tt) p = nb();
+    float* z0 = nb();
+    for (int s = 0; s < S; ++s) { za[s] = nb(); zb[s] = nb(); }
+    float* z3 = nb();
+    float* y2 = nb();
+    float* y3 = nb();
+    float* xhat = nb();
+    float* gA = nb();
+    float* gB = nb();
+    // ---------------- forward (train mode)
+    std::vector<Block> blocks;
+    Block b0;
+    b0.lin = "w1"; b0.bn = "batch_norm1"; b0.bn_idx = 0; b0.in_dim = t->in_f; b0.x = x_dev; b0.z = z0; b0.y = a[0]; b0.site = 0;
+    if ((rc = block_fwd(t, st, b0, m, nullptr))) return rc;
+    std::vector<Block> sa(S), sb(S);
+    for (int s = 0; s < S; ++s) {
+        const std::string p = "linear_stages." + std::to_string(s) + ".";
+        sa[s].lin = p + "w1"; sa[s].bn = p + "batch_norm1"; sa[s].bn_idx = 1 + 2 * s; sa[s].in_dim = H;
+        sa[s].x = a[s]; sa[s].z = za[s]; sa[s].y = tt[s]; sa[s].site = 1 + 2 * s;
+        if ((rc = block_fwd(t, st, sa[s], m, nullptr))) return rc;
+        sb[s].lin = p + "w2"; sb[s].bn = p + "batch_norm2"; sb[s].bn_idx = 2 + 2 * s; sb[s].in_dim = H;
+        sb[s].x = tt[s]; sb[s].z = zb[s]; sb[s].y = a[s + 1]; sb[s].site = 2 + 2 * s;
+        if ((rc = block_fwd(t, st, sb[s], m, a[s]))) return rc;  // a_{s+1} = a_s + block(t_s)
+    }
+    if ((rc = linear_fwd(st, a[S], H, P(t, "w2.weight"), P(t, "w2.bias"), y2, H, (int)m, H, H))) return rc;
+    if ((rc = linear_fwd(st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
+    Block b3;
+    b3.lin = "w3"; b3.bn = "batch_norm3"; b3.bn_idx = 2 * S + 1; b3.in_dim = H; b3.x = y2; b3.z = z3; b3.y = y3; b3.site = 2 * S + 1;
+    if ((rc = block_fwd(t, st, b3, m, nullptr))) return rc;
+    if ((rc = linear_fwd(st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
+    if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
+    // ---------------- loss and its gradient
+    double* d_loss = t->d_red + 2 * H;
+    T_TRY(hipMemsetAsync(d_loss, 0, 16 * sizeof(double), st));
+    T_TRY(hipMemsetAsync(t->d_dout, 0, (size_t)m * C * 4, st));
+    hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
+                       t->d_dout, d_loss);
+    double lv[16];
+    T_TRY(hipMemcpyAsync(lv, d_loss, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    // ---------------- backward
+    T_TRY(hipMemsetAsync(t->g, 0, (size_t)t->n_param * 4, st));
+    // heads: column sums of dout give both biases
+    if ((rc = col_stats(t, st, t->d_dout, nullptr, m, C))) return rc;
+    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)t->d_red, C - 1, G(t, "w_fin.bias"));
+    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)(t->d_red + (C - 1)), 1,
+                       G(t, "w_aux.bias"));
+    if ((rc = linear_bwd_weight(st, t->d_dout, C, y3, H, G(t, "w_fin.weight"), (int)m, C - 1, H))) return rc;
+    if ((rc = linear_bwd_data(st, t->d_dout, C, P(t, "w_fin.weight"), gA, H, (int)m, C - 1, H, 0))) return rc;  // dy3
+    if ((rc = block_bwd(t, st, b3, m, gA, xhat))) return rc;                                                     // gA = dz3
+    if ((rc = linear_bwd_data(st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0))) return rc;                 // gB = dy2
+    if ((rc = linear_bwd_weight(st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H))) return rc;
+    if ((rc = linear_bwd_data(st, t->d_dout + (C - 1), C, P(t, "w_aux.weight"), gB, H, (int)m, 1, H, 1))) return rc;  // += daux (x) w_aux
+    // y2 = w2 a_S + b2
+    if ((rc = col_stats(t, st, gB, nullptr, m, H))) return rc;
+    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red, H, G(t, "w2.bias"));
+    if ((rc = linear_bwd_weight(st, gB, H, a[S], H, G(t, "w2.weight"), (int)m, H, H))) return rc;
+    if ((rc = linear_bwd_data(st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0))) return rc;                 // gA = da_S
+    // residual stages, last to first:  a_{s+1} = a_s + B(A(a_s))
+    for (int s = S - 1; s >= 0; --s) {
+        T_TRY(hipMemcpyAsync(gB, gA, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));                          // gB = d r_s
+        if ((rc = block_bwd(t, st, sb[s], m, gB, xhat))) return rc;                                              // gB = dz_b
+        float* gT = xhat;  // xhat is free again: reuse it for d t_s
+        if ((rc = linear_bwd_data(st, gB, H, P(t, sb[s].lin + ".weight"), gT, H, (int)m, H, H, 0))) return rc;
+        T_TRY(hipMemcpyAsync(gB, gT, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));                          // gB = d t_s
+        if ((rc = block_bwd(t, st, sa[s], m, gB, xhat))) return rc;                                              // gB = dz_a
+        if ((rc = linear_bwd_data(st, gB, H, P(t, sa[s].lin + ".weight"), gA, H, (int)m, H, H, 1))) return rc;   // da_s += ...
+    }
+    if ((rc = block_bwd(t, st, b0, m, gA, xhat))) return rc;
+    // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)
+    {
+        double* d_ss = t->d_red + 2 * H + 16;
+        T_TRY(hipMemsetAsync(d_ss, 0, sizeof(double), st));
+        hipLaunchKernelGGL(mlt::sumsq_kernel, dim3(512), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
+        const int64_t k = t->step + 1;
+        const float lr = t->lr0 * std::pow(t->gamma, (float)(t->step / t->sched_step));
+        const float bc1 = 1.f - std::pow(0.9f, (float)k), bc2 = 1.f - std::pow(0.999f, (float)k);
+        hipLaunchKernelGGL(mlt::clip_adam_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
+                           (const double*)d_ss, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);
+        if (update) t->step++;
+    }
+    T_TRY(hipStreamSynchronize(st));
+    if (losses_host) {
+        double tot = 0;
+        const int nt = (C == 10) ? 8 : 7;
+        for (int i = 0; i < nt; ++i) tot += lv[i];
+        losses_host[0] = tot;
+        for (int i = 0; i < 8; ++i) losses_host[1 + i] = lv[i];
+    }
+    return ML_OK;
+}
+
+}  // extern "C"

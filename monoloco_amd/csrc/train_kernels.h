@@ -1,0 +1,300 @@
+// train_kernels.h -- device kernels of the training step (reference monoloco/train/trainer.py:150-161,
+// losses.py:46-142, network/architectures.py:48-102 in train mode).  Everything is fp32 with exact-fp32
+// MFMA (v_mfma_f32_32x32x2_f32 == an fmaf chain), reductions accumulate in fp64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rng.h"
+
+namespace mlt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// Generic fp32 GEMM on the matrix cores:  C[i][j] = sum_k A(i,k) * B(k,j) (+ bias[j]) (+ C if accumulate)
+// with A(i,k) = a[i*sai + k*sak], B(k,j) = b[k*sbk + j*sbj]: covers x.W^T (forward), dz.W (data gradient)
+// and dz^T.x (weight gradient) without materialising transposes.  Tile 128x128x16, 4 waves (2x2), each
+// 64x64 = 2x2 MFMA 32x32x2 tiles; operands staged in LDS k-major so the fragment reads are contiguous.
+// Any M, N, K (zero fill at the edges).
+struct GemmParams {
+    const float* a;
+    const float* b;
+    const float* bias;  // [N] or nullptr
+    float* c;           // [M][ldc]
+    int M, N, K;
+    long sai, sak, sbk, sbj;
+    int ldc;
+    int accumulate;     // C += instead of C =
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;
+
+__global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
+    __shared__ float As[GBK * GLD];
+    __shared__ float Bs[GBK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w >> 1, wj = w & 1;
+    const int i0 = blockIdx.y * GBM, j0 = blockIdx.x * GBN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    // loader mapping: element index e8 = tid*8 .. +7 of the 128x16 tile.  If the "mn" dimension is the
+    // contiguous one in memory, consecutive threads walk along it; otherwise along k.
+    const bool a_mn = (p.sai == 1), b_mn = (p.sbj == 1);
+    for (int k0 = 0; k0 < p.K; k0 += GBK) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int ia, ka, jb, kb;
+            if (a_mn) { const int id = e * 256 + tid; ia = id & 127; ka = id >> 7; }
+            else      { const int id = e * 256 + tid; ka = id & 15;  ia = id >> 4; }
+            if (b_mn) { const int id = e * 256 + tid; jb = id & 127; kb = id >> 7; }
+            else      { const int id = e * 256 + tid; kb = id & 15;  jb = id >> 4; }
+            const int gi = i0 + ia, gka = k0 + ka, gj = j0 + jb, gkb = k0 + kb;
+            As[ka * GLD + ia] = (gi < p.M && gka < p.K) ? p.a[(long)gi * p.sai + (long)gka * p.sak] : 0.f;
+            Bs[kb * GLD + jb] = (gj < p.N && gkb < p.K) ? p.b[(long)gkb * p.sbk + (long)gj * p.sbj] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GBK; kk += 2) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                av[t] = As[(kk + (lane >> 5)) * GLD + wi * 64 + t * 32 + (lane & 31)];
+                bv[t] = Bs[(kk + (lane >> 5)) * GLD + wj * 64 + t * 32 + (lane & 31)];
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int j = j0 + wj * 64 + tj * 32 + (lane & 31);
+            const float bj = (p.bias && j < p.N) ? p.bias[j] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wi * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (i < p.M && j < p.N) {
+                    float v = acc[ti][tj][r] + bj;
+                    float* dst = p.c + (long)i * p.ldc + j;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column statistics over the batch: for each column j of z (m x n): sum and sum of squares in fp64
+// (two outputs), one workgroup per 64 columns, 4 row-groups per workgroup.
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ z, const float* __restrict__ w2,
+                                                        int64_t m, int n, double* __restrict__ s1,
+                                                        double* __restrict__ s2) {
+    // s1[j] = sum_i z[i][j]; s2[j] = sum_i z[i][j] * (w2 ? w2[i][j] : z[i][j])
+    __shared__ double r1[4][64], r2[4][64];
+    const int cj = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cj;
+    double a = 0.0, b = 0.0;
+    if (j < n)
+        for (int64_t i = blockIdx.y * 4 + rg; i < m; i += (int64_t)gridDim.y * 4) {
+            const double v = (double)z[i * n + j];
+            a += v;
+            b += v * (w2 ? (double)w2[i * n + j] : v);
+        }
+    r1[rg][cj] = a;
+    r2[rg][cj] = b;
+    __syncthreads();
+    if (rg == 0 && j < n) {
+        a = r1[0][cj] + r1[1][cj] + r1[2][cj] + r1[3][cj];
+        b = r2[0][cj] + r2[1][cj] + r2[2][cj] + r2[3][cj];
+        atomicAdd(&s1[j], a);
+        atomicAdd(&s2[j], b);
+    }
+}
+
+// BatchNorm1d, training mode (reference architectures.py:51,91,96 with nn.BatchNorm1d defaults): batch mean
+// and biased variance; running stats updated with momentum 0.1 (unbiased variance); then ReLU and inverted
+// dropout.  Stores invstd and mean for the backward pass; y = dropout(relu(g * (z - mean) * invstd + b)).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
+                                                         int64_t m, int n, float eps, float momentum,
+                                                         float* __restrict__ mean, float* __restrict__ invstd,
+                                                         float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const double mu = s1[j] / (double)m;
+    double var = s2[j] / (double)m - mu * mu;
+    if (var < 0) var = 0;
+    mean[j] = (float)mu;
+    invstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+    const double unb = m > 1 ? var * (double)m / (double)(m - 1) : var;
+    run_mean[j] = (1.f - momentum) * run_mean[j] + momentum * (float)mu;
+    run_var[j] = (1.f - momentum) * run_var[j] + momentum * (float)unb;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_drop_kernel(const float* __restrict__ z, int64_t m, int n,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float p_drop, uint32_t seed, uint32_t site,
+                                                          const float* __restrict__ residual, float* __restrict__ y) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= m * n) return;
+    const int j = (int)(id % n);
+    const int64_t i = id / n;
+    float v = gamma[j] * ((z[id] - mean[j]) * invstd[j]) + beta[j];
+    v = v > 0.f ? v : 0.f;
+    if (p_drop > 0.f) v = (mlk::u01(seed, (uint32_t)i * 4099u + site, (uint32_t)j) >= p_drop) ? v / (1.f - p_drop) : 0.f;
+    if (residual) v += residual[id];
+    y[id] = v;
+}
+
+// backward of dropout + ReLU (+ BN affine part): dy = dout * mask/(1-p) * (pre-dropout activation > 0), written
+// in place; also needs xhat = (z - mean) * invstd for the BN reductions, computed on the fly by the consumers.
+__global__ __launch_bounds__(256) void relu_drop_bwd_kernel(float* __restrict__ dout, const float* __restrict__ z,
+                                                           int64_t m, int n, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float p_drop, uint32_t seed,
+                                                           uint32_t site, float* __restrict__ xhat) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= m * n) return;
+    const int j = (int)(id % n);
+    const int64_t i = id / n;
+    const float xh = (z[id] - mean[j]) * invstd[j];
+    const float pre = gamma[j] * xh + beta[j];
+    float g = pre > 0.f ? dout[id] : 0.f;
+    if (p_drop > 0.f) g = (mlk::u01(seed, (uint32_t)i * 4099u + site, (uint32_t)j) >= p_drop) ? g / (1.f - p_drop) : 0.f;
+    dout[id] = g;
+    xhat[id] = xh;
+}
+
+// BN backward, elementwise part: dz = gamma*invstd/m * (m*dy - sum(dy) - xhat*sum(dy*xhat)); in place on dy
+__global__ __launch_bounds__(256) void bn_bwd_kernel(float* __restrict__ dy, const float* __restrict__ xhat, int64_t m, int n,
+                                                    const double* __restrict__ sdy, const double* __restrict__ sdyx,
+                                                    const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= m * n) return;
+    const int j = (int)(id % n);
+    const float a = (float)sdy[j], b = (float)sdyx[j];
+    const float g = gamma[j] * invstd[j] / (float)m;
+    dy[id] = g * ((float)m * dy[id] - a - xhat[id] * b);
+    if (id < n) {  // one thread per column publishes the parameter gradients
+        dgamma[j] = (float)sdyx[j];
+        dbeta[j] = (float)sdy[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void col_sum_to_float_kernel(const double* __restrict__ s, int n, float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) out[j] = (float)s[j];
+}
+
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id < n) a[id] += b[id];
+}
+
+// ------------------------------------------------------------------------------------------------
+// MultiTaskLoss of the reference (losses.py:59-73 with CompositeLoss :80-83): tasks d, x, y, h, w, l, ori
+// (+ aux for stereo), all lambdas 1.  out (m, C) raw network rows, lab (m, L) label rows
+// [theta, psi, z, d, h, w, l, sin, cos, yaw(, aux)] (process.py:293-301).  Writes dout (m, C) = dLoss/dout and
+// accumulates the 8 per-task mean losses in fp64 (index 0..7 = d, x, y, h, w, l, ori, aux).
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, int C, const float* __restrict__ lab, int L,
+                                                  int64_t m, float* __restrict__ dout, double* __restrict__ losses) {
+    __shared__ double red[8][256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < m) {
+        const float* o = out + i * C;
+        const float* y = lab + i * L;
+        float* g = dout + i * C;
+        const float invm = 1.f / (float)m;
+        // LaplacianLoss on (mu, s) = out[2:4] vs d = lab[3]: |1 - mu/x| exp(-s) + 0.01 + s + 2   (losses.py:112-131)
+        const float mu = o[2], s = o[3], x = y[3];
+        const float norm = 1.f - mu / x, es = expf(-s);
+        t[0] = (double)(fabsf(norm) * es + 0.01f + s + 2.f);
+        const float sg = norm > 0.f ? 1.f : (norm < 0.f ? -1.f : 0.f);
+        g[2] = -sg / x * es * invm;
+        g[3] = (1.f - fabsf(norm) * es) * invm;
+        // L1 on x (col 0 vs lab 0), y (1 vs 1), h, w, l (4..6 vs 4..6)
+        const int oc[5] = {0, 1, 4, 5, 6}, lc[5] = {0, 1, 4, 5, 6};
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const float d = o[oc[q]] - y[lc[q]];
+            t[1 + q] = (double)fabsf(d);
+            g[oc[q]] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * invm;
+        }
+        // L1 on ori (cols 7,8 vs lab 7,8): mean over 2m elements
+        double so = 0;
+#pragma unroll
+        for (int q = 7; q < 9; ++q) {
+            const float d = o[q] - y[q];
+            so += (double)fabsf(d);
+            g[q] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * invm * 0.5f;
+        }
+        t[6] = so * 0.5;
+        if (C == 10) {  // BCEWithLogits on the aux logit vs lab[10]
+            const float a = o[9], yy = y[10];
+            t[7] = (double)(fmaxf(a, 0.f) - a * yy + log1pf(expf(-fabsf(a))));
+            g[9] = (1.f / (1.f + expf(-a)) - yy) * invm;
+        } else if (C == 9) {
+            // mono: column 8 is (sin,cos)[1]; the aux head is the last column only for stereo -- nothing to do
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[q][threadIdx.x] = t[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 8) atomicAdd(&losses[threadIdx.x], red[threadIdx.x][0] / (double)m);
+}
+
+// sum of squares of a flat fp32 buffer (gradient norm), fp64
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
+    __shared__ double red[256];
+    double a = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += (double)g[i] * (double)g[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+
+// clip_grad_norm_(params, max_norm) (trainer.py:159; torch: coef = min(1, max_norm / (norm + 1e-6))) fused with
+// Adam (torch.optim.Adam defaults: betas 0.9/0.999, eps 1e-8, no weight decay, trainer.py:129) on the flat buffers.
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m1,
+                                                       float* __restrict__ m2, int64_t n, const double* __restrict__ sumsq,
+                                                       float max_norm, float lr, float b1, float b2, float eps, float bc1,
+                                                       float bc2, int do_adam) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float norm = (float)sqrt(*sumsq);
+    float coef = max_norm / (norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    const float gi = g[i] * coef;
+    g[i] = gi;
+    if (!do_adam) return;
+    const float a = m1[i] + (gi - m1[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = b2 * m2[i] + (1.f - b2) * gi * gi;
+    m1[i] = a;
+    m2[i] = v;
+    const float denom = sqrtf(v) / sqrtf(bc2) + eps;
+    w[i] -= (lr / bc1) * (a / denom);
+}
+
+}  // namespace mlt

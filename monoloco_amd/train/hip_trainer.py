@@ -1,0 +1,87 @@
+"""ctypes front-end of the ``ml_trainer_*`` C ABI: one LocoModel in train mode on one HIP device."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check, fptr
+from ..engine import _dev_f32, _ptr, _require_cuda, _stream
+
+TASKS = ('d', 'x', 'y', 'h', 'w', 'l', 'ori', 'aux')
+
+
+class HipTrainer:
+    """Parameters, Adam state and the training step live in the library; tensors cross by state_dict key."""
+
+    def __init__(self, state_dict, p_dropout=0.2, lr=0.002, sched_gamma=0.98, sched_step=30, seed=1, device=None):
+        self._h = None
+        lib = _lib.load()
+        self.device = _require_cuda(device)
+        w1 = state_dict['w1.weight']
+        self.hidden, self.in_features = int(w1.shape[0]), int(w1.shape[1])
+        self.out_features = int(state_dict['w_fin.weight'].shape[0]) + 1
+        self.num_stage = len({k.split('.')[1] for k in state_dict if k.startswith('linear_stages.')})
+        self.shapes = {k: tuple(v.shape) for k, v in state_dict.items() if not k.endswith('num_batches_tracked')}
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.ml_trainer_create(self.in_features, self.hidden, self.out_features, self.num_stage, float(p_dropout),
+                                        float(lr), float(sched_gamma), int(sched_step), int(seed), ctypes.byref(h)), train=True)
+            self._h = h
+            self.load_state_dict(state_dict)
+
+    def close(self):
+        if self._h is not None:
+            _lib.load().ml_trainer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, state_dict):
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            for key, val in state_dict.items():
+                if key.endswith('num_batches_tracked'):
+                    continue
+                arr = np.ascontiguousarray(val.detach().to('cpu', torch.float32).numpy() if isinstance(val, torch.Tensor)
+                                           else np.asarray(val, dtype=np.float32))
+                check(lib.ml_trainer_set_tensor(self._h, key.encode(), fptr(arr), arr.size), train=True)
+
+    def _get(self, fn, key):
+        arr = np.empty(self.shapes[key], dtype=np.float32)
+        with torch.cuda.device(self.device):
+            check(fn(self._h, key.encode(), fptr(arr), arr.size), train=True)
+        return torch.from_numpy(arr)
+
+    def state_dict(self):
+        lib = _lib.load()
+        return {k: self._get(lib.ml_trainer_get_tensor, k) for k in self.shapes}
+
+    def grads(self):
+        lib = _lib.load()
+        return {k: self._get(lib.ml_trainer_get_grad, k) for k in self.shapes if 'running_' not in k}
+
+    @property
+    def num_steps(self):
+        return int(_lib.load().ml_trainer_num_steps(self._h))
+
+    def step(self, inputs, labels, update=True, want_outputs=False):
+        """One training step (reference trainer.py:154-161).  Returns dict(loss, d, x, y, h, w, l, ori, aux)
+        [and the train-mode outputs]."""
+        dev = self.device
+        x = _dev_f32(inputs, dev)
+        y = _dev_f32(labels, dev)
+        m = x.shape[0]
+        assert y.shape[0] == m and x.shape[1] == self.in_features
+        losses = (ctypes.c_double * 9)()
+        raw = torch.empty((m, self.out_features), dtype=torch.float32, device=dev) if want_outputs else None
+        with torch.cuda.device(dev):
+            check(_lib.load().ml_trainer_step(self._h, _ptr(x), _ptr(y), int(y.shape[1]), m, int(bool(update)), losses,
+                                              _ptr(raw), _stream(dev)), train=True)
+        out = {'loss': losses[0]}
+        out.update({t: losses[1 + i] for i, t in enumerate(TASKS)})
+        return (out, raw) if want_outputs else out

@@ -1,0 +1,138 @@
+"""``Trainer`` with the reference's surface (monoloco/train/trainer.py:36-248) on the HIP training step.
+
+Same constructor contract (an argparse-like ``args`` with joints, epochs, lr, bs, hidden_size, n_stage, dropout,
+sched_step, sched_gamma, r_seed, mode, out, no_save), same loop (per epoch: a training pass with Adam + per-batch
+StepLR + clip 3, then a validation pass; the weights of the best validation 'd' epoch are kept, trainer.py:173-177)
+and ``evaluate`` saves a reference-compatible ``state_dict`` with ``torch.save``.  The dataset is the reference's
+``joints-*.json`` (KeypointsDataset, train/datasets.py:49-66); shuffling uses torch's DataLoader exactly as the
+reference does, so with ``--dropout 0`` the trajectory is comparable batch by batch.
+"""
+import copy
+import datetime
+import json
+import os
+import time
+from collections import defaultdict
+
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from ..network.architectures import LocoModel
+from .hip_trainer import HipTrainer
+
+
+class KeypointsDataset(Dataset):
+    """Inputs X (N, 34|68) and labels Y (N, 10|11) of one phase of a joints json (reference datasets.py:44-96)."""
+
+    def __init__(self, joints, phase):
+        assert phase in ['train', 'val', 'test']
+        with open(joints, 'r') as f:
+            dic_jo = json.load(f)
+        self.inputs_all = torch.tensor(dic_jo[phase]['X'])
+        self.outputs_all = torch.tensor(dic_jo[phase]['Y'])
+        self.names_all = dic_jo[phase]['names']
+        self.kps_all = torch.tensor(dic_jo[phase]['kps'])
+        self.version = dic_jo['version']
+        self.dic_clst = dic_jo[phase]['clst']
+
+    def __len__(self):
+        return self.inputs_all.shape[0]
+
+    def __getitem__(self, idx):
+        return self.inputs_all[idx, :], self.outputs_all[idx], self.names_all[idx], self.kps_all[idx, :]
+
+    def get_cluster_annotations(self, clst):
+        inputs = torch.tensor(self.dic_clst[clst]['X'])
+        outputs = torch.tensor(self.dic_clst[clst]['Y']).float()
+        return inputs, outputs, len(self.dic_clst[clst]['Y'])
+
+    def get_version(self):
+        return self.version
+
+
+class Trainer:
+    VAL_BS = 10000
+    tasks = ('d', 'x', 'y', 'h', 'w', 'l', 'ori', 'aux')
+    val_task = 'd'
+    input_size = dict(mono=34, stereo=68)
+    output_size = dict(mono=9, stereo=10)
+
+    def __init__(self, args):
+        assert os.path.exists(args.joints), "Input file not found"
+        self.mode = args.mode
+        self.joints = args.joints
+        self.num_epochs = args.epochs
+        self.no_save = getattr(args, 'no_save', False)
+        self.lr = args.lr
+        if getattr(args, 'out', None):
+            self.path_out = args.out
+        else:
+            name = 'monoloco_pp' if self.mode == 'mono' else 'monstereo'
+            self.path_out = os.path.join('data', 'outputs', name + '-' + datetime.datetime.now().strftime("%Y%m%d-%H%M")[2:] + '.pkl')
+        self.path_model = self.path_out
+        self.device = torch.device('cuda')
+        torch.manual_seed(args.r_seed)
+        if self.mode == 'mono':
+            self.tasks = self.tasks[:-1]
+        self.dataloaders = {phase: DataLoader(KeypointsDataset(self.joints, phase=phase), batch_size=args.bs, shuffle=True)
+                            for phase in ['train', 'val']}
+        self.dataset_sizes = {phase: len(KeypointsDataset(self.joints, phase=phase)) for phase in ['train', 'val']}
+        # same construction order as the reference (trainer.py:115-123), hence the same default initialisation
+        self.model = LocoModel(input_size=self.input_size[self.mode], output_size=self.output_size[self.mode],
+                               linear_size=args.hidden_size, p_dropout=args.dropout, num_stage=args.n_stage)
+        self.hip = HipTrainer(self.model.state_dict(), p_dropout=args.dropout, lr=args.lr, sched_gamma=args.sched_gamma,
+                              sched_step=int(args.sched_step), seed=args.r_seed, device=self.device)
+        self.epoch_losses = defaultdict(lambda: defaultdict(list))
+
+    def _val_losses(self, inputs, labels):
+        """Validation metrics of the reference (losses.py:85-96): L1 from Laplace for d, L1, angle error for ori."""
+        from ..engine import LocoEngine
+        eng = LocoEngine(self.hip.state_dict(), device=self.device, merge_w2w3=True) if self.model.linear_size % 256 == 0 else None
+        if eng is None:
+            return {}
+        out = eng.forward_raw(inputs.to(self.device)).cpu()
+        eng.close()
+        lab = labels
+        vals = {'d': (out[:, 2:3] - lab[:, 3:4]).abs().mean().item()}
+        for t, c in (('x', 0), ('y', 1), ('h', 4), ('w', 5), ('l', 6)):
+            vals[t] = (out[:, c] - lab[:, c]).abs().mean().item()
+        ang = torch.atan2(out[:, 7], out[:, 8]) - torch.atan2(lab[:, 7], lab[:, 8])
+        vals['ori'] = ang.abs().mean().item() * 180 / 3.14
+        return vals
+
+    def train(self):
+        since = time.time()
+        best_wts = copy.deepcopy(self.hip.state_dict())
+        best_acc, best_epoch = 1e6, 0
+        for epoch in range(self.num_epochs):
+            running = defaultdict(lambda: defaultdict(float))
+            for inputs, labels, _, _ in self.dataloaders['train']:
+                losses = self.hip.step(inputs, labels, update=True)
+                for k, v in losses.items():
+                    running['train'][k] += v * inputs.size(0)
+            for inputs, labels, _, _ in self.dataloaders['val']:
+                vals = self._val_losses(inputs, labels)
+                for k, v in vals.items():
+                    running['val'][k] += v * inputs.size(0)
+            for phase in running:
+                for k, v in running[phase].items():
+                    self.epoch_losses[phase][k].append(v / self.dataset_sizes[phase])
+            val_d = self.epoch_losses['val'][self.val_task][-1] if self.epoch_losses['val'][self.val_task] else 0.0
+            if val_d < best_acc:
+                best_acc, best_epoch = val_d, epoch
+                best_wts = copy.deepcopy(self.hip.state_dict())
+        self.training_time = time.time() - since
+        self.hip.load_state_dict(best_wts)
+        return best_epoch
+
+    def evaluate(self, load=False, model=None, debug=False):
+        if load:
+            self.hip.load_state_dict(torch.load(model, map_location=lambda storage, loc: storage))
+        sd = self.hip.state_dict()
+        self.model.load_state_dict(sd, strict=False)
+        dataset = KeypointsDataset(self.joints, phase='val')
+        inputs, labels, _, _ = dataset[0:len(dataset)]
+        dic_err = {'val': {'all': self._val_losses(inputs, labels)}}
+        if not (self.no_save or load):
+            torch.save({k: v.clone() for k, v in self.model.state_dict().items()}, self.path_model)
+        return dic_err, self.model

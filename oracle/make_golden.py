@@ -232,5 +232,58 @@ def main():
         print('  %-28s %8.1f KiB' % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+
+
+def golden_train():
+    """Three iterations of the reference's own training loop body (trainer.py:150-161) with dropout 0 on its
+    mono and stereo fixtures, from seeded weights: per-step losses, the clipped gradients of step 1, the state
+    after step 3."""
+    import itertools
+    from monoloco.train.losses import CompositeLoss, MultiTaskLoss
+    g = {}
+    for mode, in_f, out_f, seed in (('mono', 34, 9, 7), ('stereo', 68, 10, 8)):
+        hidden = 128
+        dj = json.load(open(os.path.join(REF, 'tests', 'sample_joints-kitti-%s.json' % mode)))
+        x = torch.tensor(dj['train']['X'])
+        y = torch.tensor(dj['train']['Y'])
+        tasks = ('d', 'x', 'y', 'h', 'w', 'l', 'ori') + (('aux',) if mode == 'stereo' else ())
+        losses_tr, losses_val = CompositeLoss(tasks)()
+        mt = MultiTaskLoss(losses_tr, losses_val, (1,) * len(tasks), tasks)
+        model = LocoModel(in_f, out_f, hidden, p_dropout=0.0, device='cpu')
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(seed, in_f, out_f, hidden).items()},
+                              strict=False)
+        model.train()
+        opt = torch.optim.Adam(params=itertools.chain(model.parameters(), mt.parameters()), lr=0.001)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.5)   # small step so that the decay is exercised
+        for step in range(3):
+            opt.zero_grad()
+            out = model(x)
+            loss, vals = mt(out, y, phase='train')
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 3)
+            if step == 0:
+                g[mode + '_out0'] = out.detach().numpy()
+                for k, p in model.named_parameters():
+                    g[mode + '_grad0/' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+            opt.step()
+            sched.step()
+            g[mode + '_loss%d' % step] = np.array([float(loss)] + [float(v) for v in vals])
+        for k, v in model.state_dict().items():
+            if v.dtype.is_floating_point:
+                g[mode + '_final/' + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'golden_train.npz'), **g)
+    # the batches themselves (train/val split X, Y of the reference's fixtures), inputs of these goldens
+    inp = {}
+    for mode in ('mono', 'stereo'):
+        dj = json.load(open(os.path.join(REF, 'tests', 'sample_joints-kitti-%s.json' % mode)))
+        for ph, tag in (('train', ''), ('val', 'val')):
+            inp[mode + '_x' + tag] = np.asarray(dj[ph]['X'], dtype=np.float32)
+            inp[mode + '_y' + tag] = np.asarray(dj[ph]['Y'], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, 'golden_train_inputs.npz'), **inp)
+    print('golden_train.npz %.1f KiB' % (os.path.getsize(os.path.join(OUT, 'golden_train.npz')) / 1024))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train':
+    golden_train()
