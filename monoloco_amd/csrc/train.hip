@@ -59,6 +59,8 @@ struct ml_trainer {
     float *d_out = nullptr, *d_dout = nullptr, *d_y2aux = nullptr;
     float *bn_mean = nullptr, *bn_invstd = nullptr;  // (nbn x H)
     double* d_red = nullptr;                          // scratch for fp64 reductions (2*H + 16)
+    float* d_splitk = nullptr;                        // split-K partials of the weight-gradient GEMMs
+    size_t splitk_cap = 0;                            // floats
     int nbn = 0;
 };
 
@@ -94,9 +96,33 @@ int gemm(hipStream_t st, const float* a, long sai, long sak, const float* b, lon
     p.M = M; p.N = N; p.K = K;
     p.sai = sai; p.sak = sak; p.sbk = sbk; p.sbj = sbj;
     p.ldc = ldc; p.accumulate = accumulate;
+    p.kchunk = K;
     dim3 grid((N + mlt::GBN - 1) / mlt::GBN, (M + mlt::GBM - 1) / mlt::GBM);
     hipLaunchKernelGGL(mlt::sgemm_kernel, grid, dim3(256), 0, st, p);
     if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "sgemm launch failed");
+    return 0;
+}
+
+// weight-gradient shape: a long reduction (K = batch) into a small output.  Split the reduction over blockIdx.z
+// into a partial buffer and add the partials in a fixed order (deterministic, unlike atomics).
+int gemm_splitk(ml_trainer* t, hipStream_t st, const float* a, long sai, long sak, const float* b, long sbk, long sbj, float* c,
+                int ldc, int M, int N, int K) {
+    int tiles = ((N + mlt::GBN - 1) / mlt::GBN) * ((M + mlt::GBM - 1) / mlt::GBM);
+    int splits = 1;
+    while (splits < 32 && tiles * splits < 512 && K / (splits * 2) >= 2048) splits *= 2;
+    if (splits == 1 || (size_t)splits * M * ldc > t->splitk_cap) return gemm(st, a, sai, sak, b, sbk, sbj, nullptr, c, ldc, M, N, K, 0);
+    mlt::GemmParams p;
+    p.a = a; p.b = b; p.bias = nullptr; p.c = t->d_splitk;
+    p.M = M; p.N = N; p.K = K;
+    p.sai = sai; p.sak = sak; p.sbk = sbk; p.sbj = sbj;
+    p.ldc = ldc; p.accumulate = 0;
+    p.kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
+    dim3 grid((N + mlt::GBN - 1) / mlt::GBN, (M + mlt::GBM - 1) / mlt::GBM, splits);
+    hipLaunchKernelGGL(mlt::sgemm_kernel, grid, dim3(256), 0, st, p);
+    const int64_t n = (int64_t)M * ldc;
+    hipLaunchKernelGGL(mlt::splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)t->d_splitk,
+                       splits, n, c);
+    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "split-K sgemm launch failed");
     return 0;
 }
 // y (m x n) = x (m x k) . W^T + b           (nn.Linear forward)
@@ -108,8 +134,9 @@ int linear_bwd_data(hipStream_t st, const float* dy, int lddy, const float* W, f
     return gemm(st, dy, lddy, 1, W, k, 1, nullptr, dx, lddx, m, k, n, acc);
 }
 // dW (n x k) = dy^T (n x m) . x (m x k)
-int linear_bwd_weight(hipStream_t st, const float* dy, int lddy, const float* x, int ldx, float* dW, int m, int n, int k) {
-    return gemm(st, dy, 1, lddy, x, ldx, 1, nullptr, dW, k, n, k, m, 0);
+int linear_bwd_weight(ml_trainer* t, hipStream_t st, const float* dy, int lddy, const float* x, int ldx, float* dW, int m, int n,
+                      int k) {
+    return gemm_splitk(t, st, dy, 1, lddy, x, ldx, 1, dW, k, n, k, m);
 }
 
 unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
@@ -168,7 +195,7 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
     if ((rc = col_stats(t, st, dout, nullptr, m, H))) return rc;
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red, H,
                        G(t, b.lin + ".bias"));
-    return linear_bwd_weight(st, dout, H, b.x, b.in_dim, G(t, b.lin + ".weight"), (int)m, H, b.in_dim);
+    return linear_bwd_weight(t, st, dout, H, b.x, b.in_dim, G(t, b.lin + ".weight"), (int)m, H, b.in_dim);
 }
 
 int ensure_cap(ml_trainer* t, int64_t m) {
@@ -227,6 +254,8 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
     T_TRY(hipMalloc((void**)&t->bn_mean, (size_t)t->nbn * hidden * 4));
     T_TRY(hipMalloc((void**)&t->bn_invstd, (size_t)t->nbn * hidden * 4));
     T_TRY(hipMalloc((void**)&t->d_red, (size_t)(2 * hidden + 32) * sizeof(double)));
+    t->splitk_cap = (size_t)32 * hidden * (hidden > in_features ? hidden : in_features);
+    T_TRY(hipMalloc((void**)&t->d_splitk, t->splitk_cap * 4));
     T_TRY(hipMemset(t->w, 0, (size_t)t->n_param * 4));
     T_TRY(hipMemset(t->g, 0, (size_t)t->n_param * 4));
     T_TRY(hipMemset(t->m1, 0, (size_t)t->n_param * 4));
@@ -240,7 +269,7 @@ int ml_trainer_destroy(ml_trainer* t) {
     if (!t) return ML_OK;
     (void)hipDeviceSynchronize();
     for (float* p : t->bufs) (void)hipFree(p);
-    void* ptrs[] = {t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red};
+    void* ptrs[] = {t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -333,16 +362,16 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)t->d_red, C - 1, G(t, "w_fin.bias"));
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)(t->d_red + (C - 1)), 1,
                        G(t, "w_aux.bias"));
-    if ((rc = linear_bwd_weight(st, t->d_dout, C, y3, H, G(t, "w_fin.weight"), (int)m, C - 1, H))) return rc;
+    if ((rc = linear_bwd_weight(t, st, t->d_dout, C, y3, H, G(t, "w_fin.weight"), (int)m, C - 1, H))) return rc;
     if ((rc = linear_bwd_data(st, t->d_dout, C, P(t, "w_fin.weight"), gA, H, (int)m, C - 1, H, 0))) return rc;  // dy3
     if ((rc = block_bwd(t, st, b3, m, gA, xhat))) return rc;                                                     // gA = dz3
     if ((rc = linear_bwd_data(st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0))) return rc;                 // gB = dy2
-    if ((rc = linear_bwd_weight(st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H))) return rc;
+    if ((rc = linear_bwd_weight(t, st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H))) return rc;
     if ((rc = linear_bwd_data(st, t->d_dout + (C - 1), C, P(t, "w_aux.weight"), gB, H, (int)m, 1, H, 1))) return rc;  // += daux (x) w_aux
     // y2 = w2 a_S + b2
     if ((rc = col_stats(t, st, gB, nullptr, m, H))) return rc;
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red, H, G(t, "w2.bias"));
-    if ((rc = linear_bwd_weight(st, gB, H, a[S], H, G(t, "w2.weight"), (int)m, H, H))) return rc;
+    if ((rc = linear_bwd_weight(t, st, gB, H, a[S], H, G(t, "w2.weight"), (int)m, H, H))) return rc;
     if ((rc = linear_bwd_data(st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0))) return rc;                 // gA = da_S
     // residual stages, last to first:  a_{s+1} = a_s + B(A(a_s))
     for (int s = S - 1; s >= 0; --s) {

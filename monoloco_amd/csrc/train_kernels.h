@@ -20,21 +20,59 @@ struct GemmParams {
     const float* a;
     const float* b;
     const float* bias;  // [N] or nullptr
-    float* c;           // [M][ldc]
+    float* c;           // [M][ldc]  (split-K: partial z goes to c + z * M * ldc, bias/accumulate ignored)
     int M, N, K;
     long sai, sak, sbk, sbj;
     int ldc;
     int accumulate;     // C += instead of C =
+    int kchunk;         // K range per blockIdx.z (multiple of 16); K if not split
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = 132;
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one operand tile (128 "mn" x 16 k) from global memory into registers (8 floats per thread), fast path:
+// the tile is fully inside the matrix and the contiguous dimension has 16-byte aligned rows
+struct TileRegs {
+    f32x4 v[2];
+};
+__device__ __forceinline__ TileRegs load_tile_fast(const float* base, long s_mn, long s_k, int mn0, int k0, int tid) {
+    TileRegs r;
+    if (s_mn == 1) {  // mn contiguous: thread -> (k = tid/16, mn = 8*(tid%16) .. +7)
+        const float* p = base + (long)(k0 + (tid >> 4)) * s_k + mn0 + (tid & 15) * 8;
+        r.v[0] = *(const f32x4*)p;
+        r.v[1] = *(const f32x4*)(p + 4);
+    } else {          // k contiguous: thread -> (mn = tid/2, k = 8*(tid%2) .. +7)
+        const float* p = base + (long)(mn0 + (tid >> 1)) * s_mn + k0 + (tid & 1) * 8;
+        r.v[0] = *(const f32x4*)p;
+        r.v[1] = *(const f32x4*)(p + 4);
+    }
+    return r;
+}
+__device__ __forceinline__ void store_tile_fast(float* lds, const TileRegs& r, bool mn_contig, int tid) {
+    if (mn_contig) {
+        float* q = lds + (tid >> 4) * GLD + (tid & 15) * 8;
+        *(f32x4*)q = r.v[0];
+        *(f32x4*)(q + 4) = r.v[1];
+    } else {
+        const int mn = tid >> 1, kb = (tid & 1) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lds[(kb + e) * GLD + mn] = r.v[0][e];
+            lds[(kb + 4 + e) * GLD + mn] = r.v[1][e];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
-    __shared__ float As[GBK * GLD];
-    __shared__ float Bs[GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float As[GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK * GLD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w >> 1, wj = w & 1;
     const int i0 = blockIdx.y * GBM, j0 = blockIdx.x * GBN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -42,22 +80,12 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    // loader mapping: element index e8 = tid*8 .. +7 of the 128x16 tile.  If the "mn" dimension is the
-    // contiguous one in memory, consecutive threads walk along it; otherwise along k.
     const bool a_mn = (p.sai == 1), b_mn = (p.sbj == 1);
-    for (int k0 = 0; k0 < p.K; k0 += GBK) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int ia, ka, jb, kb;
-            if (a_mn) { const int id = e * 256 + tid; ia = id & 127; ka = id >> 7; }
-            else      { const int id = e * 256 + tid; ka = id & 15;  ia = id >> 4; }
-            if (b_mn) { const int id = e * 256 + tid; jb = id & 127; kb = id >> 7; }
-            else      { const int id = e * 256 + tid; kb = id & 15;  jb = id >> 4; }
-            const int gi = i0 + ia, gka = k0 + ka, gj = j0 + jb, gkb = k0 + kb;
-            As[ka * GLD + ia] = (gi < p.M && gka < p.K) ? p.a[(long)gi * p.sai + (long)gka * p.sak] : 0.f;
-            Bs[kb * GLD + jb] = (gj < p.N && gkb < p.K) ? p.b[(long)gkb * p.sbk + (long)gj * p.sbj] : 0.f;
-        }
-        __syncthreads();
+    // fast path: whole tile in range, one unit stride per operand, 16-byte aligned rows
+    const bool fast = (i0 + GBM <= p.M) && (j0 + GBN <= p.N) && ((kend - kbeg) % GBK == 0) && (p.sai == 1 || p.sak == 1) &&
+                      (p.sbj == 1 || p.sbk == 1) && (((a_mn ? p.sak : p.sai) & 3) == 0) && (((b_mn ? p.sbk : p.sbj) & 3) == 0) &&
+                      ((((size_t)p.a) & 15) == 0) && ((((size_t)p.b) & 15) == 0);
+    auto mma = [&]() {
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 2) {
             float av[2], bv[2];
@@ -72,25 +100,67 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
                 for (int tj = 0; tj < 2; ++tj)
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
         }
-        __syncthreads();
+    };
+    if (fast) {
+        TileRegs ra = load_tile_fast(p.a, p.sai, p.sak, i0, kbeg, tid);
+        TileRegs rb = load_tile_fast(p.b, p.sbj, p.sbk, j0, kbeg, tid);
+        for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+            store_tile_fast(As, ra, a_mn, tid);
+            store_tile_fast(Bs, rb, b_mn, tid);
+            __syncthreads();
+            if (k0 + GBK < kend) {  // prefetch the next k tile while this one is multiplied
+                ra = load_tile_fast(p.a, p.sai, p.sak, i0, k0 + GBK, tid);
+                rb = load_tile_fast(p.b, p.sbj, p.sbk, j0, k0 + GBK, tid);
+            }
+            mma();
+            __syncthreads();
+        }
+    } else {
+        for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int ia, ka, jb, kb;
+                const int id = e * 256 + tid;
+                if (a_mn) { ia = id & 127; ka = id >> 7; } else { ka = id & 15; ia = id >> 4; }
+                if (b_mn) { jb = id & 127; kb = id >> 7; } else { kb = id & 15; jb = id >> 4; }
+                const int gi = i0 + ia, gka = k0 + ka, gj = j0 + jb, gkb = k0 + kb;
+                As[ka * GLD + ia] = (gi < p.M && gka < kend) ? p.a[(long)gi * p.sai + (long)gka * p.sak] : 0.f;
+                Bs[kb * GLD + jb] = (gj < p.N && gkb < kend) ? p.b[(long)gkb * p.sbk + (long)gj * p.sbj] : 0.f;
+            }
+            __syncthreads();
+            mma();
+            __syncthreads();
+        }
     }
+    const bool split = gridDim.z > 1;
+    float* cbase = p.c + (split ? (size_t)blockIdx.z * p.M * p.ldc : 0);
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
             const int j = j0 + wj * 64 + tj * 32 + (lane & 31);
-            const float bj = (p.bias && j < p.N) ? p.bias[j] : 0.f;
+            const float bj = (!split && p.bias && j < p.N) ? p.bias[j] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + wi * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (i < p.M && j < p.N) {
                     float v = acc[ti][tj][r] + bj;
-                    float* dst = p.c + (long)i * p.ldc + j;
-                    if (p.accumulate) v += *dst;
+                    float* dst = cbase + (long)i * p.ldc + j;
+                    if (!split && p.accumulate) v += *dst;
                     *dst = v;
                 }
             }
         }
+}
+
+// deterministic split-K combine: c[i] = sum_z part[z][i]  (n = M*ldc elements)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t n,
+                                                           float* __restrict__ c) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += part[(int64_t)z * n + i];
+    c[i] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
