@@ -166,7 +166,7 @@ def main():
             line["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16_DENSE, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_F16_DENSE, 4), "traffic": traffic_from_profiles(args),
-                "kernel": "mlk::dense_kernel_pp<%d,*,*>" % (3 if args.precision == 'f16x2' else 1),
+                "kernel": "mlk::dense_kernel_pp<%d,*,*,*>" % (3 if args.precision == 'f16x2' else 1),
                 "launches": prof['launches'], "avg_launch_ms": round(prof['total_ms'] / prof['launches'], 5),
                 "per_layer_avg_ms": [round(a / max(n, 1), 5) for a, n in zip(prof['per_layer_ms'], prof['per_layer_n'])],
                 "note": "achieved = algorithmic FLOP of the reference layer structure (%d/row) / summed dense-kernel "

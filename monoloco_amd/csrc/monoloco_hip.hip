@@ -517,11 +517,11 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             const Head* fused = nullptr;
             for (const Head& hd : h->heads)
                 if (hd.after_layer == (int)li && (hd.nh == 8 || hd.nh == 9) && dense_variant() != 1 && L.relu && L.res < 0 &&
-                    chunk == m_pad_all && !dense_debug_bits() && mc.p <= 0.f)
+                    !dense_debug_bits() && mc.p <= 0.f)
                     fused = &hd;
             if (fused) {
                 p.head_w = fused->d_w;
-                p.head_part = h->d_part;
+                p.head_part = h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16;
             }
             const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
             if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
@@ -534,7 +534,8 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             }
             if (fused && rows_here > 0) {
                 hipLaunchKernelGGL(mlk::head_reduce_kernel, dim3((unsigned)((rows_here * 16 + 255) / 256)), dim3(256), 0, st,
-                                   (const float*)h->d_part, 2 * h->hidden / 256, m_pad, rows_here, fused->nh,
+                                   (const float*)(h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16), 2 * h->hidden / 256, m_pad,
+                                   rows_here, fused->nh,
                                    (const float*)fused->d_b, raw_out + r0 * h->out_f, h->out_f, fused->col0);
                 HIP_TRY(hipGetLastError());
             }
