@@ -192,6 +192,31 @@ int64_t ml_trainer_num_steps(const ml_trainer* t);
 int ml_trainer_destroy(ml_trainer* t);
 const char* ml_train_last_error(void);
 
+/* ---- on-disk formats either side of the path (host only; no GPU, no HIP calls) ---------- */
+/* Counts the annotation objects of an OpenPifPaf `*.predictions.json` text (a top-level array). */
+int ml_pifpaf_count(const char* json, int64_t len, int64_t* n_annotations);
+/* json.load + preprocess_pifpaf (monoloco/network/process.py:155-207, prepare_pif_kps :210-218) in one pass
+ * over the JSON text: per annotation 'keypoints' (51 numbers) -> [xs(17), ys(17), cs(17)]; 'bbox' grown by
+ * h/10, w/5 (x,y,w,h boxes, when a 'score' key exists) or by 1/7, 1/3.5 of its height/width (corner boxes,
+ * conf = numpy float64 mean of the 17 confidences), halved when enlarge_boxes == 0, clamped to
+ * (im_w, im_h) when has_im_size != 0; annotations with conf < min_conf are dropped.  boxes (cap,5) =
+ * x1,y1,x2,y2,conf and keypoints (cap,3,17) are doubles, bit-identical to the Python floats of the
+ * reference; *m = rows written.  Errors: ML_ERR_ARG (syntax, missing key, "Bounding box <=0", cap too
+ * small), ML_ERR_SHAPE (wrong keypoint / bbox count); text in ml_formats_last_error(). */
+int ml_pifpaf_parse(const char* json, int64_t len, int has_im_size, double im_w, double im_h, int enlarge_boxes,
+                    double min_conf, int64_t cap, double* boxes, double* keypoints, int64_t* m);
+/* The lines save_txts writes for one image (monoloco/eval/generate_kitti.py:202-253):
+ * "<Pedestrian|Cyclist> -1 -1 alpha x1 y1 x2 y2 h w l x y z ry conf bi epi \n", every number as "%f ".
+ * boxes (m,5) as returned by preprocess_pifpaf; xyz (m,3); tt (3) is subtracted from xyz when not NULL;
+ * zz_override (m) replaces z when not NULL ('geometric'); alpha / ry NULL -> -10; hwl (m,3) NULL -> 0;
+ * cat (m): < 0.1 is a pedestrian; conf = conf_scale * box_conf / (bi / |xyz|).  With out == NULL only
+ * the needed size is returned in *written. */
+int ml_kitti_txt_format(int64_t m, const double* boxes, const double* xyz, const double* bi, const double* epi,
+                        const double* alpha, const double* ry, const double* hwl, const double* zz_override,
+                        const double* tt, const double* cat, double conf_scale, char* out, int64_t cap,
+                        int64_t* written);
+const char* ml_formats_last_error(void);
+
 /* ---- measurement: per-launch timing of the dense (MFMA) kernel ----------------------- */
 /* After ml_loco_profile_begin, every dense-kernel launch made through this handle is bracketed by
  * a pair of HIP events recorded on the launch stream (up to max_launches launches).

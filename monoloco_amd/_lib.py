@@ -58,6 +58,11 @@ SIGNATURES = {
     'ml_trainer_num_steps': (c_int64, [_P]),
     'ml_trainer_destroy': (c_int, [_P]),
     'ml_train_last_error': (c_char_p, []),
+    'ml_pifpaf_count': (c_int, [c_char_p, c_int64, POINTER(c_int64)]),
+    'ml_pifpaf_parse': (c_int, [c_char_p, c_int64, c_int, c_double, c_double, c_int, c_double, c_int64,
+                                POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
+    'ml_kitti_txt_format': (c_int, [c_int64] + [POINTER(c_double)] * 10 + [c_double, _P, c_int64, POINTER(c_int64)]),
+    'ml_formats_last_error': (c_char_p, []),
     'ml_loco_profile_begin': (c_int, [_P, c_int]),
     'ml_loco_profile_end': (c_int, [_P, POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_int]),
     'ml_debug_linear': (c_int, [_P, c_int64, c_int, POINTER(c_float), POINTER(c_float), c_int, c_int, _P, _P,

@@ -287,3 +287,81 @@ def golden_train():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train':
     golden_train()
+
+
+def golden_formats():
+    """On-disk formats: the reference's preprocess_pifpaf on JSON texts (fixture + a synthetic x,y,w,h/'score'
+    list) and the reference's save_txts (eval/generate_kitti.py:202-253) for every `net` branch on seeded
+    synthetic outputs.  Stored as JSON (Python's float repr round-trips doubles exactly)."""
+    os.makedirs('/tmp/make_golden/data/logs', exist_ok=True)
+    os.chdir('/tmp/make_golden')  # monoloco.eval asserts that data/logs exists relative to the cwd
+    sys.modules.setdefault('torchvision.models', types.ModuleType('torchvision.models'))
+    from monoloco.eval.generate_kitti import save_txts
+    gold = {'pifpaf': [], 'kitti': []}
+    fixture = open(os.path.join(REF, 'tests', '002282.png.pifpaf.json')).read()
+    rng = np.random.default_rng(5)
+    synth_anns = []
+    for i in range(23):
+        kp = []
+        for _ in range(17):
+            kp += [float(rng.uniform(-20, 1300)), float(rng.uniform(-20, 400)), float(rng.uniform(0, 1))]
+        ann = {'keypoints': kp, 'bbox': [float(rng.uniform(-30, 1200)), float(rng.uniform(-30, 350)),
+                                          float(rng.uniform(1, 200)), float(rng.uniform(1, 300))],
+               'score': float(rng.uniform(0, 1)), 'category_id': 1, 'extra': {'a': [1, {"b": 'x"y\\z ]}'}], 'c': None}}
+        if i % 5 == 0:
+            ann['bbox'] = [int(v) for v in ann['bbox']]  # ints in the JSON
+        if i % 7 == 0:
+            ann['score'] = 1
+        synth_anns.append(ann)
+    synth_text = json.dumps(synth_anns, indent=1)
+    texts = {'fixture': fixture, 'synthetic_score': synth_text, 'empty': '[]'}
+    gold['texts'] = {'synthetic_score': synth_text, 'empty': '[]'}
+    for name, text in texts.items():
+        for kw in (dict(), dict(im_size=[1238, 374], enlarge_boxes=False), dict(im_size=[1238, 374], min_conf=0.45),
+                   dict(enlarge_boxes=False, min_conf=0.2)):
+            boxes, kps = preprocess_pifpaf(json.loads(text), **{k: (tuple(v) if isinstance(v, list) else v)
+                                                              for k, v in kw.items()})
+            gold['pifpaf'].append({'text': name, 'kwargs': kw, 'boxes': boxes, 'keypoints': kps})
+
+    torch.manual_seed(11)
+    m = 9
+    boxes = [[float(rng.uniform(0, 600)), float(rng.uniform(0, 200)), float(rng.uniform(600, 1238)),
+              float(rng.uniform(200, 374)), float(rng.uniform(0.05, 1))] for _ in range(m)]
+    xyzd = torch.randn(m, 4) * torch.tensor([5., 1., 10., 1.]) + torch.tensor([0., 1., 20., 20.])
+    bis = torch.rand(m, 1) * 2 + 0.1
+    epis = [0.] * (m - 3) + [float(v) for v in torch.rand(3)]
+    yaws = (torch.rand(m, 1) * 6 - 3, torch.rand(m, 1) * 6 - 3)
+    hs, ws, ls = torch.rand(m, 1) + 1, torch.rand(m, 1), torch.rand(m, 1)
+    dds = torch.rand(m, 1) * 30 + 1
+    xy_centers = torch.cat((torch.randn(m, 2) * 0.3, torch.ones(m, 1)), dim=1)
+    zzs_geom = [float(v) for v in torch.rand(m) * 30 + 1]
+    cat = [0.0, 1.0, 0.05, 0.2, 0.0, 0.0, 1.0, 0.0, 0.099][:m]
+    tt = [0.06, -0.01, 0.003]
+    xyz_b = [[float(v) for v in row] for row in torch.randn(m, 3) * 4 + torch.tensor([0., 1., 15.])]
+    cases = {
+        'monoloco_pp': ([xyzd, bis, epis, yaws, hs, ws, ls], [None, None]),
+        'monstereo': ([xyzd, bis, epis, yaws, hs, ws, ls], [None, None]),
+        'monoloco': ([dds, bis, epis, zzs_geom, xy_centers], [None, None]),
+        'geometric': ([dds, bis, epis, zzs_geom, xy_centers], [None, None]),
+        'baseline': ([xyz_b, bis, epis, zzs_geom, xy_centers], [None, tt]),
+    }
+
+    def plain(x):
+        if isinstance(x, torch.Tensor):
+            return {'tensor': x.tolist()}
+        if isinstance(x, tuple):
+            return {'tuple': [plain(v) for v in x]}
+        return x
+
+    for net, (outs, params) in cases.items():
+        path = os.path.join('/tmp/make_golden', 'kitti_%s.txt' % net)
+        save_txts(path, copy.deepcopy(boxes), outs, params, net=net, cat=cat)
+        gold['kitti'].append({'net': net, 'boxes': boxes, 'outputs': [plain(o) for o in outs], 'params': params,
+                              'cat': cat, 'text': open(path).read()})
+    with open(os.path.join(OUT, 'golden_formats.json'), 'w') as f:
+        json.dump(gold, f)
+    print('wrote golden_formats.json:', len(gold['pifpaf']), 'pifpaf cases,', len(gold['kitti']), 'kitti cases')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'formats':
+    golden_formats()
