@@ -1,0 +1,126 @@
+// dense_small_kernel — the same Linear(+folded BN)+ReLU(+residual) layer as dense_kernel_pp, for SMALL row
+// counts (a single image: a handful to a few hundred persons; reference use: Loco.forward per frame,
+// monoloco/network/net.py:83-133).  The 256x256-tile persistent kernel keeps only (rows/256)*(N/256)
+// CUs busy there and costs ~75 us per layer whatever the row count; here the layer is cut into
+// 16 (n) x 16 (m) output tiles so that even 16 persons spread over N/16 = 64 workgroups, every wave
+// streams its operands straight from L2 into MFMA registers (no LDS staging: nothing is reused inside a
+// 16x16 tile) and the K range is split over the 4 waves of the workgroup.
+//
+//   grid  = (N/16, ceil(rows/16)),  block = 256 threads = 4 waves, wave w takes the k32 lines w, w+4, ...
+//   MFMA  = v_mfma_f32_16x16x32_f16, A = 16 weight rows, B = 16 persons, hi*hi + hi*lo + lo*hi
+//   operand fetch: lane (r = lane&15, q = lane>>4) loads 16 B = k 8q..8q+7 of row r: chunk q of the line is the
+//                  hi half, chunk 4+q the lo half -- exactly the A/B register layout of the 16x16x32 MFMA
+//   reduce: the 4 partial accumulators meet in 4 KiB of LDS; wave 0 finishes: * 2^-e, ReLU, + residual,
+//           split to fp16 hi+lo, 8-byte stores into the line format (D: person = lane&15, n = 4q + reg)
+// Arithmetic is the same as the big kernel (same operands, fp32 accumulation, same epilogue); only the order
+// of the fp32 accumulation differs.
+#pragma once
+#include "dense_kernel.h"
+
+namespace mlk {
+
+constexpr int SMALL_THREADS = 256;
+
+template <int NSPLIT, bool RELU, bool RES>
+__global__ __launch_bounds__(SMALL_THREADS) void dense_small_kernel(DenseParams p) {
+    __shared__ __attribute__((aligned(16))) float red[3][4][64];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16;
+    const int m0 = blockIdx.y * 16;
+    const int r = lane & 15, q = lane >> 4;
+    const size_t rowb = (size_t)p.K * 4;
+    const int nl = p.K / 32;
+
+    const char* wp = p.w + (size_t)(n0 + r) * rowb + q * 16;
+    const char* xp = p.x + (size_t)(m0 + r) * rowb + q * 16;
+
+    f32x4 acc;
+    if (w == 0) {
+        // bias * 2^e of weight rows n0 + 4q .. +3 (the D rows of this lane)
+        acc = *(const f32x4*)(p.bias_scaled + n0 + 4 * q);
+    } else {
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // Lines of this wave: l = w + 4*i.  They are fetched in groups of 4 (16 independent 16-byte loads in
+    // flight) into two register sets that alternate; every array index below is a compile-time constant
+    // (a run-time buffer index would turn the fragment arrays into select chains).
+    struct Frag {
+        half8 whi, wlo, xhi, xlo;
+    };
+    Frag fa[4], fb[4];
+    auto fetch4 = [&](Frag(&f)[4], int g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = w + 4 * (4 * g + j);
+            if (l < nl) {
+                const size_t o = (size_t)l * LINE;
+                f[j].whi = *(const half8*)(wp + o);
+                f[j].xhi = *(const half8*)(xp + o);
+                if (NSPLIT == 3) {
+                    f[j].wlo = *(const half8*)(wp + o + 64);
+                    f[j].xlo = *(const half8*)(xp + o + 64);
+                }
+            }
+        }
+    };
+    auto compute4 = [&](Frag(&f)[4], int g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = w + 4 * (4 * g + j);
+            if (l < nl) {
+                if (NSPLIT == 3) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[j].whi, f[j].xlo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[j].wlo, f[j].xhi, acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[j].whi, f[j].xhi, acc, 0, 0, 0);
+            }
+        }
+    };
+    const int nw = nl > w ? (nl - w + 3) / 4 : 0;  // lines of this wave
+    const int ng = (nw + 3) / 4;
+    if (ng > 0) fetch4(fa, 0);
+    for (int g = 0; g < ng; g += 2) {
+        if (g + 1 < ng) fetch4(fb, g + 1);
+        compute4(fa, g);
+        if (g + 2 < ng) fetch4(fa, g + 2);
+        if (g + 1 < ng) compute4(fb, g + 1);
+    }
+
+    if (w > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[w - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += red[ww][e][lane];
+
+    // lane holds person m0 + r, outputs n0 + 4q + e (e = 0..3): 4 consecutive fp16 of the hi half and of the
+    // lo half of line n0/32 of the output row
+    const size_t yoff = (size_t)(m0 + r) * ((size_t)p.N * 4) + (size_t)(n0 >> 5) * LINE + (size_t)((n0 & 16) + 4 * q) * 2;
+    half4 rh, rl;
+    if (RES) {
+        rh = *(const half4*)(p.res + yoff);
+        rl = *(const half4*)(p.res + yoff + 64);
+    }
+    half4 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = acc[e] * p.descale;
+        if (RELU) v = __builtin_fmaxf(v, 0.0f);
+        if (RES) v += (float)rh[e] + (float)rl[e];
+        _Float16 a, b;
+        split_f16(v, a, b);
+        oh[e] = a;
+        ol[e] = b;
+    }
+    *(half4*)(p.y + yoff) = oh;
+    *(half4*)(p.y + yoff + 64) = ol;
+}
+
+}  // namespace mlk

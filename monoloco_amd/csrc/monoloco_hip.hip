@@ -19,6 +19,7 @@
 
 #include "dense_kernel.h"
 #include "dense_kernel_pp.h"
+#include "dense_small.h"
 #include "geom_kernels.h"
 #include "geom_ops.h"
 #include "mc_kernels.h"
@@ -393,10 +394,43 @@ int trace_after_launch(unsigned long long* buf, size_t n, int grid, const mlk::D
     return ML_OK;
 }
 
-int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0) {
+int small_rows_env() {
+    // rows <= ML_SMALL_ROWS take dense_small_kernel (16x16 output tiles, no LDS staging) instead of the
+    // 256x256-tile persistent kernel; 0 disables the small path
+    const char* e = getenv("ML_SMALL_ROWS");  // read per call (cheap) so that tests can switch paths in-process
+    const int v = e ? atoi(e) : 1024;
+    return v < 0 ? 0 : v;
+}
+
+bool use_small_path(int64_t rows) { return dense_variant() != 1 && !dense_debug_bits() && rows <= small_rows_env(); }
+
+int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0, int64_t rows = -1) {
     mlk::DenseParams p = p_in;
     p.debug = dense_debug_bits();
     p.trace = nullptr;
+
+    if (rows >= 0 && use_small_path(rows) && head_nh == 0) {
+        const dim3 grid((unsigned)(p.N / 16), (unsigned)((rows + 15) / 16));
+        if (grid.y == 0) return ML_OK;
+#define ML_SM(NS, RL, RS) \
+    hipLaunchKernelGGL((mlk::dense_small_kernel<NS, RL, RS>), grid, dim3(mlk::SMALL_THREADS), 0, st, p)
+#define ML_SM_NS(NS)                                  \
+    do {                                              \
+        if (p.relu) {                                 \
+            if (p.res) ML_SM(NS, true, true);         \
+            else ML_SM(NS, true, false);              \
+        } else {                                      \
+            if (p.res) ML_SM(NS, false, true);        \
+            else ML_SM(NS, false, false);             \
+        }                                             \
+    } while (0)
+        if (precision == ML_PREC_F16X2) ML_SM_NS(3);
+        else ML_SM_NS(1);
+#undef ML_SM_NS
+#undef ML_SM
+        HIP_TRY(hipGetLastError());
+        return ML_OK;
+    }
 
     const int tiles = (p.M_pad / mlk::BM) * (p.N / mlk::BN);
     if (dense_variant() == 1) {
@@ -517,7 +551,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             const Head* fused = nullptr;
             for (const Head& hd : h->heads)
                 if (hd.after_layer == (int)li && (hd.nh == 8 || hd.nh == 9) && dense_variant() != 1 && L.relu && L.res < 0 &&
-                    !dense_debug_bits() && mc.p <= 0.f)
+                    !dense_debug_bits() && mc.p <= 0.f && !use_small_path(rows_here))
                     fused = &hd;
             if (fused) {
                 p.head_w = fused->d_w;
@@ -525,7 +559,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             }
             const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
             if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
-            int rc = launch_dense(h->precision, p, st, fused ? fused->nh : 0);
+            int rc = launch_dense(h->precision, p, st, fused ? fused->nh : 0, rows_here);
             if (rc) return rc;
             if (timed) {
                 HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));

@@ -196,3 +196,27 @@ def test_empty_and_errors(hip_lib, cuda_device):
     bad['w1.weight'] = np.zeros((250, 34), np.float32)
     with pytest.raises(_lib.MonolocoHipError):
         engine.LocoEngine(_sd_t(bad), device=cuda_device)
+
+
+@pytest.mark.parametrize("mode", ["mono", "stereo"])
+@pytest.mark.parametrize("m", [1, 16, 17, 100, 1000])
+def test_small_row_path_matches_tile_path(hip_lib, cuda_device, monkeypatch, m, mode):
+    """rows <= ML_SMALL_ROWS run dense_small_kernel (16x16 tiles, K split over 4 waves), larger batches the
+    256x256-tile persistent kernel: same operands and epilogue, only the fp32 accumulation order differs.
+    Both must agree with each other far below the parity bar and each must meet the bar against fp64."""
+    from monoloco_amd import engine
+    in_f, out_f = (34, 9) if mode == "mono" else (68, 10)
+    sd = synth.make_state_dict(4, in_features=in_f, out_features=out_f)
+    rng = np.random.default_rng(m)
+    x = torch.tensor((rng.standard_normal((m, in_f)) * 3).astype(np.float32), device=cuda_device)
+    eng = engine.LocoEngine(_sd_t(sd), device=cuda_device)
+    monkeypatch.setenv("ML_SMALL_ROWS", "0")
+    raw_tile = eng.forward_raw(x).cpu()
+    monkeypatch.setenv("ML_SMALL_ROWS", "1024")
+    raw_small = eng.forward_raw(x).cpu()
+    ref64 = O.loco_forward(_sd_t(sd), x.cpu(), dtype=torch.float64)
+    scale = ref64.abs().max().item()
+    assert (raw_small.double() - ref64).abs().max().item() <= 1e-4
+    assert (raw_tile.double() - ref64).abs().max().item() <= 1e-4
+    assert (raw_small - raw_tile).abs().max().item() <= 2e-6 * max(1.0, scale)
+    eng.close()
