@@ -81,7 +81,10 @@ int ml_device_count(void);
 /* ---- model lifetime: stands in for Loco.__init__ (monoloco/network/net.py:30-81) --- */
 /* Shape of LocoModel (monoloco/network/architectures.py:8-46): in_features 34 (mono) or
  * 68 (stereo), hidden a multiple of 256, out_features 9 or 10 (includes the auxiliary
- * head, architectures.py:70), num_stage residual stages. */
+ * head, architectures.py:70), num_stage residual stages.  The legacy MonolocoModel
+ * (architectures.py:105-176: the same stages followed by one Linear w2 -> out_features, 2 or 9; no w3 /
+ * w_aux / w_fin keys) is recognised at ml_loco_finalize from the tensors that were fed; it runs through
+ * ml_loco_forward_raw and ml_loco_epistemic_mono (the fused mono pipeline refuses it). */
 int ml_loco_create(int in_features, int hidden, int out_features, int num_stage, ml_loco** out);
 /* Feed one tensor of the reference state_dict by its key (e.g. "linear_stages.0.w1.weight",
  * "batch_norm3.running_var"; net.py:77 loads exactly these).  `data` is host fp32, row-major,

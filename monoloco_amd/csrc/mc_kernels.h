@@ -43,13 +43,13 @@ __global__ __launch_bounds__(256) void dropout_lines_kernel(char* __restrict__ a
 // one pass: per person accumulate sum and sum of squares of  mu + |b| * L_i,  i < n_samples, where L_i are
 // standard Laplace draws that depend on (seed, person, i) only -- identical for every pass, like the
 // reference's re-seeding.  Inverse CDF: L = -sign(u-1/2) * ln(1 - 2|u-1/2|).
-__global__ __launch_bounds__(256) void mc_accumulate_kernel(const float* __restrict__ raw, int out_f, int64_t m,
+__global__ __launch_bounds__(256) void mc_accumulate_kernel(const float* __restrict__ raw, int out_f, int col_d, int64_t m,
                                                            int n_samples, uint32_t seed, double* __restrict__ sum,
                                                            double* __restrict__ sumsq) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
-    const float mu = raw[i * out_f + 2];
-    const float b = fabsf(expf(raw[i * out_f + 3]) * mu);
+    const float mu = raw[i * out_f + col_d];
+    const float b = fabsf(expf(raw[i * out_f + col_d + 1]) * mu);
     double s = 0.0, s2 = 0.0;
     for (int k = 0; k < n_samples; ++k) {
         const float u = u01(seed, (uint32_t)i, (uint32_t)k) - 0.5f;

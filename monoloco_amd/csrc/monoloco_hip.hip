@@ -127,6 +127,7 @@ struct Head {
     int src = 0;   // activation buffer id
     int col0 = 0;  // first raw column
     int after_layer = 0;  // run after dense layer index
+    bool mc_site = false; // MC-dropout: the top-level dropout sits on this head's input (w_fin only)
     std::vector<float> w, b;
     float* d_w = nullptr;
     float* d_b = nullptr;
@@ -139,6 +140,7 @@ struct ml_loco {
     int precision = ML_PREC_F16X2, flags = 0;
     bool finalized = false;
     bool host_only = false;
+    bool legacy = false;  // MonolocoModel (w1, stages, w2 -> out_f) instead of LocoModel
     int device = -1;
     std::map<std::string, std::vector<float>> tensors;
     std::vector<DenseLayer> layers;
@@ -578,7 +580,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                 // after relu(bn3) = the input of the w_fin head
                 bool site = (li == 0);
                 for (const Head& hd : h->heads)
-                    if (hd.after_layer == (int)li && hd.nh > 1) site = true;
+                    if (hd.after_layer == (int)li && hd.mc_site) site = true;
                 if (site) {
                     const int64_t groups = m_pad * (L.n / 8);
                     hipLaunchKernelGGL(mlk::dropout_lines_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
@@ -674,6 +676,23 @@ int ml_loco_finalize(ml_loco* h, int precision, int flags) {
         if ((rc = fold(h, p + "w2", p + "batch_norm2", H, H, W, B))) return rc;
         add_dense(h, W, B, H, H, 1, 2, 1, 1);
     }
+    h->legacy = h->tensors.count("w_fin.weight") == 0 && h->tensors.count("w3.weight") == 0;
+    if (h->legacy) {
+        // MonolocoModel (architectures.py:105-145): the stages are followed by one Linear w2: hidden -> out_f,
+        // a GEMV-shaped head on a3 (buffer A)
+        const auto* w2 = get_t(h, "w2.weight", (int64_t)h->out_f * H);
+        const auto* b2 = get_t(h, "w2.bias", h->out_f);
+        if (!w2 || !b2) return ML_ERR_STATE;
+        if (h->out_f != 2 && h->out_f != 9) return fail(ML_ERR_SHAPE, "legacy MonolocoModel: output size %d unsupported (2 or 9)", h->out_f);
+        Head out;
+        out.nh = h->out_f;
+        out.col0 = 0;
+        out.src = 1;
+        out.after_layer = (int)h->layers.size() - 1;
+        out.w.assign(w2->begin(), w2->end());
+        out.b.assign(b2->begin(), b2->end());
+        h->heads.push_back(std::move(out));
+    } else {
     std::vector<double> W2, B2, W3, B3, WA, BA;
     if ((rc = fold(h, "w2", "", H, H, W2, B2))) return rc;
     if ((rc = fold(h, "w3", "batch_norm3", H, H, W3, B3))) return rc;
@@ -720,8 +739,10 @@ int ml_loco_finalize(ml_loco* h, int precision, int flags) {
         fin.src = 1;
         fin.after_layer = (int)h->layers.size() - 1;
     }
+    fin.mc_site = true;  // net.py:141 re-enables the top-level dropout, which sits in front of w_fin
     h->heads.push_back(std::move(aux));
     h->heads.push_back(std::move(fin));
+    }
     h->k0pad = h->layers[0].kpad;
     for (auto& L : h->layers) pack_layer(h->precision, L);
     h->tensors.clear();
@@ -921,7 +942,9 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
     int rc = check_ready(h);
     if (rc) return rc;
     if (h->in_f != mlk::NIN) return fail(ML_ERR_SHAPE, "mono pipeline needs a 34-input model, this one has %d", h->in_f);
-    if (h->out_f != 9 && h->out_f != 10) return fail(ML_ERR_SHAPE, "mono pipeline needs 9 or 10 outputs");
+    if (h->legacy || (h->out_f != 9 && h->out_f != 10))
+        return fail(ML_ERR_SHAPE, "the fused mono pipeline needs a LocoModel with 9 or 10 outputs (legacy MonolocoModel: "
+                                  "ml_preprocess_mono + ml_loco_forward_raw)");
     if (m == 0) return ML_OK;
     if (m < 0 || !kinv_host || !out_dev || !kps_dev) return fail(ML_ERR_ARG, "bad argument");
     if ((rc = ensure_rows(h, m))) return rc;
@@ -996,8 +1019,9 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
     const unsigned grid_m = (unsigned)((m + 255) / 256);
     for (int pass = 0; pass < n_dropout && !rc; ++pass) {
         // the stochastic forward consumes the input lines afresh every pass (buffer A is overwritten)
+        // legacy 'monoloco' (2 outputs = d, s) is fed zero-centred inputs (net.py:96)
         hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(m_pad / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
-                           (float*)nullptr, (float*)nullptr, h->buf[0], h->k0pad, m_pad, 0);
+                           (float*)nullptr, (float*)nullptr, h->buf[0], h->k0pad, m_pad, (h->legacy && h->out_f == 2) ? 1 : 0);
         McPass mc;
         mc.p = p_dropout;
         mc.seed = seed * 7919u + (uint32_t)pass + 1u;
@@ -1006,8 +1030,8 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
         if (raw_passes_dev)
             HIP_TRY(hipMemcpyAsync(raw_passes_dev + (size_t)pass * m * h->out_f, h->d_raw, (size_t)m * h->out_f * 4,
                                    hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(mlk::mc_accumulate_kernel, dim3(grid_m), dim3(256), 0, st, (const float*)h->d_raw, h->out_f, m,
-                           n_samples, seed, acc, acc + m);
+        hipLaunchKernelGGL(mlk::mc_accumulate_kernel, dim3(grid_m), dim3(256), 0, st, (const float*)h->d_raw, h->out_f,
+                           (h->legacy && h->out_f == 2) ? 0 : 2, m, n_samples, seed, acc, acc + m);  // net.py:148-151
     }
     if (!rc) {
         hipLaunchKernelGGL(mlk::mc_finish_kernel, dim3(grid_m), dim3(256), 0, st, (const double*)acc, (const double*)(acc + m),

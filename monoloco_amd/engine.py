@@ -135,7 +135,9 @@ class LocoEngine:
         sd = {k: v for k, v in state_dict.items()}
         w1 = sd['w1.weight']
         self.hidden, self.in_features = int(w1.shape[0]), int(w1.shape[1])
-        self.out_features = int(sd['w_fin.weight'].shape[0]) + 1
+        # LocoModel: w_fin (out-1 rows) + w_aux; legacy MonolocoModel (architectures.py:105-145): w2 maps to the outputs
+        self.legacy = 'w_fin.weight' not in sd and 'w3.weight' not in sd
+        self.out_features = int(sd['w2.weight'].shape[0]) if self.legacy else int(sd['w_fin.weight'].shape[0]) + 1
         self.num_stage = len({k.split('.')[1] for k in sd if k.startswith('linear_stages.')})
         handle = ctypes.c_void_p()
         check(lib.ml_loco_create(self.in_features, self.hidden, self.out_features, self.num_stage,

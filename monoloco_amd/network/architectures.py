@@ -5,7 +5,7 @@ The modules own ordinary ``nn.Linear`` / ``nn.BatchNorm1d`` parameters under the
 (``w1``, ``batch_norm1``, ``linear_stages.{i}.w1`` ...), so reference checkpoints load with
 ``load_state_dict`` unchanged.  ``forward`` in eval mode packs the current parameters once
 (BN folded, fp16 hi|lo split, uploaded) and calls the MFMA kernels; there is no torch compute path.
-Training-mode forward (batch-stat BN, dropout, backward) is the "next" row of SURVEY.md 8f.
+The training step (batch-stat BN, dropout, backward, Adam) lives in ``monoloco_amd.train`` (ml_trainer_*).
 """
 import torch
 from torch import nn
@@ -27,7 +27,40 @@ class _Stage(nn.Module):
         self.dropout = nn.Dropout(p_dropout)
 
 
-class LocoModel(nn.Module):
+class _HipForward(nn.Module):
+    """Eval-mode forward on the HIP engine, shared by LocoModel and the legacy MonolocoModel."""
+    precision = 'f16x2'
+    merge_w2w3 = True
+    _engine = None
+    _engine_key = None
+
+    # -- engine management: re-pack when parameters were replaced or modified in place
+    def _params_key(self, dev):
+        return (str(dev), self.precision, self.merge_w2w3) + tuple(
+            (t.data_ptr(), t._version) for t in self.state_dict().values())
+
+    def hip_engine(self, device=None):
+        dev = engine._require_cuda(device)
+        key = self._params_key(dev)
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = engine.LocoEngine(self.state_dict(), device=dev, precision=self.precision,
+                                             merge_w2w3=self.merge_w2w3)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, x):
+        if self.training or self.dropout.training:
+            raise NotImplementedError(
+                "the module forward is the eval-mode network (running-stat BatchNorm, no dropout); training runs "
+                "through monoloco_amd.train.Trainer / HipTrainer and MC-dropout through Loco(n_dropout=...)")
+        home = x.device
+        eng = self.hip_engine(home if home.type == 'cuda' else None)
+        return eng.forward_raw(x.detach()).to(home)
+
+
+class LocoModel(_HipForward):
     """MonoLoco++ (input 34) / MonStereo (input 68) residual MLP (reference architectures.py:6-71).
 
     ``output_size`` counts the auxiliary head as in the reference: w_fin has output_size-1 rows and
@@ -55,39 +88,12 @@ class LocoModel(nn.Module):
         self.w_fin = nn.Linear(linear_size, self.output_size)
         self.relu = nn.ReLU(inplace=True)
         self.dropout = nn.Dropout(p_dropout)
-        self._engine = None
-        self._engine_key = None
-
-    # -- engine management: re-pack when parameters were replaced or modified in place
-    def _params_key(self, dev):
-        return (str(dev), self.precision, self.merge_w2w3) + tuple(
-            (t.data_ptr(), t._version) for t in self.state_dict().values())
-
-    def hip_engine(self, device=None):
-        dev = engine._require_cuda(device)
-        key = self._params_key(dev)
-        if self._engine is None or self._engine_key != key:
-            if self._engine is not None:
-                self._engine.close()
-            self._engine = engine.LocoEngine(self.state_dict(), device=dev, precision=self.precision,
-                                             merge_w2w3=self.merge_w2w3)
-            self._engine_key = key
-        return self._engine
-
-    def forward(self, x):
-        if self.training or self.dropout.training:
-            raise NotImplementedError(
-                "monoloco_amd implements the eval-mode forward (running-stat BatchNorm, no dropout); the training "
-                "step and MC-dropout are the next rows of the hot-path scope (SURVEY.md 8f)")
-        home = x.device
-        eng = self.hip_engine(home if home.type == 'cuda' else None)
-        return eng.forward_raw(x.detach()).to(home)
 
 
-class MonolocoModel(nn.Module):
-    """Legacy MonoLoco (hidden 256, 2 outputs; reference architectures.py:105-145).  Kept as a
-    checkpoint-compatible container only: the reference's own ``Loco`` cannot reach it (passing
-    ``net=`` raises before assignment, reference net.py:41), so no kernel is built for it."""
+class MonolocoModel(_HipForward):
+    """Legacy MonoLoco (hidden 256, 2 outputs: d and log(b/d); reference architectures.py:105-176): the same
+    w1/bn/relu + residual stages as LocoModel, followed by one Linear ``w2`` to the outputs.  Runs on the same
+    dense kernels; ``w2`` is a GEMV-shaped head."""
 
     def __init__(self, input_size, output_size=2, linear_size=256, p_dropout=0.2, num_stage=3):
         super().__init__()
@@ -102,7 +108,3 @@ class MonolocoModel(nn.Module):
         self.w2 = nn.Linear(linear_size, output_size)
         self.relu = nn.ReLU(inplace=True)
         self.dropout = nn.Dropout(p_dropout)
-
-    def forward(self, x):
-        raise NotImplementedError("legacy MonolocoModel has no HIP kernel (unreachable through Loco in the "
-                                  "reference as well); use LocoModel (monoloco_pp / monstereo)")

@@ -15,7 +15,7 @@ import torch
 from .. import engine
 from ..utils import get_iou_matches, get_keypoints, pixel_to_camera, reorder_matches, xyz_from_distance
 from .architectures import LocoModel, MonolocoModel
-from .process import packed_to_dict
+from .process import packed_to_dict, unnormalize_bi
 
 
 class Loco:
@@ -30,21 +30,29 @@ class Loco:
         if net is None:
             self.net = 'monoloco_pp' if mode == 'mono' else 'monstereo'
         else:
-            # The reference reads self.net before assigning it here (net.py:41) and raises
-            # AttributeError; only the default nets are reachable there.  Be explicit instead.
+            # The reference reads self.net before assigning it here (net.py:41) and raises AttributeError, so
+            # net= is unusable there; the evident intent (net.py:47-60, 95-104) is implemented instead.
             assert net in ('monstereo', 'monoloco', 'monoloco_p', 'monoloco_pp')
-            if net in ('monoloco', 'monoloco_p'):
-                raise NotImplementedError("legacy nets 'monoloco'/'monoloco_p' are not reachable through the "
-                                          "reference's Loco either; use monoloco_pp or monstereo")
+            if net == 'monoloco_p':
+                raise NotImplementedError("net='monoloco_p' (extract_outputs_mono) is not built; use monoloco_pp")
             assert (net == 'monstereo') == (mode == 'stereo'), "Assert arguments mode and net are in conflict"
             self.net = net
-        input_size, output_size = (68, 10) if self.net == 'monstereo' else (34, 9)
+        if self.net == 'monstereo':
+            input_size, output_size = 68, 10
+        elif self.net == 'monoloco_pp':
+            input_size, output_size = 34, 9
+        else:  # legacy MonoLoco: 34 -> 256 -> (d, log(b/d)), net.py:58-60 and LINEAR_SIZE_MONO
+            input_size, output_size = 34, 2
         self.device = engine._require_cuda(device)
         self.n_dropout = n_dropout
         self.epistemic = bool(self.n_dropout > 0)
         if isinstance(model, str):
-            self.model = LocoModel(p_dropout=p_dropout, input_size=input_size, output_size=output_size,
-                                   linear_size=linear_size, device=self.device)
+            if self.net == 'monoloco':
+                self.model = MonolocoModel(p_dropout=p_dropout, input_size=input_size, linear_size=linear_size,
+                                           output_size=output_size)
+            else:
+                self.model = LocoModel(p_dropout=p_dropout, input_size=input_size, output_size=output_size,
+                                       linear_size=linear_size, device=self.device)
             self.model.load_state_dict(torch.load(model, map_location=lambda storage, loc: storage))
         else:
             self.model = model
@@ -63,7 +71,14 @@ class Loco:
         dev = self.device
         kps = engine._dev_f32(keypoints, dev)
         kinv = engine.inverse_intrinsics(kk.tolist() if isinstance(kk, torch.Tensor) else kk)
-        if self.net == 'monoloco_pp':
+        if self.net == 'monoloco':
+            # legacy MonoLoco (net.py:95-100): zero-centred inputs, outputs (d, log(b/d))
+            x = engine.preprocess_mono(kps, kk.tolist() if isinstance(kk, torch.Tensor) else kk, device=dev,
+                                       zero_center=True)
+            raw = self.engine.forward_raw(x)
+            dic_out = {'d': raw[:, 0:1].cpu(), 'bi': unnormalize_bi(raw).cpu()}
+            n_out = kps.shape[0]
+        elif self.net == 'monoloco_pp':
             out, _, _ = self.engine.forward_mono(kps, kinv)
             dic_out = packed_to_dict(out, 9)
             n_out = kps.shape[0]

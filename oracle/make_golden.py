@@ -365,3 +365,41 @@ def golden_formats():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'formats':
     golden_formats()
+
+
+def golden_legacy():
+    """The legacy MonolocoModel (architectures.py:105-176; 34 -> 256 -> 2) through the reference's own classes, on
+    the pifpaf fixture with zero-centred inputs exactly as Loco.forward's 'monoloco' branch (net.py:95-100) does."""
+    from monoloco.network.architectures import MonolocoModel
+    from monoloco.network.process import unnormalize_bi
+    torch.manual_seed(7)
+    model = MonolocoModel(input_size=34, output_size=2, linear_size=256, p_dropout=0.2)
+    with torch.no_grad():
+        for name, mod in model.named_modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):  # non-trivial running statistics and affine parameters
+                mod.running_mean.copy_(torch.randn_like(mod.running_mean) * 0.3)
+                mod.running_var.copy_(torch.rand_like(mod.running_var) + 0.5)
+                mod.weight.copy_(torch.rand_like(mod.weight) + 0.5)
+                mod.bias.copy_(torch.randn_like(mod.bias) * 0.2)
+        model.w2.bias.copy_(torch.tensor([12.0, -1.5]))  # d around 12 m, b/d around e^-1.5
+    model.eval()
+    anns = json.load(open(os.path.join(REF, 'tests', '002282.png.pifpaf.json')))
+    im_size = (1238, 374)
+    boxes, keypoints = preprocess_pifpaf(copy.deepcopy(anns), im_size, enlarge_boxes=False)
+    kk = load_calibration('kitti', im_size)
+    out = {}
+    with torch.no_grad():
+        kps = torch.tensor(keypoints)
+        x = preprocess_monoloco(kps, torch.tensor(kk), zero_center=True)
+        raw = model(x)
+        out.update(kps=kps.numpy(), kk=np.array(kk, dtype=np.float64), x=x.numpy(), raw=raw.numpy(),
+                   d=raw[:, 0:1].numpy(), bi=unnormalize_bi(raw).numpy(),
+                   raw64=model.double()(x.double()).numpy())
+    for k, v in np_sd(model.float().state_dict()).items():
+        out['sd.' + k] = v
+    np.savez_compressed(os.path.join(OUT, 'golden_legacy.npz'), **out)
+    print('wrote golden_legacy.npz: raw range', raw.min().item(), raw.max().item())
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'legacy':
+    golden_legacy()

@@ -289,3 +289,36 @@ def test_mc_dropout_epistemic(hip_lib, cuda_device, gold):
     assert abs(r0.mean().item() - 2 ** 0.5) < 0.06 and r0.min() > 0.8 and r0.max() < 2.4
     assert torch.equal(e0, eng.epistemic_mono(kps, kinv, 3, p_dropout=1e-7).cpu())  # counter-based RNG
     eng.close()
+
+
+def test_legacy_monoloco_model_vs_reference(hip_lib, cuda_device):
+    """Legacy MonolocoModel (architectures.py:105-176) on the HIP engine: module forward, and Loco(net='monoloco')
+    (zero-centred inputs, d / bi dictionary, net.py:95-100) against the reference's own classes."""
+    from monoloco_amd.network import Loco
+    from monoloco_amd.network.architectures import MonolocoModel
+    g = dict(np.load(os.path.join(G, 'golden_legacy.npz')))
+    model = MonolocoModel(input_size=34, output_size=2, linear_size=256)
+    model.load_state_dict({k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith('sd.')})
+    model.eval()
+    raw = model(torch.tensor(g['x']).to(cuda_device)).cpu().numpy()
+    noise = np.abs(g['raw'] - g['raw64']).max()
+    print("legacy MonolocoModel: raw vs ref fp32 %.2e, vs ref fp64 %.2e (ref noise %.2e)"
+          % (np.abs(raw - g['raw']).max(), np.abs(raw - g['raw64']).max(), noise))
+    assert np.abs(raw - g['raw']).max() <= TOL
+    assert np.abs(raw - g['raw64']).max() <= max(3 * noise, 2e-5)
+    net = Loco(model=model, mode='mono', net='monoloco', device=cuda_device)
+    dic = net.forward(g['kps'].tolist(), g['kk'].tolist())
+    assert set(dic) == {'d', 'bi', 'epi'} and dic['epi'] == [0.] * len(g['kps'])
+    assert dic['d'].shape == g['d'].shape and not dic['d'].is_cuda
+    assert np.abs(dic['d'].numpy() - g['d']).max() <= TOL
+    assert np.abs(dic['bi'].numpy() - g['bi']).max() <= TOL
+    # the fused pp pipeline must refuse a legacy model loudly
+    from monoloco_amd import _lib, engine
+    with pytest.raises(_lib.MonolocoHipError):
+        net.engine.forward_mono(torch.tensor(g['kps']), engine.inverse_intrinsics(g['kk'].tolist()))
+    # MC-dropout on the legacy net: columns (d, s) = 0:2, dropout only after the first layer
+    net_mc = Loco(model=model, mode='mono', net='monoloco', device=cuda_device, n_dropout=30)
+    epi = net_mc.forward(g['kps'].tolist(), g['kk'].tolist())['epi']
+    assert epi.shape == (len(g['kps']),) and torch.isfinite(epi).all()
+    lap = np.sqrt(2.0) * np.abs(g['bi'][:, 0])           # std of Laplace(d, bi) without any dropout spread
+    assert (epi.numpy() > 0.5 * lap).all() and (epi.numpy() < 5.0 * lap + 5.0).all()

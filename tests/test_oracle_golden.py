@@ -124,3 +124,17 @@ def test_oracle_z_nan_semantics():
     raw2[0, 2] = -5.0  # negative d: x^2+y^2 <= d^2 still holds, z = sqrt(...) finite; bi negative
     assert torch.isfinite(ext['xyzd']).all()
     assert O.extract_outputs(raw2)['bi'][0, 0] < 0
+
+
+def test_legacy_monoloco_model_oracle_vs_reference():
+    """Legacy MonolocoModel (34 -> 256 -> 2) and the 'monoloco' branch of Loco.forward (net.py:95-100) against the
+    reference's own classes on the pifpaf fixture (oracle/make_golden.py legacy)."""
+    g = dict(np.load(os.path.join(G, 'golden_legacy.npz')))
+    sd = {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith('sd.')}
+    res = O.forward_legacy_monoloco(sd, torch.tensor(g['kps']), g['kk'].tolist())
+    assert torch.equal(res['x'], torch.tensor(g['x']))          # zero-centred inputs: bit exact
+    assert (res['raw'] - torch.tensor(g['raw'])).abs().max().item() <= 5e-6
+    assert (res['d'] - torch.tensor(g['d'])).abs().max().item() <= 5e-6
+    assert (res['bi'] - torch.tensor(g['bi'])).abs().max().item() <= 5e-6
+    raw64 = O.monoloco_forward(sd, torch.tensor(g['x']), dtype=torch.float64)
+    assert (raw64 - torch.tensor(g['raw64'])).abs().max().item() <= 1e-12
