@@ -89,54 +89,56 @@ float* P(ml_trainer* t, const std::string& k) { return t->w + t->slots[k].off; }
 float* G(ml_trainer* t, const std::string& k) { return t->g + t->slots[k].off; }
 float* ST(ml_trainer* t, const std::string& k) { return t->stat + t->slots[k].off; }
 
-int gemm(hipStream_t st, const float* a, long sai, long sak, const float* b, long sbk, long sbj, const float* bias, float* c,
-         int ldc, int M, int N, int K, int accumulate) {
+// c (M x N, row stride ldc) (+)= a (M x K) . b (K x N) + bias on the exact-fp32 MFMA GEMM.  When the output has too
+// few 128x128 tiles to fill the chip (a weight gradient: small output, K = batch; or any layer of a small batch) the
+// reduction is split over blockIdx.z into a partial buffer and the partials are added in a fixed order
+// (deterministic, unlike atomics).
+int gemm(ml_trainer* t, hipStream_t st, const float* a, long sai, long sak, const float* b, long sbk, long sbj, const float* bias,
+         float* c, int ldc, int M, int N, int K, int accumulate) {
+    const int tiles = ((N + mlt::GBN - 1) / mlt::GBN) * ((M + mlt::GBM - 1) / mlt::GBM);
+    int splits = 1;
+    while (splits < 32 && tiles * splits < 512 && K / (splits * 2) >= 128) splits *= 2;
+    if ((size_t)splits * M * ldc > t->splitk_cap) splits = 1;
+    int kchunk = K;
+    if (splits > 1) {
+        kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
+        splits = (K + kchunk - 1) / kchunk;  // the rounding may leave fewer, all non-empty, chunks
+    }
     mlt::GemmParams p;
     p.a = a; p.b = b; p.bias = bias; p.c = c;
     p.M = M; p.N = N; p.K = K;
     p.sai = sai; p.sak = sak; p.sbk = sbk; p.sbj = sbj;
     p.ldc = ldc; p.accumulate = accumulate;
     p.kchunk = K;
-    dim3 grid((N + mlt::GBN - 1) / mlt::GBN, (M + mlt::GBM - 1) / mlt::GBM);
+    if (splits > 1) {
+        p.c = t->d_splitk;
+        p.bias = nullptr;
+        p.accumulate = 0;
+        p.kchunk = kchunk;
+    }
+    dim3 grid((N + mlt::GBN - 1) / mlt::GBN, (M + mlt::GBM - 1) / mlt::GBM, splits);
     hipLaunchKernelGGL(mlt::sgemm_kernel, grid, dim3(256), 0, st, p);
+    if (splits > 1) {
+        const int64_t n = (int64_t)M * N;
+        hipLaunchKernelGGL(mlt::splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           (const float*)t->d_splitk, splits, M, N, ldc, bias, accumulate, c);
+    }
     if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "sgemm launch failed");
     return 0;
 }
 
-// weight-gradient shape: a long reduction (K = batch) into a small output.  Split the reduction over blockIdx.z
-// into a partial buffer and add the partials in a fixed order (deterministic, unlike atomics).
-int gemm_splitk(ml_trainer* t, hipStream_t st, const float* a, long sai, long sak, const float* b, long sbk, long sbj, float* c,
-                int ldc, int M, int N, int K) {
-    int tiles = ((N + mlt::GBN - 1) / mlt::GBN) * ((M + mlt::GBM - 1) / mlt::GBM);
-    int splits = 1;
-    while (splits < 32 && tiles * splits < 512 && K / (splits * 2) >= 2048) splits *= 2;
-    if (splits == 1 || (size_t)splits * M * ldc > t->splitk_cap) return gemm(st, a, sai, sak, b, sbk, sbj, nullptr, c, ldc, M, N, K, 0);
-    mlt::GemmParams p;
-    p.a = a; p.b = b; p.bias = nullptr; p.c = t->d_splitk;
-    p.M = M; p.N = N; p.K = K;
-    p.sai = sai; p.sak = sak; p.sbk = sbk; p.sbj = sbj;
-    p.ldc = ldc; p.accumulate = 0;
-    p.kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
-    dim3 grid((N + mlt::GBN - 1) / mlt::GBN, (M + mlt::GBM - 1) / mlt::GBM, splits);
-    hipLaunchKernelGGL(mlt::sgemm_kernel, grid, dim3(256), 0, st, p);
-    const int64_t n = (int64_t)M * ldc;
-    hipLaunchKernelGGL(mlt::splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)t->d_splitk,
-                       splits, n, c);
-    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "split-K sgemm launch failed");
-    return 0;
-}
 // y (m x n) = x (m x k) . W^T + b           (nn.Linear forward)
-int linear_fwd(hipStream_t st, const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int m, int n, int k) {
-    return gemm(st, x, ldx, 1, W, 1, k, b, y, ldy, m, n, k, 0);
+int linear_fwd(ml_trainer* t, hipStream_t st, const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int m, int n, int k) {
+    return gemm(t, st, x, ldx, 1, W, 1, k, b, y, ldy, m, n, k, 0);
 }
 // dx (m x k) (+)= dy (m x n) . W
-int linear_bwd_data(hipStream_t st, const float* dy, int lddy, const float* W, float* dx, int lddx, int m, int n, int k, int acc) {
-    return gemm(st, dy, lddy, 1, W, k, 1, nullptr, dx, lddx, m, k, n, acc);
+int linear_bwd_data(ml_trainer* t, hipStream_t st, const float* dy, int lddy, const float* W, float* dx, int lddx, int m, int n, int k, int acc) {
+    return gemm(t, st, dy, lddy, 1, W, k, 1, nullptr, dx, lddx, m, k, n, acc);
 }
 // dW (n x k) = dy^T (n x m) . x (m x k)
 int linear_bwd_weight(ml_trainer* t, hipStream_t st, const float* dy, int lddy, const float* x, int ldx, float* dW, int m, int n,
                       int k) {
-    return gemm_splitk(t, st, dy, 1, lddy, x, ldx, 1, dW, k, n, k, m);
+    return gemm(t, st, dy, 1, lddy, x, ldx, 1, nullptr, dW, k, n, k, m, 0);
 }
 
 unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
@@ -163,7 +165,7 @@ struct Block {  // Linear + BatchNorm + ReLU + Dropout
 
 int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* residual) {
     const int H = t->H;
-    int rc = linear_fwd(st, b.x, b.in_dim, P(t, b.lin + ".weight"), P(t, b.lin + ".bias"), b.z, H, (int)m, H, b.in_dim);
+    int rc = linear_fwd(t, st, b.x, b.in_dim, P(t, b.lin + ".weight"), P(t, b.lin + ".bias"), b.z, H, (int)m, H, b.in_dim);
     if (rc) return rc;
     if ((rc = col_stats(t, st, b.z, nullptr, m, H))) return rc;
     float* mean = t->bn_mean + (size_t)b.bn_idx * H;
@@ -340,12 +342,12 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         sb[s].x = tt[s]; sb[s].z = zb[s]; sb[s].y = a[s + 1]; sb[s].site = 2 + 2 * s;
         if ((rc = block_fwd(t, st, sb[s], m, a[s]))) return rc;  // a_{s+1} = a_s + block(t_s)
     }
-    if ((rc = linear_fwd(st, a[S], H, P(t, "w2.weight"), P(t, "w2.bias"), y2, H, (int)m, H, H))) return rc;
-    if ((rc = linear_fwd(st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
+    if ((rc = linear_fwd(t, st, a[S], H, P(t, "w2.weight"), P(t, "w2.bias"), y2, H, (int)m, H, H))) return rc;
+    if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
     Block b3;
     b3.lin = "w3"; b3.bn = "batch_norm3"; b3.bn_idx = 2 * S + 1; b3.in_dim = H; b3.x = y2; b3.z = z3; b3.y = y3; b3.site = 2 * S + 1;
     if ((rc = block_fwd(t, st, b3, m, nullptr))) return rc;
-    if ((rc = linear_fwd(st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
+    if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
     if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
     // ---------------- loss and its gradient
     double* d_loss = t->d_red + 2 * H;
@@ -363,25 +365,25 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)(t->d_red + (C - 1)), 1,
                        G(t, "w_aux.bias"));
     if ((rc = linear_bwd_weight(t, st, t->d_dout, C, y3, H, G(t, "w_fin.weight"), (int)m, C - 1, H))) return rc;
-    if ((rc = linear_bwd_data(st, t->d_dout, C, P(t, "w_fin.weight"), gA, H, (int)m, C - 1, H, 0))) return rc;  // dy3
+    if ((rc = linear_bwd_data(t, st, t->d_dout, C, P(t, "w_fin.weight"), gA, H, (int)m, C - 1, H, 0))) return rc;  // dy3
     if ((rc = block_bwd(t, st, b3, m, gA, xhat))) return rc;                                                     // gA = dz3
-    if ((rc = linear_bwd_data(st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0))) return rc;                 // gB = dy2
+    if ((rc = linear_bwd_data(t, st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0))) return rc;                 // gB = dy2
     if ((rc = linear_bwd_weight(t, st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H))) return rc;
-    if ((rc = linear_bwd_data(st, t->d_dout + (C - 1), C, P(t, "w_aux.weight"), gB, H, (int)m, 1, H, 1))) return rc;  // += daux (x) w_aux
+    if ((rc = linear_bwd_data(t, st, t->d_dout + (C - 1), C, P(t, "w_aux.weight"), gB, H, (int)m, 1, H, 1))) return rc;  // += daux (x) w_aux
     // y2 = w2 a_S + b2
     if ((rc = col_stats(t, st, gB, nullptr, m, H))) return rc;
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red, H, G(t, "w2.bias"));
     if ((rc = linear_bwd_weight(t, st, gB, H, a[S], H, G(t, "w2.weight"), (int)m, H, H))) return rc;
-    if ((rc = linear_bwd_data(st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0))) return rc;                 // gA = da_S
+    if ((rc = linear_bwd_data(t, st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0))) return rc;                 // gA = da_S
     // residual stages, last to first:  a_{s+1} = a_s + B(A(a_s))
     for (int s = S - 1; s >= 0; --s) {
         T_TRY(hipMemcpyAsync(gB, gA, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));                          // gB = d r_s
         if ((rc = block_bwd(t, st, sb[s], m, gB, xhat))) return rc;                                              // gB = dz_b
         float* gT = xhat;  // xhat is free again: reuse it for d t_s
-        if ((rc = linear_bwd_data(st, gB, H, P(t, sb[s].lin + ".weight"), gT, H, (int)m, H, H, 0))) return rc;
+        if ((rc = linear_bwd_data(t, st, gB, H, P(t, sb[s].lin + ".weight"), gT, H, (int)m, H, H, 0))) return rc;
         T_TRY(hipMemcpyAsync(gB, gT, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));                          // gB = d t_s
         if ((rc = block_bwd(t, st, sa[s], m, gB, xhat))) return rc;                                              // gB = dz_a
-        if ((rc = linear_bwd_data(st, gB, H, P(t, sa[s].lin + ".weight"), gA, H, (int)m, H, H, 1))) return rc;   // da_s += ...
+        if ((rc = linear_bwd_data(t, st, gB, H, P(t, sa[s].lin + ".weight"), gA, H, (int)m, H, H, 1))) return rc;   // da_s += ...
     }
     if ((rc = block_bwd(t, st, b0, m, gA, xhat))) return rc;
     // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)

@@ -153,14 +153,21 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
         }
 }
 
-// deterministic split-K combine: c[i] = sum_z part[z][i]  (n = M*ldc elements)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t n,
+// deterministic split-K combine: c[i][j] = (accumulate ? c[i][j] : 0) + bias[j] + sum_z part[z][i][j] for j < N
+// (partials and c share the row stride ldc; columns >= N of c are not touched)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int M, int N, int ldc,
+                                                           const float* __restrict__ bias, int accumulate,
                                                            float* __restrict__ c) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)M * N) return;
+    const int64_t i = id / N;
+    const int j = (int)(id - i * N);
+    const int64_t o = i * ldc + j, plane = (int64_t)M * ldc;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[(int64_t)z * n + i];
-    c[i] = s;
+    for (int z = 0; z < splits; ++z) s += part[(int64_t)z * plane + o];
+    if (bias) s += bias[j];
+    if (accumulate) s += c[o];
+    c[o] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
