@@ -13,9 +13,9 @@
 //    fire-and-forget, so the 256 KiB a tile writes drain while the next tile computes, and the next
 //    tile's first stage is requested BEFORE the epilogue runs.
 //  * ping-pong: the 8 waves form two groups (waves 0-3 / 4-7 = the two waves of each SIMD).  A wave
-//    alternates an L phase (12 ds_read_b128 of one k16 half-step + exactly 4 LDS-DMA instructions)
-//    and a C phase (its 24 MFMAs); group 1 runs one phase behind group 0, so on every SIMD one wave
-//    computes while the other reads LDS and feeds the DMA engine.  Phases are separated by raw
+//    alternates an L phase (12 ds_read_b128 of one k16 half-step + 2 LDS-DMA instructions) and a C phase
+//    (its 24 MFMAs, with the other 2 DMA instructions of its share issued between them); group 1 runs one
+//    phase behind group 0, so on every SIMD one wave computes while the other reads LDS.  Phases are separated by raw
 //    s_barrier; all vmcnt waits are counted ones placed by hand (vmcnt retires in order).
 //  * epilogue per 32x32 MFMA tile through a private 4 KiB LDS scratch per wave (the 32 KiB the two
 //    stage buffers leave free).  No ordinary vector load: bias comes through the scalar path
@@ -26,6 +26,16 @@
 //    writes HEAD partial sums per person; head_reduce_kernel adds the 2*N/256 slices and the bias.
 #pragma once
 #include "dense_kernel.h"
+
+// Where the LDS-DMA instructions of a k-step are issued (profiles/r01_ablation.md, "schedule B"):
+//   ML_SCHED_B 0: all 4 per operand share in the L phases;  1: 3 in L + 1 between the MFMAs of the next C phase;
+//   2 (default): 2 + 2.   ML_HOOK_STYLE: position of the C-phase ones (1 = one per MFMA row block, default).
+#ifndef ML_SCHED_B
+#define ML_SCHED_B 2
+#endif
+#ifndef ML_HOOK_STYLE
+#define ML_HOOK_STYLE 1
+#endif
 
 namespace mlk {
 
@@ -71,15 +81,18 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
     const unsigned goff_e = (unsigned)((lane >> 3) * (int)rowb + (((lane & 7) ^ (lane >> 4)) * 16));
     const unsigned goff_o = (unsigned)((lane >> 3) * (int)rowb + (((lane & 7) ^ (4 + (lane >> 4))) * 16));
     const unsigned row8 = (unsigned)(8 * (int)rowb);
-    auto issue4 = [&](const char* tile, int base, int lds_off, int kt) {
+    // quarters [qa, qb) of a wave's 4-instruction share of one operand of stage kt
+    auto issue_q = [&](const char* tile, int base, int lds_off, int kt, int qa, int qb) {
         char* sb = smem + (kt & 1) * STAGE_BYTES + lds_off + base * LINE;
         const char* src = tile + (size_t)base * rowb + (unsigned)kt * LINE;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
+            if (q4 < qa || q4 >= qb) continue;
             if ((p.debug & 64) && q4 >= 2) break;
             glds16(src + ((q4 & 1) ? goff_o : goff_e) + q4 * row8, sb + q4 * 8 * LINE);
         }
     };
+    auto issue4 = [&](const char* tile, int base, int lds_off, int kt) { issue_q(tile, base, lds_off, kt, 0, 4); };
 
     // ---- fragment addressing (as dense_kernel.h)
     const int sw = (lane >> 1) & 7;
@@ -128,6 +141,12 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
     const char* xtile = p.x + (size_t)m0 * rowb;
     auto issueX = [&](int kt) { issue4(xtile, xbase, TILE_BYTES, kt); };
     auto issueW = [&](int kt) { issue4(wtile, wbase, 0, kt); };
+    auto issueXq = [&](int kt, int qa, int qb) { issue_q(xtile, xbase, TILE_BYTES, kt, qa, qb); };
+    auto issueWq = [&](int kt, int qa, int qb) { issue_q(wtile, wbase, 0, kt, qa, qb); };
+    // schedule B: an L phase carries only NL of the 4 DMA instructions of an operand share, the others ride
+    // between the MFMAs of the following C phase (an L phase with 4 of them is ~40 % longer than a C phase)
+    constexpr bool schedB = ML_SCHED_B != 0;
+    constexpr int NL = ML_SCHED_B == 2 ? 2 : 3;  // DMA instructions left in an L phase
     if (nk > 0 && loads) {
         issueX(0);
         issueW(0);
@@ -188,11 +207,46 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
                 if (NSPLIT == 3) xlo[jt] = *(const half8*)(sb + xrow + jt * 32 * LINE + coff[kk][1]);
             }
         };
-        auto compute = [&]() {
+        // hook (schedule B): the DMA instructions that ride between the MFMAs of a C phase, one per slot
+        // (slot k = after the first 3 MFMAs of row block k):
+        //   1 = group 0, first C phase : X(kt) quarters [NL,4) then W(kt) quarters [0,4-NL)
+        //   2 = group 1, first C phase : W(kt) quarters [NL,4)
+        //   3 = group 1, second C phase: X(kt) quarters [NL,4)
+        auto compute = [&](int hook, int kt) {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) {
+                    if (schedB && hook) {
+                        constexpr int NC = 4 - NL;                     // instructions per operand moved into C phases
+                        const int count = (hook == 1) ? 2 * NC : NC;
+                        // which of the `count` instructions sit in front of MFMA block (it, jt):
+                        //   style 0: all of them before block (1,0);  style 1: one per row block, before (k+first, 1);
+                        //   style 2: two per row block, before (1 + k/2, 0)
+                        int k0 = 0, k1 = 0;
+                        if (ML_HOOK_STYLE == 0) {
+                            if (it == 1 && jt == 0) k1 = count;
+                        } else if (ML_HOOK_STYLE == 1) {
+                            const int first = (count == 4) ? 0 : 1;
+                            if (jt == 1 && it - first >= 0 && it - first < count) { k0 = it - first; k1 = k0 + 1; }
+                        } else {
+                            if (jt == 0 && it >= 1 && 2 * (it - 1) < count) { k0 = 2 * (it - 1); k1 = (k0 + 2 < count) ? k0 + 2 : count; }
+                        }
+                        if (k1 > k0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            for (int k = k0; k < k1; ++k) {
+                                if (hook == 1) {
+                                    if (k < NC) issueXq(kt, NL + k, NL + k + 1);
+                                    else issueWq(kt, k - NC, k - NC + 1);
+                                } else if (hook == 2) {
+                                    issueWq(kt, NL + k, NL + k + 1);
+                                } else {
+                                    issueXq(kt, NL + k, NL + k + 1);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                     if (NSPLIT == 3) {
                         acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[it], xlo[jt], acc[it][jt], 0, 0, 0);
                         acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[it], xhi[jt], acc[it][jt], 0, 0, 0);
@@ -220,37 +274,73 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
             const char* sb = smem + (t & 1) * STAGE_BYTES;
             const bool pre = loads && t + 1 < nk;
             const bool nxt = loads && t + 2 < nk;
-            if (pre) {                                         // G0: phase 4t     G1: phase 4t+1
-                if (grp == 0) issueX(t + 1);
-                else issueW(t + 1);
-            }
-            load_frags(sb, 0);
-            pp_barrier();
-            compute();                                         // G0: phase 4t+1   G1: phase 4t+2
-            pp_barrier();
-            if (pre && grp == 0) issueW(t + 1);                // G0: phase 4t+2
-            load_frags(sb, 1);                                 //                  G1: phase 4t+3
-            if (grp == 1) {
-                if (nxt) {
-                    // stage t is now completely read (group 0 finished it a phase ago, our own reads are
-                    // drained here): its X rows 128.. can already be overwritten with stage t+2
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    issueX(t + 2);
+            if constexpr (!schedB) {
+                if (pre) {                                         // G0: phase 4t     G1: phase 4t+1
+                    if (grp == 0) issueX(t + 1);
+                    else issueW(t + 1);
                 }
+                load_frags(sb, 0);
+                pp_barrier();
+                compute(0, 0);                                     // G0: phase 4t+1   G1: phase 4t+2
+                pp_barrier();
+                if (pre && grp == 0) issueW(t + 1);                // G0: phase 4t+2
+                load_frags(sb, 1);                                 //                  G1: phase 4t+3
+                if (grp == 1) {
+                    if (nxt) {
+                        // stage t is now completely read (group 0 finished it a phase ago, our own reads are
+                        // drained here): its X rows 128.. can already be overwritten with stage t+2
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        issueX(t + 2);
+                    }
+                    if (pre) {
+                        if (nxt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    if (t < 2) stamp();
+                }
+                pp_barrier();
+                compute(0, 0);                                     // G0: phase 4t+3   G1: phase 4t+4
+                if (grp == 0) {
+                    if (pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (t < 2) stamp();                            // [+3], [+4] end of k-step 0 / 1 incl. DMA wait
+                }
+                pp_barrier();
+            } else {
+                // schedule B.  Per wave and k-step, in program (= vmcnt) order:
+                //   G0: X(t+1) q[0,NL) | C: X(t+1) q[NL,4), W(t+1) q[0,4-NL) | W(t+1) q[4-NL,4) | C: -     then vmcnt(0)
+                //   G1: W(t+1) q[0,NL) | C: W(t+1) q[NL,4)  | X(t+2) q[0,NL), vmcnt(NL) | C: X(t+2) q[NL,4)
+                // (t = 0: group 1 issued all of X(1) before the loop, so its first vmcnt(3) also covers that)
                 if (pre) {
-                    if (nxt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (grp == 0) issueXq(t + 1, 0, NL);
+                    else issueWq(t + 1, 0, NL);
                 }
-                if (t < 2) stamp();
+                load_frags(sb, 0);
+                pp_barrier();
+                compute(pre ? (grp == 0 ? 1 : 2) : 0, t + 1);
+                pp_barrier();
+                if (pre && grp == 0) issueWq(t + 1, 4 - NL, 4);
+                load_frags(sb, 1);
+                if (grp == 1) {
+                    if (nxt) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        issueXq(t + 2, 0, NL);
+                    }
+                    if (pre) {
+                        if (nxt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    if (t < 2) stamp();
+                }
+                pp_barrier();
+                compute((grp == 1 && nxt) ? 3 : 0, t + 2);
+                if (grp == 0) {
+                    if (pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (t < 2) stamp();
+                }
+                pp_barrier();
             }
-            pp_barrier();
-            compute();                                         // G0: phase 4t+3   G1: phase 4t+4
-            if (grp == 0) {
-                if (pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (t < 2) stamp();                            // [+3], [+4] end of k-step 0 / 1 incl. DMA wait
-            }
-            pp_barrier();
         }
         if (grp == 0) pp_barrier();  // group 1's last compute phase
         // every wave has passed the same number of barriers; nobody reads the stage buffers any more
