@@ -36,6 +36,9 @@
 #ifndef ML_HOOK_STYLE
 #define ML_HOOK_STYLE 1
 #endif
+#ifndef ML_L_ORDER
+#define ML_L_ORDER 0   // 1: in an L phase the fragment reads are issued before the DMA instructions
+#endif
 
 namespace mlk {
 
@@ -311,16 +314,18 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
                 //   G0: X(t+1) q[0,NL) | C: X(t+1) q[NL,4), W(t+1) q[0,4-NL) | W(t+1) q[4-NL,4) | C: -     then vmcnt(0)
                 //   G1: W(t+1) q[0,NL) | C: W(t+1) q[NL,4)  | X(t+2) q[0,NL), vmcnt(NL) | C: X(t+2) q[NL,4)
                 // (t = 0: group 1 issued all of X(1) before the loop, so its first vmcnt(3) also covers that)
+                if (ML_L_ORDER) load_frags(sb, 0);
                 if (pre) {
                     if (grp == 0) issueXq(t + 1, 0, NL);
                     else issueWq(t + 1, 0, NL);
                 }
-                load_frags(sb, 0);
+                if (!ML_L_ORDER) load_frags(sb, 0);
                 pp_barrier();
                 compute(pre ? (grp == 0 ? 1 : 2) : 0, t + 1);
                 pp_barrier();
+                if (ML_L_ORDER) load_frags(sb, 1);
                 if (pre && grp == 0) issueWq(t + 1, 4 - NL, 4);
-                load_frags(sb, 1);
+                if (!ML_L_ORDER) load_frags(sb, 1);
                 if (grp == 1) {
                     if (nxt) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

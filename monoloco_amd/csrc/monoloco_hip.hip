@@ -411,7 +411,7 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, in
     p.debug = dense_debug_bits();
     p.trace = nullptr;
 
-    if (rows >= 0 && use_small_path(rows) && head_nh == 0) {
+    if (rows >= 0 && head_nh == 0) {  // the caller chose the small-row path
         const dim3 grid((unsigned)(p.N / 16), (unsigned)((rows + 15) / 16));
         if (grid.y == 0) return ML_OK;
 #define ML_SM(NS, RL, RS) \
@@ -506,14 +506,10 @@ int chunk_rows_env() {
     // ML_CHUNK_ROWS=n (multiple of 256): walk the batch in row chunks through ALL layers so that the
     // two activation buffers of a chunk (2 x n x hidden x 4 B) stay resident in the 256 MiB Infinity
     // Cache between layers.  0 = whole batch per layer.
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("ML_CHUNK_ROWS");
-        v = e ? atoi(e) : 0;
-        if (v < 0) v = 0;
-        v = v / 256 * 256;
-    }
-    return v;
+    const char* e = getenv("ML_CHUNK_ROWS");  // read per call so that tests can switch it in-process
+    int v = e ? atoi(e) : 0;
+    if (v < 0) v = 0;
+    return v / 256 * 256;
 }
 
 // Runs the dense chain + heads on `rows` network rows whose line-format input already sits in
@@ -527,6 +523,7 @@ struct McPass {
 int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass mc = McPass()) {
     const int64_t m_pad_all = round_up64(rows, 256);
     const int64_t chunk = chunk_rows_env() > 0 ? chunk_rows_env() : m_pad_all;
+    const bool small = use_small_path(rows);  // decided on the whole call, not per chunk
     for (int64_t r0 = 0; r0 < m_pad_all; r0 += chunk) {
         const int64_t m_pad = (m_pad_all - r0 < chunk) ? (m_pad_all - r0) : chunk;
         const int64_t rows_here = (rows - r0 < m_pad) ? (rows - r0) : m_pad;
@@ -553,7 +550,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             const Head* fused = nullptr;
             for (const Head& hd : h->heads)
                 if (hd.after_layer == (int)li && (hd.nh == 8 || hd.nh == 9) && dense_variant() != 1 && L.relu && L.res < 0 &&
-                    !dense_debug_bits() && mc.p <= 0.f && !use_small_path(rows_here))
+                    !dense_debug_bits() && mc.p <= 0.f && !small)
                     fused = &hd;
             if (fused) {
                 p.head_w = fused->d_w;
@@ -561,7 +558,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             }
             const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
             if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
-            int rc = launch_dense(h->precision, p, st, fused ? fused->nh : 0, rows_here);
+            int rc = launch_dense(h->precision, p, st, fused ? fused->nh : 0, small ? rows_here : -1);
             if (rc) return rc;
             if (timed) {
                 HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));

@@ -220,3 +220,20 @@ def test_small_row_path_matches_tile_path(hip_lib, cuda_device, monkeypatch, m, 
     assert (raw_tile.double() - ref64).abs().max().item() <= 1e-4
     assert (raw_small - raw_tile).abs().max().item() <= 2e-6 * max(1.0, scale)
     eng.close()
+
+
+def test_row_chunking_is_bit_identical(hip_lib, cuda_device, monkeypatch):
+    """ML_CHUNK_ROWS walks the batch in row chunks through all layers (Infinity-Cache residency experiment): rows
+    are independent, so the result must not change by a bit -- including the fused-head partial sums."""
+    from monoloco_amd import engine
+    sd = synth.make_state_dict(6)
+    kps = torch.tensor(synth.make_poses(5000, 3)).to(cuda_device)
+    kinv = engine.inverse_intrinsics(synth.KITTI_K)
+    eng = engine.LocoEngine(_sd_t(sd), device=cuda_device)
+    out0, xyzds0, raw0 = eng.forward_mono(kps, kinv, want_raw=True)
+    out0, xyzds0, raw0 = out0.clone(), xyzds0.clone(), raw0.clone()
+    monkeypatch.setenv("ML_CHUNK_ROWS", "2048")
+    out1, xyzds1, raw1 = eng.forward_mono(kps, kinv, want_raw=True)
+    assert torch.equal(raw0, raw1) and torch.equal(xyzds0, xyzds1)
+    assert torch.equal(out0.nan_to_num(), out1.nan_to_num())
+    eng.close()
