@@ -128,6 +128,14 @@ int ml_pixel_to_camera(const float* uv_dev, int64_t n, const float* kinv_host, f
 /* get_keypoints (utils/camera.py:69-107): kps_dev (m,3,17) -> out_dev (m,2).  mode: 0 center, 1 bottom,
  * 2 head, 3 shoulder, 4 hip, 5 ankle. */
 int ml_get_keypoints(const float* kps_dev, int64_t m, int mode, float* out_dev, void* stream);
+/* extract_outputs_mono (process.py:330-360, legacy 'monoloco_p' outputs x, y, z, log(b/z), h, w, l, sin, cos):
+ * raw_dev (m,9) -> out_dev (m, ML_OUT_STRIDE) with X,Y,Z = the raw xyz, D = ||xyz||, BI = exp(raw3)*raw2,
+ * YAW, YAW_EGO, H, W, L, ORI0/1; AUX, CONF, UC, VC are 0. */
+int ml_extract_outputs_mono(const float* raw_dev, int64_t m, float* out_dev, void* stream);
+/* laplace_sampling (process.py:101-122): mu_b_dev (m,2) = (mu, b) -> out_dev (n_samples, m) draws of
+ * Laplace(mu, |b|) from the library's counter-based generator (same draws as ml_loco_epistemic_mono for the same
+ * seed; the reference seeds torch's generator with 1, so parity is statistical). */
+int ml_laplace_sampling(const float* mu_b_dev, int64_t m, int n_samples, uint32_t seed, float* out_dev, void* stream);
 /* xyz_from_distance (utils/camera.py:161-177): d_dev (m) (or one value if d_is_scalar), centres_dev (m,3)
  * -> out_dev (m,3). */
 int ml_xyz_from_distance(const float* d_dev, int d_is_scalar, const float* centres_dev, int64_t m, float* out_dev,

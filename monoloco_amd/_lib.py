@@ -6,6 +6,12 @@ fallback: if the library is missing or a call fails, a ``MonolocoHipError`` is r
 """
 import ctypes
 import os
+
+# PyTorch-ROCm bundles its own HIP/HSA runtime (torch/lib/libamdhip64.so).  It has to be in the process BEFORE
+# this library is dlopen'ed: the library's NEEDED libamdhip64.so.7 then binds to that already-loaded runtime and
+# both sides share one device context.  Loaded the other way round, /opt/rocm's runtime comes in first, torch
+# later brings a second HSA runtime and HIP reports "no ROCm-capable device" (seen on the GPU box).
+import torch  # noqa: F401  (import order matters, see above)
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint16, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -40,6 +46,8 @@ SIGNATURES = {
     'ml_preprocess_mono': (c_int, [_P, c_int64, POINTER(c_float), c_float, c_int, _P, _P, _P]),
     'ml_stereo_pairs': (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
     'ml_extract_outputs': (c_int, [_P, c_int, _P, c_int64, _P, POINTER(c_float), _P, _P, _P, _P]),
+    'ml_extract_outputs_mono': (c_int, [_P, c_int64, _P, _P]),
+    'ml_laplace_sampling': (c_int, [_P, c_int64, c_int, c_uint32, _P, _P]),
     'ml_pixel_to_camera': (c_int, [_P, c_int64, POINTER(c_float), c_float, _P, _P]),
     'ml_get_keypoints': (c_int, [_P, c_int64, c_int, _P, _P]),
     'ml_xyz_from_distance': (c_int, [_P, c_int, _P, c_int64, _P, _P]),

@@ -371,4 +371,29 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ raw
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// post, legacy 'monoloco_p' flavour: extract_outputs_mono (reference process.py:330-360).  raw columns: x, y, z,
+// s = log(b/z) shares column 3 with nothing else -- zb = raw[:,2:4] -- then h, w, l, sin, cos.
+//   bi = exp(raw3) * raw2 (unnormalize_bi on zb), d = ||xyz||_2, yaw = atan2(raw7, raw8),
+//   yaw_ego = back_correct_angles(yaw, xyz).  Same packed layout as post_kernel (aux, conf, uc, vc = 0).
+__global__ __launch_bounds__(256) void post_mono_p_kernel(const float* __restrict__ raw, int64_t m,
+                                                          float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const float* r = raw + i * 9;
+    const float x = r[0], y = r[1], z = r[2];
+    const float bi = __fmul_rn(expf(r[3]), z);                                            // process.py:131
+    const float d = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));  // :351
+    const float yaw = atan2f(r[7], r[8]);                                                 // :356
+    float ego = __fadd_rn(yaw, atan2f(x, z));                                             // camera.py:203-204
+    const float PI_F = 3.14159274101257324f, TWO_PI_F = 6.28318548202514648f;
+    if (ego > PI_F) ego = __fsub_rn(ego, TWO_PI_F);
+    if (ego < -PI_F) ego = __fadd_rn(ego, TWO_PI_F);
+    float* o = out + i * 16;
+    o[0] = x; o[1] = y; o[2] = z; o[3] = d;
+    o[4] = bi; o[5] = yaw; o[6] = ego; o[7] = 0.f;
+    o[8] = r[4]; o[9] = r[5]; o[10] = r[6]; o[11] = 0.f;
+    o[12] = r[7]; o[13] = r[8]; o[14] = 0.f; o[15] = 0.f;
+}
+
 }  // namespace mlk

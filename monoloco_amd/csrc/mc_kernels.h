@@ -62,6 +62,19 @@ __global__ __launch_bounds__(256) void mc_accumulate_kernel(const float* __restr
     sumsq[i] += s2;
 }
 
+// laplace_sampling (reference process.py:101-122): n_samples draws of Laplace(mu, |b|) per person, laid out
+// (n_samples, m) like laplace.sample((n_samples,)).  Same draws as mc_accumulate_kernel for the same seed.
+__global__ __launch_bounds__(256) void laplace_sample_kernel(const float* __restrict__ mu_b, int64_t m, int n_samples,
+                                                            uint32_t seed, float* __restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= m * (int64_t)n_samples) return;
+    const int64_t k = id / m, i = id - k * m;
+    const float mu = mu_b[i * 2], b = fabsf(mu_b[i * 2 + 1]);
+    const float u = u01(seed, (uint32_t)i, (uint32_t)k) - 0.5f;
+    const float l = -copysignf(logf(1.0f - 2.0f * fabsf(u)), u);
+    out[id] = mu + b * l;
+}
+
 // unbiased standard deviation over n_total = passes * n_samples draws (torch.std default)
 __global__ __launch_bounds__(256) void mc_finish_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq,
                                                        int64_t m, double n_total, float* __restrict__ epi) {

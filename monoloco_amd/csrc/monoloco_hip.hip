@@ -873,6 +873,22 @@ int ml_extract_outputs(const float* raw_dev, int out_features, const int32_t* ro
 
 #define ML_GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, (hipStream_t)stream
 
+int ml_extract_outputs_mono(const float* raw_dev, int64_t m, float* out_dev, void* stream) {
+    if (m < 0 || (m > 0 && (!raw_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    hipLaunchKernelGGL(mlk::post_mono_p_kernel, ML_GRID(m), raw_dev, m, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+int ml_laplace_sampling(const float* mu_b_dev, int64_t m, int n_samples, uint32_t seed, float* out_dev, void* stream) {
+    if (m < 0 || n_samples <= 0 || (m > 0 && (!mu_b_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    hipLaunchKernelGGL(mlk::laplace_sample_kernel, ML_GRID(m * (int64_t)n_samples), mu_b_dev, m, n_samples, seed, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
 int ml_pixel_to_camera(const float* uv_dev, int64_t n, const float* kinv_host, float z_met, float* out_dev,
                        void* stream) {
     if (n < 0 || !kinv_host || (n > 0 && (!uv_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");

@@ -100,6 +100,30 @@ def extract_outputs_device(raw, centre=None, kk=None, box_conf=None, row_index=N
     return out, xyzds
 
 
+def extract_outputs_mono_device(raw):
+    """raw (m, 9) legacy 'monoloco_p' outputs -> packed (m,16) device tensor (ml_extract_outputs_mono)."""
+    lib = _lib.load()
+    dev = _require_cuda(raw.device)
+    raw = _dev_f32(raw, dev)
+    assert raw.dim() == 2 and raw.shape[1] == 9, "extract_outputs_mono needs (m, 9) outputs"
+    out = torch.empty((raw.shape[0], _lib.ML_OUT_STRIDE), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ml_extract_outputs_mono(_ptr(raw), raw.shape[0], _ptr(out), _stream(dev)))
+    return out
+
+
+def laplace_sampling_device(mu_b, n_samples, seed=1):
+    """(m,2) = (mu, b) -> (n_samples, m) draws of Laplace(mu, |b|) on the device (ml_laplace_sampling)."""
+    lib = _lib.load()
+    dev = _require_cuda(mu_b.device)
+    mu_b = _dev_f32(mu_b, dev)
+    assert mu_b.dim() == 2 and mu_b.shape[1] == 2
+    out = torch.empty((int(n_samples), mu_b.shape[0]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ml_laplace_sampling(_ptr(mu_b), mu_b.shape[0], int(n_samples), int(seed), _ptr(out), _stream(dev)))
+    return out
+
+
 def debug_linear(x, w, b, relu=False, res=None, precision='f16x2'):
     """Single dense layer through the MFMA kernel (test hook)."""
     lib = _lib.load()

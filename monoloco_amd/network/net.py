@@ -15,7 +15,7 @@ import torch
 from .. import engine
 from ..utils import get_iou_matches, get_keypoints, pixel_to_camera, reorder_matches, xyz_from_distance
 from .architectures import LocoModel, MonolocoModel
-from .process import packed_to_dict, unnormalize_bi
+from .process import extract_outputs_mono, packed_to_dict, unnormalize_bi
 
 
 class Loco:
@@ -33,21 +33,21 @@ class Loco:
             # The reference reads self.net before assigning it here (net.py:41) and raises AttributeError, so
             # net= is unusable there; the evident intent (net.py:47-60, 95-104) is implemented instead.
             assert net in ('monstereo', 'monoloco', 'monoloco_p', 'monoloco_pp')
-            if net == 'monoloco_p':
-                raise NotImplementedError("net='monoloco_p' (extract_outputs_mono) is not built; use monoloco_pp")
             assert (net == 'monstereo') == (mode == 'stereo'), "Assert arguments mode and net are in conflict"
             self.net = net
         if self.net == 'monstereo':
             input_size, output_size = 68, 10
         elif self.net == 'monoloco_pp':
             input_size, output_size = 34, 9
-        else:  # legacy MonoLoco: 34 -> 256 -> (d, log(b/d)), net.py:58-60 and LINEAR_SIZE_MONO
+        elif self.net == 'monoloco_p':  # legacy: MonolocoModel 34 -> 256 -> 9 (net.py:50-53)
+            input_size, output_size, linear_size = 34, 9, 256
+        else:  # legacy MonoLoco: 34 -> linear_size -> (d, log(b/d)), net.py:58-60
             input_size, output_size = 34, 2
         self.device = engine._require_cuda(device)
         self.n_dropout = n_dropout
         self.epistemic = bool(self.n_dropout > 0)
         if isinstance(model, str):
-            if self.net == 'monoloco':
+            if self.net in ('monoloco', 'monoloco_p'):
                 self.model = MonolocoModel(p_dropout=p_dropout, input_size=input_size, linear_size=linear_size,
                                            output_size=output_size)
             else:
@@ -77,6 +77,11 @@ class Loco:
                                        zero_center=True)
             raw = self.engine.forward_raw(x)
             dic_out = {'d': raw[:, 0:1].cpu(), 'bi': unnormalize_bi(raw).cpu()}
+            n_out = kps.shape[0]
+        elif self.net == 'monoloco_p':
+            # legacy (net.py:102-104): plain inputs, MonolocoModel with 9 outputs, extract_outputs_mono
+            x = engine.preprocess_mono(kps, kk.tolist() if isinstance(kk, torch.Tensor) else kk, device=dev)
+            dic_out = extract_outputs_mono(self.engine.forward_raw(x))
             n_out = kps.shape[0]
         elif self.net == 'monoloco_pp':
             out, _, _ = self.engine.forward_mono(kps, kinv)

@@ -156,6 +156,34 @@ def extract_outputs(outputs, tasks=()):
     return packed_to_dict(out, outputs.shape[1])
 
 
+def extract_outputs_mono(outputs, tasks=None):
+    """Legacy 'monoloco_p' outputs (m, 9) = x, y, z, log(b/z), h, w, l, sin, cos -> raw slices (tasks given) or the
+    processed dictionary of detached CPU tensors (reference process.py:330-360)."""
+    slices = {'xyz': outputs[:, 0:3], 'zb': outputs[:, 2:4], 'h': outputs[:, 4:5], 'w': outputs[:, 5:6],
+              'l': outputs[:, 6:7], 'ori': outputs[:, 7:9]}
+    if tasks is not None:
+        assert isinstance(tasks, tuple), "tasks need to be a tuple"
+        return [slices[task] for task in tasks]
+    dev = engine._require_cuda(outputs.device if outputs.is_cuda else None)
+    o = engine.extract_outputs_mono_device(outputs.detach().to(dev)).cpu()
+    dic = {key: el.detach().cpu() for key, el in slices.items()}
+    dic['xyzd'] = o[:, 0:4].clone()
+    dic['d'], dic['bi'] = o[:, 3:4].clone(), o[:, 4:5].clone()
+    dic['yaw'] = (o[:, 5:6].clone(), o[:, 6:7].clone())
+    return dic
+
+
+def laplace_sampling(outputs, n_samples):
+    """n_samples draws of Laplace(mu = outputs[:,0], b = |outputs[:,1]|) per row -> (n_samples, m) on the device of
+    `outputs` (reference process.py:101-122).  The reference re-seeds torch's generator with 1 on every call; here the
+    library's counter-based generator is seeded with 1, so two calls give the same draws as well, but the streams
+    differ from torch's (statistical parity)."""
+    home = outputs.device
+    xx = engine.laplace_sampling_device(outputs.detach().to(engine._require_cuda(home if home.type == 'cuda' else None)),
+                                        n_samples, seed=1)
+    return xx.to(home)
+
+
 def extract_labels_aux(labels, tasks=None):
     """reference process.py:281-290."""
     dic = {'aux': labels[:, 0:1]}

@@ -403,3 +403,48 @@ def golden_legacy():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'legacy':
     golden_legacy()
+
+
+def golden_mono_p():
+    """Legacy 'monoloco_p': extract_outputs_mono (process.py:330-360) on seeded (m,9) outputs, and the reference's
+    MonolocoModel(34 -> 256 -> 9) + extract_outputs_mono on the pifpaf fixture (Loco.forward branch net.py:102-104)."""
+    from monoloco.network.architectures import MonolocoModel
+    from monoloco.network.process import extract_outputs_mono
+    torch.manual_seed(13)
+    m = 300
+    raw = torch.randn(m, 9)
+    raw[:, 0] = raw[:, 0] * 6
+    raw[:, 1] = raw[:, 1] * 1.5 + 1
+    raw[:, 2] = torch.rand(m) * 40 + 1
+    raw[::17, 2] = -raw[::17, 2]      # behind the camera: exercises the +-2pi wrap of the egocentric angle
+    raw[:, 3] = torch.randn(m) * 0.5 - 2
+    dic = extract_outputs_mono(raw.clone())
+    out = {'raw': raw.numpy()}
+    out.update(dic_to_np(dic, 'ex_'))
+    model = MonolocoModel(input_size=34, output_size=9, linear_size=256, p_dropout=0.2)
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(torch.randn_like(mod.running_mean) * 0.3)
+                mod.running_var.copy_(torch.rand_like(mod.running_var) + 0.5)
+                mod.weight.copy_(torch.rand_like(mod.weight) + 0.5)
+                mod.bias.copy_(torch.randn_like(mod.bias) * 0.2)
+        model.w2.bias.copy_(torch.tensor([0.5, 1.0, 15.0, -1.5, 1.7, 0.6, 0.8, 0.3, 0.7]))
+    model.eval()
+    anns = json.load(open(os.path.join(REF, 'tests', '002282.png.pifpaf.json')))
+    boxes, keypoints = preprocess_pifpaf(copy.deepcopy(anns), (1238, 374), enlarge_boxes=False)
+    kk = load_calibration('kitti', (1238, 374))
+    with torch.no_grad():
+        x = preprocess_monoloco(torch.tensor(keypoints), torch.tensor(kk))
+        net_raw = model(x)
+        net_dic = extract_outputs_mono(net_raw)
+    out.update(kps=np.array(keypoints, dtype=np.float32), kk=np.array(kk, dtype=np.float64), net_raw=net_raw.numpy())
+    out.update(dic_to_np(net_dic, 'net_'))
+    for k, v in np_sd(model.state_dict()).items():
+        out['sd.' + k] = v
+    np.savez_compressed(os.path.join(OUT, 'golden_mono_p.npz'), **out)
+    print('wrote golden_mono_p.npz', sorted(k for k in out if not k.startswith('sd.')))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'mono_p':
+    golden_mono_p()

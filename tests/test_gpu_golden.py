@@ -322,3 +322,56 @@ def test_legacy_monoloco_model_vs_reference(hip_lib, cuda_device):
     assert epi.shape == (len(g['kps']),) and torch.isfinite(epi).all()
     lap = np.sqrt(2.0) * np.abs(g['bi'][:, 0])           # std of Laplace(d, bi) without any dropout spread
     assert (epi.numpy() > 0.5 * lap).all() and (epi.numpy() < 5.0 * lap + 5.0).all()
+
+
+def test_legacy_monoloco_p_vs_reference(hip_lib, cuda_device):
+    """extract_outputs_mono on the HIP kernel (bit-level against the reference on the same raw rows) and
+    Loco(net='monoloco_p') = MonolocoModel(34 -> 256 -> 9) + extract_outputs_mono on the pifpaf fixture."""
+    from monoloco_amd.network import Loco
+    from monoloco_amd.network.architectures import MonolocoModel
+    from monoloco_amd.network.process import extract_outputs_mono
+    g = dict(np.load(os.path.join(G, 'golden_mono_p.npz')))
+    dic = extract_outputs_mono(torch.tensor(g['raw']))
+    for key in ('xyz', 'zb', 'h', 'w', 'l', 'ori'):
+        assert torch.equal(dic[key], torch.tensor(g['ex_' + key])), key
+    assert not dic['d'].is_cuda and dic['xyzd'].shape == (len(g['raw']), 4)
+    assert np.abs(dic['d'].numpy() - g['ex_d']).max() <= 4e-6            # fp32 norm: summation order / sqrt ulp
+    assert np.abs(dic['xyzd'].numpy() - g['ex_xyzd']).max() <= 4e-6
+    assert np.abs(dic['bi'].numpy() / g['ex_bi'] - 1).max() <= 2e-6      # exp: libm vs device ulp
+    assert np.abs(dic['yaw'][0].numpy() - g['ex_yaw_pred']).max() <= 1e-6
+    assert np.abs(dic['yaw'][1].numpy() - g['ex_yaw_ego']).max() <= 2e-6
+    slices = extract_outputs_mono(torch.tensor(g['raw']), tasks=('xyz', 'ori'))
+    assert torch.equal(slices[0], torch.tensor(g['raw'][:, 0:3])) and torch.equal(slices[1], torch.tensor(g['raw'][:, 7:9]))
+
+    model = MonolocoModel(input_size=34, output_size=9, linear_size=256)
+    model.load_state_dict({k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith('sd.')})
+    net = Loco(model=model, mode='mono', net='monoloco_p', device=cuda_device)
+    out = net.forward(g['kps'].tolist(), g['kk'].tolist())
+    assert set(out) == {'xyz', 'zb', 'h', 'w', 'l', 'ori', 'xyzd', 'd', 'bi', 'yaw', 'epi'}
+    for key in ('xyz', 'zb', 'h', 'w', 'l', 'ori', 'xyzd', 'd', 'bi'):
+        assert np.abs(out[key].numpy() - g['net_' + key]).max() <= TOL, key
+    assert np.abs(out['yaw'][0].numpy() - g['net_yaw_pred']).max() <= TOL
+    assert np.abs(out['yaw'][1].numpy() - g['net_yaw_ego']).max() <= TOL
+
+
+def test_laplace_sampling_statistics(hip_lib, cuda_device):
+    """laplace_sampling (process.py:101-122) on the device generator: layout (n_samples, m), same draws on every
+    call (the reference re-seeds with 1), Laplace(mu, |b|) moments per person."""
+    from monoloco_amd.network.process import laplace_sampling
+    m, n = 64, 20000
+    mu = torch.linspace(1., 40., m)
+    b = torch.linspace(0.05, 3., m) * torch.where(torch.arange(m) % 2 == 0, 1., -1.)   # sign is ignored (abs)
+    outputs = torch.stack((mu, b), 1)
+    xx = laplace_sampling(outputs, n)
+    assert xx.shape == (n, m) and not xx.is_cuda
+    assert torch.equal(xx, laplace_sampling(outputs, n))
+    assert laplace_sampling(outputs.to(cuda_device), 8).is_cuda
+    mean, std = xx.double().mean(0), xx.double().std(0)
+    se = b.abs().double() * np.sqrt(2.0 / n)
+    assert ((mean - mu.double()).abs() <= 5 * se).all()
+    assert (std / (np.sqrt(2.0) * b.abs().double()) - 1).abs().max().item() <= 0.05
+    med = xx.double().median(0).values
+    assert ((med - mu.double()).abs() <= 5 * b.abs().double() / np.sqrt(n)).all()
+    # two persons never share their draws
+    z = (xx - mu) / b.abs()
+    assert abs(np.corrcoef(z[:, 0].numpy(), z[:, 1].numpy())[0, 1]) < 0.03

@@ -138,3 +138,18 @@ def test_legacy_monoloco_model_oracle_vs_reference():
     assert (res['bi'] - torch.tensor(g['bi'])).abs().max().item() <= 5e-6
     raw64 = O.monoloco_forward(sd, torch.tensor(g['x']), dtype=torch.float64)
     assert (raw64 - torch.tensor(g['raw64'])).abs().max().item() <= 1e-12
+
+
+def test_extract_outputs_mono_oracle_vs_reference():
+    """Legacy 'monoloco_p' post-processing (process.py:330-360) against the reference's own function."""
+    g = dict(np.load(os.path.join(G, 'golden_mono_p.npz')))
+    dic = O.extract_outputs_mono(torch.tensor(g['raw']))
+    for key in ('xyz', 'zb', 'h', 'w', 'l', 'ori', 'xyzd', 'd', 'bi'):
+        assert torch.equal(dic[key], torch.tensor(g['ex_' + key])), key
+    assert torch.equal(dic['yaw'][0], torch.tensor(g['ex_yaw_pred']))
+    assert (dic['yaw'][1] - torch.tensor(g['ex_yaw_ego'])).abs().max().item() <= 5e-7
+    assert (torch.tensor(g['ex_yaw_ego']).abs() <= np.pi + 1e-6).all()
+    sd = {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith('sd.')}
+    x = O.preprocess_monoloco(torch.tensor(g['kps']), g['kk'].tolist())
+    raw = O.monoloco_forward(sd, x)
+    assert (raw - torch.tensor(g['net_raw'])).abs().max().item() <= 5e-6
