@@ -79,6 +79,17 @@ def main():
     import torch
     import torch.distributed as dist
     import synth
+    from monoloco_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        # the library normally travels with the tree; on a box without it local rank 0 builds it, the others wait
+        if int(os.environ.get('LOCAL_RANK', '0')) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(_lib.LIB_PATH) and time.time() - t_wait < 900:
+                time.sleep(1.0)
+            time.sleep(2.0)  # let the linker finish writing
     from monoloco_amd import engine, parallel
 
     rank, world, local = parallel.init_from_env('nccl' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else None)
