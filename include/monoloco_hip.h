@@ -128,6 +128,13 @@ int ml_pixel_to_camera(const float* uv_dev, int64_t n, const float* kinv_host, f
 /* get_keypoints (utils/camera.py:69-107): kps_dev (m,3,17) -> out_dev (m,2).  mode: 0 center, 1 bottom,
  * 2 head, 3 shoulder, 4 hip, 5 ankle. */
 int ml_get_keypoints(const float* kps_dev, int64_t m, int mode, float* out_dev, void* stream);
+/* Dataset-preparation rows in one launch (prep/preprocess_kitti.py:190-253 calls preprocess_monoloco once per
+ * matched annotation, each with the K of its image): kps_dev (m,3,17); kinv_table_host (nk,9) = inverses of the
+ * distinct intrinsic matrices; k_index_dev (m) int32 = table entry of each row (not range-checked).  kps_r_dev
+ * NULL -> x_dev (m,34) mono inputs; else (m,3,17) right keypoints -> x_dev (m,68) stereo training rows
+ * [L, L - R] (preprocess_kitti.py:242-247).  Bit-identical to the per-annotation calls. */
+int ml_preprocess_rows(const float* kps_dev, const float* kps_r_dev, int64_t m, const float* kinv_table_host, int nk,
+                       const int32_t* k_index_dev, float z_met, float* x_dev, void* stream);
 /* extract_outputs_mono (process.py:330-360, legacy 'monoloco_p' outputs x, y, z, log(b/z), h, w, l, sin, cos):
  * raw_dev (m,9) -> out_dev (m, ML_OUT_STRIDE) with X,Y,Z = the raw xyz, D = ||xyz||, BI = exp(raw3)*raw2,
  * YAW, YAW_EGO, H, W, L, ORI0/1; AUX, CONF, UC, VC are 0. */

@@ -396,4 +396,36 @@ __global__ __launch_bounds__(256) void post_mono_p_kernel(const float* __restric
     o[12] = r[7]; o[13] = r[8]; o[14] = 0.f; o[15] = 0.f;
 }
 
+// ------------------------------------------------------------------------------------------
+// dataset preparation rows (reference prep/preprocess_kitti.py:190-253): every matched annotation is normalised
+// with the K of ITS image.  One thread per (row, joint); kinv_table holds the inverses of the distinct K,
+// k_index the table entry of each row.  With right keypoints the row is the stereo training input
+// [L (34), L - R (34)] (preprocess_kitti.py:242-247), else the 34 mono inputs.
+__global__ __launch_bounds__(256) void prep_rows_kernel(const float* __restrict__ kps, const float* __restrict__ kps_r,
+                                                        int64_t m, const Kinv* __restrict__ kinv_table,
+                                                        const int32_t* __restrict__ k_index, float z_met,
+                                                        float* __restrict__ x) {
+#pragma clang fp contract(off)  // L - R must subtract the ROUNDED right value: no fma(-acc, z, lx)
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= m * NKP) return;
+    const int64_t row = id / NKP;
+    const int j = (int)(id - row * NKP);
+    const float* kr = kinv_table[k_index[row]].k;
+    const float* p = kps + row * KPS_ROW;
+    const float lx = cam_row(p[j], p[NKP + j], kr + 0, z_met);
+    const float ly = cam_row(p[j], p[NKP + j], kr + 3, z_met);
+    const int width = kps_r ? 2 * NIN : NIN;
+    float* o = x + row * width;
+    o[2 * j] = lx;
+    o[2 * j + 1] = ly;
+    if (kps_r) {
+        const float* q = kps_r + row * KPS_ROW;
+        float rx = cam_row(q[j], q[NKP + j], kr + 0, z_met);
+        float ry = cam_row(q[j], q[NKP + j], kr + 3, z_met);
+        asm volatile("" : "+v"(rx), "+v"(ry));  // the rounded products, opaque to the contraction pass
+        o[NIN + 2 * j] = lx - rx;
+        o[NIN + 2 * j + 1] = ly - ry;
+    }
+}
+
 }  // namespace mlk

@@ -873,6 +873,28 @@ int ml_extract_outputs(const float* raw_dev, int out_features, const int32_t* ro
 
 #define ML_GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, (hipStream_t)stream
 
+int ml_preprocess_rows(const float* kps_dev, const float* kps_r_dev, int64_t m, const float* kinv_table_host, int nk,
+                       const int32_t* k_index_dev, float z_met, float* x_dev, void* stream) {
+    if (m < 0 || nk <= 0 || !kinv_table_host || (m > 0 && (!kps_dev || !k_index_dev || !x_dev)))
+        return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<mlk::Kinv> table((size_t)nk);
+    for (int i = 0; i < nk; ++i) table[i] = make_kinv(kinv_table_host + (size_t)i * 9);
+    mlk::Kinv* d_table = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&d_table, (size_t)nk * sizeof(mlk::Kinv), st));
+    // pageable source: the copy is complete (staged) when the call returns, so `table` may go out of scope
+    hipError_t e = hipMemcpyAsync(d_table, table.data(), (size_t)nk * sizeof(mlk::Kinv), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mlk::prep_rows_kernel, ML_GRID(m * mlk::NKP), kps_dev, kps_r_dev, m, (const mlk::Kinv*)d_table,
+                           k_index_dev, z_met, x_dev);
+        e = hipGetLastError();
+    }
+    (void)hipFreeAsync(d_table, st);
+    if (e != hipSuccess) return fail(ML_ERR_HIP, "ml_preprocess_rows: %s", hipGetErrorString(e));
+    return ML_OK;
+}
+
 int ml_extract_outputs_mono(const float* raw_dev, int64_t m, float* out_dev, void* stream) {
     if (m < 0 || (m > 0 && (!raw_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
     if (m == 0) return ML_OK;

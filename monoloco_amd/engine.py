@@ -69,6 +69,27 @@ def preprocess_mono(kps, kk, z_met=10.0, device=None, want_centre=False, zero_ce
     return (x, c) if want_centre else x
 
 
+def preprocess_rows(kps, kks, k_index, kps_r=None, device=None, z_met=10.0):
+    """Dataset-preparation inputs in one launch: row i of kps (m,3,17) is normalised with kks[k_index[i]]
+    (reference prep/preprocess_kitti.py:190-253).  kps_r (m,3,17) given -> (m,68) stereo rows [L, L - R]."""
+    lib = _lib.load()
+    dev = _require_cuda(device)
+    kps = _dev_f32(kps, dev)
+    assert kps.dim() == 3 and kps.shape[1] == 3 and kps.shape[2] == 17, "keypoints must be (m, 3, 17)"
+    m = kps.shape[0]
+    if kps_r is not None:
+        kps_r = _dev_f32(kps_r, dev)
+        assert kps_r.shape == kps.shape, "left and right keypoints must pair row by row"
+    table = np.ascontiguousarray(np.stack([inverse_intrinsics(kk) for kk in kks]).astype(np.float32))
+    idx = torch.as_tensor(np.asarray(k_index), dtype=torch.int32).to(dev).contiguous()
+    assert idx.shape == (m,) and (m == 0 or (int(idx.min()) >= 0 and int(idx.max()) < len(table)))
+    x = torch.empty((m, 68 if kps_r is not None else 34), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ml_preprocess_rows(_ptr(kps), _ptr(kps_r), m, fptr(table), len(table), _ptr(idx), float(z_met), _ptr(x),
+                                     _stream(dev)))
+    return x
+
+
 def stereo_pairs(xl, xr):
     lib = _lib.load()
     dev = _require_cuda(xl.device)

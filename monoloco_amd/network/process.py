@@ -116,6 +116,15 @@ def preprocess_monstereo(keypoints, keypoints_r, kk):
     return rows.to(home), [xr.shape[0]] * xl.shape[0]
 
 
+def preprocess_monoloco_rows(keypoints, kks, k_index, keypoints_r=None):
+    """Batched dataset preparation (reference prep/preprocess_kitti.py:190-253 runs preprocess_monoloco once per
+    matched annotation): row i is normalised with kks[k_index[i]]; with `keypoints_r` the rows are the stereo
+    training inputs [L, L - R].  One kernel launch, bit-identical to the per-annotation calls."""
+    home = _home(keypoints)
+    x = engine.preprocess_rows(keypoints, kks, k_index, kps_r=keypoints_r, device=home if home.type == 'cuda' else None)
+    return x.to(home)
+
+
 def unnormalize_bi(loc):
     """bi = exp(loc[:,1]) * loc[:,0] for loc (m,2) = (d, log b/d) (reference process.py:125-133)."""
     assert loc.size()[1] == 2, "size of the output tensor should be (m, 2)"

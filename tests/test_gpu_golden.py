@@ -375,3 +375,19 @@ def test_laplace_sampling_statistics(hip_lib, cuda_device):
     # two persons never share their draws
     z = (xx - mu) / b.abs()
     assert abs(np.corrcoef(z[:, 0].numpy(), z[:, 1].numpy())[0, 1]) < 0.03
+
+
+def test_dataset_prep_rows_one_launch(hip_lib, cuda_device, gold):
+    """Batched dataset preparation: all 500 mono / 556 stereo fixture rows, each with the K of its own image, in
+    ONE launch -- bit for bit the X the reference's prep stored in its joints files."""
+    from monoloco_amd.network.process import preprocess_monoloco_rows
+    x = preprocess_monoloco_rows(torch.tensor(gold['mono_kps']), [k.tolist() for k in gold['mono_unique_k']],
+                                 gold['mono_k_index'])
+    assert x.shape == (500, 34) and x.device.type == 'cpu'
+    assert torch.equal(x, torch.tensor(gold['mono_x_fixture']))
+    xs = preprocess_monoloco_rows(torch.tensor(gold['stereo_kps_l']).to(cuda_device),
+                                  [k.tolist() for k in gold['stereo_unique_k']], gold['stereo_k_index'],
+                                  keypoints_r=torch.tensor(gold['stereo_kps_r']))
+    assert xs.shape == (556, 68) and xs.is_cuda
+    assert torch.equal(xs.cpu(), torch.tensor(gold['stereo_x_fixture']))
+    assert preprocess_monoloco_rows(torch.zeros((0, 3, 17)), [synth.KITTI_K], np.zeros(0, dtype=np.int64)).shape == (0, 34)
