@@ -36,6 +36,9 @@
 #ifndef ML_HOOK_STYLE
 #define ML_HOOK_STYLE 1
 #endif
+#ifndef ML_SETPRIO
+#define ML_SETPRIO 0   // 1: s_setprio(1) around every C phase; 2: static priority 1 for waves 4-7
+#endif
 #ifndef ML_L_ORDER
 #define ML_L_ORDER 0   // 1: in an L phase the fragment reads are issued before the DMA instructions
 #endif
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
 
     int vb = blockIdx.x;
     if (vb >= ntiles) return;
+    if (ML_SETPRIO == 2 && grp == 1) __builtin_amdgcn_s_setprio(1);  // grp is wave-uniform (readfirstlane)
     // optional timeline (bring-up builds only, -DML_DENSE_TRACE): slot ts of this wave <- s_memtime
 #ifdef ML_DENSE_TRACE
     unsigned long long* const trc = p.trace ? p.trace + ((size_t)blockIdx.x * 8 + w) * 64 : nullptr;
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
         //   2 = group 1, first C phase : W(kt) quarters [NL,4)
         //   3 = group 1, second C phase: X(kt) quarters [NL,4)
         auto compute = [&](int hook, int kt) {
+            if (ML_SETPRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
                     }
                     acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[it], xhi[jt], acc[it][jt], 0, 0, 0);
                 }
+            if (ML_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
         };
 
         // Phase p (after the tile-start barrier): group 0 reads half-step h in phase 2h and computes it in
