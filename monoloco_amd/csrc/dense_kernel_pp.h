@@ -58,6 +58,47 @@ __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Epilogue arithmetic on value PAIRS with the mixed-precision FMA (v_fma_mix*): 3 VALU instructions per value
+// instead of the ~8 hipcc emits for  v = acc * 2^-e; clamp; hi = (f16) v; lo = (f16)(v - (float) hi).
+// Same results bit for bit for in-range values: the product with a power of two and v - hi are exact, so
+// rounding once inside the fma equals rounding the separately computed fp32 value.
+//   h = packed fp16 (rn(c0*d), rn(c1*d)),  l = packed fp16 (rn(c0*d - h.lo), rn(c1*d - h.hi)),  c = med3(acc, lo_lim, lim)
+template <bool RELU>
+__device__ __forceinline__ void split2_scaled(float a0, float a1, float d, float lim, unsigned& h, unsigned& l) {
+    // (asm: the builtin makes hipcc canonicalise the MFMA results first, one more VALU instruction per value)
+    const float lo_lim = RELU ? 0.0f : -lim;
+    float c0, c1;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(c0) : "v"(a0), "v"(lo_lim), "v"(lim));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(c1) : "v"(a1), "v"(lo_lim), "v"(lim));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(c0), "v"(d));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(c1), "v"(d));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(c0), "v"(d), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(c1), "v"(d), "v"(h));
+}
+// with a residual given as packed fp16 (hi pair rh, lo pair rl):  v = relu(acc)*d + (rh + rl), clamped to fp16 range
+template <bool RELU>
+__device__ __forceinline__ void split2_res(float a0, float a1, float d, unsigned rh, unsigned rl, unsigned& h, unsigned& l) {
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r0) : "v"(rh), "v"(rl));                  // exact
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r1) : "v"(rh), "v"(rl));
+    float c0 = a0, c1 = a1;
+    if (RELU) {
+        asm("v_max_f32 %0, 0, %1" : "=v"(c0) : "v"(a0));
+        asm("v_max_f32 %0, 0, %1" : "=v"(c1) : "v"(a1));
+    }
+    float v0, v1;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v0) : "v"(c0), "v"(d), "v"(r0));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v1) : "v"(c1), "v"(d), "v"(r1));
+    const float big = 65504.0f;
+    asm("v_med3_f32 %0, %1, -%2, %2" : "=v"(v0) : "v"(v0), "v"(big));
+    asm("v_med3_f32 %0, %1, -%2, %2" : "=v"(v1) : "v"(v1), "v"(big));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(v0), "v"(v1));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v1), "v"(h));
+}
+
 template <int NSPLIT, bool RELU, bool RES, int HEAD>
 __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
@@ -76,6 +117,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
     const size_t yrowb = (size_t)p.N * 4;
     const int nk = (p.debug & 2) ? 0 : p.K / 32;
     const bool loads = !(p.debug & 4);
+    const float lim = 65504.0f / p.descale;  // fp16 range in the accumulator's scale (descale is a power of two)
 
     // ---- LDS-DMA duty: per stage a wave fetches 32 rows of X and 32 rows of W (4 instructions of 8
     // rows each):   group 0: X rows   0..127 (wave j: 32j..) and W rows 128..255
@@ -474,7 +516,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
             for (int pass = 0; pass < 8; ++pass) {
                 const int jt = pass >> 2, it = pass & 3;
                 const size_t line0 = line0_of(pass);
-                half4 rh[4], rl[4];
+                u32x2 rh[4], rl[4];
                 if (RES) {
                     const char* rb = resbuf + (pass & 1) * 4096;
                     if (pass + 1 < 8) fetch_res(pass + 1);  // one pass ahead, ahead of this pass's stores
@@ -490,28 +532,27 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        rh[g] = *(const half4*)(rb + scr_row + ((g ^ (eml & 7)) * 16));
-                        rl[g] = *(const half4*)(rb + scr_row + (((g + 4) ^ (eml & 7)) * 16));
+                        rh[g] = *(const u32x2*)(rb + scr_row + ((g ^ (eml & 7)) * 16));
+                        rl[g] = *(const u32x2*)(rb + scr_row + (((g + 4) ^ (eml & 7)) * 16));
                     }
                 }
-                half4 oh[4], ol[4];
+                u32x2 oh[4], ol[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[it][jt][g * 4 + e] * p.descale;
-                        if (RELU) v = __builtin_fmaxf(v, 0.0f);
-                        if (RES) v += (float)rh[g][e] + (float)rl[g][e];
-                        _Float16 a, b;
-                        split_f16(v, a, b);
-                        oh[g][e] = a;
-                        ol[g][e] = b;
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const float a0 = acc[it][jt][g * 4 + 2 * e2], a1 = acc[it][jt][g * 4 + 2 * e2 + 1];
+                        unsigned hh, ll;
+                        if (RES) split2_res<RELU>(a0, a1, p.descale, rh[g][e2], rl[g][e2], hh, ll);
+                        else split2_scaled<RELU>(a0, a1, p.descale, lim, hh, ll);
+                        oh[g][e2] = hh;
+                        ol[g][e2] = ll;
                     }
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    *(half4*)(scr + scr_row + ((g ^ (eml & 7)) * 16)) = oh[g];
-                    *(half4*)(scr + scr_row + (((g + 4) ^ (eml & 7)) * 16)) = ol[g];
+                    *(u32x2*)(scr + scr_row + ((g ^ (eml & 7)) * 16)) = oh[g];
+                    *(u32x2*)(scr + scr_row + (((g + 4) ^ (eml & 7)) * 16)) = ol[g];
                 }
                 __builtin_amdgcn_wave_barrier();
                 f32x4 d[4];

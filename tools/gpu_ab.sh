@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 L=monoloco_amd/lib
 cp $L/libmonoloco_hip.so $L/A.keep
 for rep in 1 2; do
-  for v in A B C; do
+  for v in A B; do
     if [ $v = A ]; then cp $L/A.keep $L/libmonoloco_hip.so; else cp $L/libmonoloco_hip_$v.so $L/libmonoloco_hip.so; fi
     python bench.py --steps 30 --cpu-seconds 0 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], d['roofline']['per_layer_avg_ms'])"
   done
