@@ -49,7 +49,7 @@ constexpr int PP_LDS = DENSE_LDS + 8 * 4096;  // 160 KiB: 2 stages + 8 x 4 KiB e
 
 // debug bits (DenseParams::debug, env ML_DENSE_DEBUG; 0 in production):
 //   1 skip the epilogue (accumulators kept live)     2 skip the main loop      4 no stage DMA
-//   64 half the stage DMA (timing only)
+//   64 half the stage DMA (timing only)          16 residual always from the first row panel (timing only)
 __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
         // stage 0 of this tile was requested before the previous tile's epilogue stores (32 per wave);
         // vmcnt retires in order, so "at most 32 outstanding" means that DMA has landed.
         // (HEAD epilogues issue 2*ceil(HEAD/4) partial-sum stores instead)
-        constexpr int EPI_VMEM = HEAD > 0 ? 2 * ((HEAD + 3) / 4) : 32;
+        // (residual epilogues issue 7 x 4 residual DMA instructions behind it as well; vmcnt goes up to 63)
+        constexpr int EPI_VMEM = HEAD > 0 ? 2 * ((HEAD + 3) / 4) : (RES ? 60 : 32);
         if (first) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
@@ -420,7 +421,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
         const int scr_row = eml * LINE + eh * 8;                       // + ((chunk ^ (eml&7)) * 16)
         const int rd_off = (elane >> 3) * LINE + (((elane & 7) ^ ((elane >> 3) & 7)) * 16);  // + qq*1024
         auto fetch_res = [&](int pass) {
-            const char* src = p.res + line0_of(pass);
+            // debug bit 16 (timing only): every tile reads the residual of the first row panel -> L2 resident
+            const char* src = p.res + ((p.debug & 16) ? (line0_of(pass) % ((size_t)BM * yrowb)) : line0_of(pass));
             char* dst = resbuf + (pass & 1) * 4096;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) glds16(src + (size_t)(qq * 8) * yrowb + res_goff, dst + qq * 1024);
