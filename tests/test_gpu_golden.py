@@ -391,3 +391,25 @@ def test_dataset_prep_rows_one_launch(hip_lib, cuda_device, gold):
     assert xs.shape == (556, 68) and xs.is_cuda
     assert torch.equal(xs.cpu(), torch.tensor(gold['stereo_x_fixture']))
     assert preprocess_monoloco_rows(torch.zeros((0, 3, 17)), [synth.KITTI_K], np.zeros(0, dtype=np.int64)).shape == (0, 34)
+
+
+def test_million_rows_addressing(hip_lib, cuda_device):
+    """BASELINE config 4 in one piece (1,048,576 persons, 4.3 GB per activation buffer): every byte offset beyond
+    2^32 must be computed in 64 bits.  Rows are independent, so slices taken at the far end of the batch must be
+    bit-identical to the same rows run as a separate (tile-kernel) batch."""
+    from monoloco_amd import engine
+    m = 1 << 20
+    eng = engine.LocoEngine({k: torch.tensor(v) for k, v in synth.make_state_dict(1).items()}, device=cuda_device)
+    kinv = engine.inverse_intrinsics(synth.KITTI_K)
+    base = torch.tensor(synth.make_keypoints(65536, seed=21)).to(cuda_device)
+    kps = base.repeat(16, 1, 1)
+    kps += (torch.arange(m, device=cuda_device).view(-1, 1, 1) % 97).float() * 0.01   # every row distinct
+    out, xyzds, raw = eng.forward_mono(kps, kinv, want_raw=True)
+    assert torch.isfinite(raw).all()
+    for lo in (0, m // 2 + 12345, m - 3000):
+        sub = slice(lo, lo + 2999)
+        _, xyzds_s, raw_s = eng.forward_mono(kps[sub].contiguous(), kinv, want_raw=True)
+        assert torch.equal(raw_s, raw[sub]) and torch.equal(xyzds_s, xyzds[sub]), lo
+    eng.close()
+    del out, xyzds, raw, kps
+    torch.cuda.empty_cache()
