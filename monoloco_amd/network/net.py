@@ -186,9 +186,8 @@ class Loco:
 
     @staticmethod
     def social_distance(dic_out, args):
-        """Delegates to the reference's rule engine (monoloco/activity.py:17-67) when the reference
-        package is importable; that O(n^2) host logic is out of this path's scope."""
-        from monoloco.activity import social_interactions  # pylint: disable=import-error
+        """Per person: does it violate social distancing / stand in an F-formation (reference net.py:250-264)."""
+        from ..activity import social_interactions
         xz = [[xx[0], xx[2]] for xx in dic_out['xyz_pred']]
         dic_out['social_distance'] = [bool(social_interactions(idx, xz, dic_out['angles'], dic_out['dds_pred'],
                                                                stds=dic_out['stds_ale'],
@@ -199,6 +198,7 @@ class Loco:
 
     @staticmethod
     def raising_hand(dic_out, keypoints):
-        from monoloco.activity import is_raising_hand  # pylint: disable=import-error
+        """Per person 'left' / 'right' / 'both' / None (reference net.py:267-270)."""
+        from ..activity import is_raising_hand
         dic_out['raising_hand'] = [is_raising_hand(keypoint) for keypoint in keypoints]
         return dic_out

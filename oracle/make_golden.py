@@ -448,3 +448,63 @@ def golden_mono_p():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'mono_p':
     golden_mono_p()
+
+
+def golden_activity():
+    """Activity rules of monoloco/activity.py through the reference's own functions on seeded random scenes."""
+    import monoloco.network  # noqa: F401  (resolves the reference's circular import)
+    from monoloco.activity import check_f_formations, is_raising_hand, social_interactions
+    rng = np.random.default_rng(17)
+    gold = {'raising': [], 'fform': [], 'social_det': [], 'social_prob': []}
+    for _ in range(400):
+        xs = rng.uniform(0, 100, 17)
+        ys = rng.uniform(0, 100, 17)
+        if rng.random() < 0.6:    # plausible upper body so that all four answers occur
+            sx = 50 + rng.uniform(-5, 5)
+            xs[[5, 6]] = [sx + 12, sx - 12]
+            ys[[5, 6]] = 40
+            xs[[3, 4]] = [sx + 5, sx - 5]
+            ys[0] = 25
+            for hand, elbow, sh in ((9, 7, 5), (10, 8, 6)):
+                xs[elbow] = xs[sh] + rng.uniform(-12, 12)
+                ys[elbow] = ys[sh] + rng.uniform(-15, 20)
+                xs[hand] = xs[elbow] + rng.uniform(-20, 20)
+                ys[hand] = ys[elbow] + rng.uniform(-30, 20)
+        kp = [xs.tolist(), ys.tolist(), rng.uniform(0, 1, 17).tolist()]
+        gold['raising'].append({'kp': kp, 'out': is_raising_hand(kp)})
+    for _ in range(400):
+        n = int(rng.integers(2, 7))
+        centers = (rng.uniform(-2, 2, (n, 2)) + [0, 6]).tolist()
+        angles = rng.uniform(-math.pi, math.pi, n).tolist()
+        radii = (0.3, 0.5, 1) if rng.random() < 0.5 else (0.3, 0.5)
+        sd = bool(rng.random() < 0.5)
+        i, j = rng.choice(n, 2, replace=False)
+        gold['fform'].append({'centers': centers, 'angles': angles, 'radii': list(radii), 'sd': sd, 'i': int(i), 'j': int(j),
+                              'out': bool(check_f_formations(int(i), int(j), centers, angles, radii, social_distance=sd))})
+    for _ in range(150):
+        n = int(rng.integers(1, 8))
+        centers = (rng.uniform(-2.5, 2.5, (n, 2)) + [0, 7]).tolist()
+        angles = rng.uniform(-math.pi, math.pi, n).tolist()
+        dds = [math.hypot(c[0], c[1]) for c in centers]
+        out = [bool(social_interactions(i, centers, angles, dds, stds=[0.1] * n, n_samples=1, threshold_dist=2.5,
+                                        radii=(0.3, 0.5, 1))) for i in range(n)]
+        gold['social_det'].append({'centers': centers, 'angles': angles, 'dds': dds, 'out': out})
+    # probabilistic branch: two persons facing each other at 1 m (flag robustly on) and back to back (robustly off)
+    for facing in (True, False):
+        centers = [[-0.5, 6.0], [0.5, 6.0], [3.0, 12.0]]
+        angles = ([0.0, math.pi, 1.0] if facing else [math.pi, 0.0, 1.0])
+        dds = [math.hypot(c[0], c[1]) for c in centers]
+        stds = [0.05, 0.05, 0.05]
+        out = [bool(social_interactions(i, centers, angles, dds, stds=stds, n_samples=100, threshold_prob=0.25,
+                                        threshold_dist=2.5, radii=(0.3, 0.5, 1))) for i in range(3)]
+        gold['social_prob'].append({'centers': centers, 'angles': angles, 'dds': dds, 'stds': stds, 'out': out})
+    with open(os.path.join(OUT, 'golden_activity.json'), 'w') as f:
+        json.dump(gold, f)
+    from collections import Counter
+    print('raising', Counter(str(g['out']) for g in gold['raising']), 'fform', Counter(g['out'] for g in gold['fform']),
+          'social', Counter(v for g in gold['social_det'] for v in g['out']), [g['out'] for g in gold['social_prob']])
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'activity':
+    import math
+    golden_activity()
