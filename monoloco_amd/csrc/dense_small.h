@@ -123,4 +123,122 @@ __global__ __launch_bounds__(SMALL_THREADS) void dense_small_kernel(DenseParams 
     *(half4*)(p.y + yoff + 64) = ol;
 }
 
+// dense_small32_kernel -- the same idea with 32 (n) x 32 (m) output tiles and v_mfma_f32_32x32x16_f16, for a few
+// hundred to ~2000 rows: a 16x16 tile re-reads 8 KiB of operands per output value from L2, a 32x32 tile half of
+// that, and above ~256 rows there are enough 32x32 tiles ((N/32) * ceil(rows/32) >= 256) to fill the chip.
+//   operand fetch per k32 line: lane (r = lane&31, q = lane>>5) loads, for both k16 half-steps s, 16 B = k 8q..8q+7
+//   of the half-step: chunk 2s+q (hi) and 4+2s+q (lo) -- the A/B register layout of the 32x32x16 MFMA.
+//   D: person = lane&31, n = 8g + 4q + e (g = reg>>2, e = reg&3): 4 x 8-byte stores per half (hi / lo) of the line
+template <int NSPLIT, bool RELU, bool RES>
+__global__ __launch_bounds__(SMALL_THREADS) void dense_small32_kernel(DenseParams p) {
+    __shared__ __attribute__((aligned(16))) float red[3][16][64];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 32;
+    const int m0 = blockIdx.y * 32;
+    const int r = lane & 31, q = lane >> 5;
+    const size_t rowb = (size_t)p.K * 4;
+    const int nl = p.K / 32;
+
+    const char* wp = p.w + (size_t)(n0 + r) * rowb + q * 16;
+    const char* xp = p.x + (size_t)(m0 + r) * rowb + q * 16;
+
+    f32x16 acc;
+    if (w == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *(const f32x4*)(p.bias_scaled + n0 + 8 * g + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[g * 4 + e] = b4[e];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    }
+
+    struct Frag {
+        half8 whi[2], wlo[2], xhi[2], xlo[2];
+    };
+    Frag fa[2], fb[2];  // groups of 2 lines (16 independent loads in flight), two alternating register sets
+    auto fetch2 = [&](Frag(&f)[2], int g) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int l = w + 4 * (2 * g + j);
+            if (l < nl) {
+                const size_t o = (size_t)l * LINE;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f[j].whi[s] = *(const half8*)(wp + o + s * 32);
+                    f[j].xhi[s] = *(const half8*)(xp + o + s * 32);
+                    if (NSPLIT == 3) {
+                        f[j].wlo[s] = *(const half8*)(wp + o + 64 + s * 32);
+                        f[j].xlo[s] = *(const half8*)(xp + o + 64 + s * 32);
+                    }
+                }
+            }
+        }
+    };
+    auto compute2 = [&](Frag(&f)[2], int g) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int l = w + 4 * (2 * g + j);
+            if (l < nl) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (NSPLIT == 3) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[j].whi[s], f[j].xlo[s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[j].wlo[s], f[j].xhi[s], acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[j].whi[s], f[j].xhi[s], acc, 0, 0, 0);
+                }
+            }
+        }
+    };
+    const int nw = nl > w ? (nl - w + 3) / 4 : 0;  // lines of this wave
+    const int ng = (nw + 1) / 2;
+    if (ng > 0) fetch2(fa, 0);
+    for (int g = 0; g < ng; g += 2) {
+        if (g + 1 < ng) fetch2(fb, g + 1);
+        compute2(fa, g);
+        if (g + 2 < ng) fetch2(fa, g + 2);
+        if (g + 1 < ng) compute2(fb, g + 1);
+    }
+
+    if (w > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[w - 1][e][lane] = acc[e];
+    }
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += red[ww][e][lane];
+
+    const size_t ybase = (size_t)(m0 + r) * ((size_t)p.N * 4) + (size_t)(n0 >> 5) * LINE + (size_t)(4 * q) * 2;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const size_t yoff = ybase + (size_t)(8 * g) * 2;
+        half4 rh, rl;
+        if (RES) {
+            rh = *(const half4*)(p.res + yoff);
+            rl = *(const half4*)(p.res + yoff + 64);
+        }
+        half4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[g * 4 + e] * p.descale;
+            if (RELU) v = __builtin_fmaxf(v, 0.0f);
+            if (RES) v += (float)rh[e] + (float)rl[e];
+            _Float16 a, b;
+            split_f16(v, a, b);
+            oh[e] = a;
+            ol[e] = b;
+        }
+        *(half4*)(p.y + yoff) = oh;
+        *(half4*)(p.y + yoff + 64) = ol;
+    }
+}
+
 }  // namespace mlk

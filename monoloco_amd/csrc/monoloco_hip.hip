@@ -400,7 +400,13 @@ int small_rows_env() {
     // rows <= ML_SMALL_ROWS take dense_small_kernel (16x16 output tiles, no LDS staging) instead of the
     // 256x256-tile persistent kernel; 0 disables the small path
     const char* e = getenv("ML_SMALL_ROWS");  // read per call (cheap) so that tests can switch paths in-process
-    const int v = e ? atoi(e) : 1024;
+    const int v = e ? atoi(e) : 2048;
+    return v < 0 ? 0 : v;
+}
+
+int small32_rows_env() {
+    const char* e = getenv("ML_SMALL32_ROWS");  // above this row count the small path uses 32x32 tiles
+    const int v = e ? atoi(e) : 128;
     return v < 0 ? 0 : v;
 }
 
@@ -412,10 +418,17 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, in
     p.trace = nullptr;
 
     if (rows >= 0 && head_nh == 0) {  // the caller chose the small-row path
-        const dim3 grid((unsigned)(p.N / 16), (unsigned)((rows + 15) / 16));
+        // 16x16 tiles while they are few (latency: more workgroups), 32x32 tiles (half the L2 traffic) once there
+        // are at least ~256 of those
+        const bool t32 = rows > small32_rows_env();
+        const int T = t32 ? 32 : 16;
+        const dim3 grid((unsigned)(p.N / T), (unsigned)((rows + T - 1) / T));
         if (grid.y == 0) return ML_OK;
-#define ML_SM(NS, RL, RS) \
-    hipLaunchKernelGGL((mlk::dense_small_kernel<NS, RL, RS>), grid, dim3(mlk::SMALL_THREADS), 0, st, p)
+#define ML_SM(NS, RL, RS)                                                                                              \
+    do {                                                                                                               \
+        if (t32) hipLaunchKernelGGL((mlk::dense_small32_kernel<NS, RL, RS>), grid, dim3(mlk::SMALL_THREADS), 0, st, p); \
+        else hipLaunchKernelGGL((mlk::dense_small_kernel<NS, RL, RS>), grid, dim3(mlk::SMALL_THREADS), 0, st, p);      \
+    } while (0)
 #define ML_SM_NS(NS)                                  \
     do {                                              \
         if (p.relu) {                                 \

@@ -199,10 +199,11 @@ def test_empty_and_errors(hip_lib, cuda_device):
 
 
 @pytest.mark.parametrize("mode", ["mono", "stereo"])
-@pytest.mark.parametrize("m", [1, 16, 17, 100, 1000])
+@pytest.mark.parametrize("m", [1, 16, 17, 100, 129, 300, 1000, 2048])
 def test_small_row_path_matches_tile_path(hip_lib, cuda_device, monkeypatch, m, mode):
-    """rows <= ML_SMALL_ROWS run dense_small_kernel (16x16 tiles, K split over 4 waves), larger batches the
-    256x256-tile persistent kernel: same operands and epilogue, only the fp32 accumulation order differs.
+    """rows <= ML_SMALL_ROWS run dense_small_kernel (16x16 tiles up to 128 rows, 32x32 tiles above; K split over 4
+    waves), larger batches the 256x256-tile persistent kernel: same operands and epilogue, only the fp32
+    accumulation order differs.
     Both must agree with each other far below the parity bar and each must meet the bar against fp64."""
     from monoloco_amd import engine
     in_f, out_f = (34, 9) if mode == "mono" else (68, 10)
@@ -212,7 +213,7 @@ def test_small_row_path_matches_tile_path(hip_lib, cuda_device, monkeypatch, m, 
     eng = engine.LocoEngine(_sd_t(sd), device=cuda_device)
     monkeypatch.setenv("ML_SMALL_ROWS", "0")
     raw_tile = eng.forward_raw(x).cpu()
-    monkeypatch.setenv("ML_SMALL_ROWS", "1024")
+    monkeypatch.setenv("ML_SMALL_ROWS", "2048")
     raw_small = eng.forward_raw(x).cpu()
     ref64 = O.loco_forward(_sd_t(sd), x.cpu(), dtype=torch.float64)
     scale = ref64.abs().max().item()
