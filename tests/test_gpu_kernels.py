@@ -238,3 +238,23 @@ def test_row_chunking_is_bit_identical(hip_lib, cuda_device, monkeypatch):
     assert torch.equal(raw0, raw1) and torch.equal(xyzds0, xyzds1)
     assert torch.equal(out0.nan_to_num(), out1.nan_to_num())
     eng.close()
+
+
+@pytest.mark.parametrize("m", [16, 300])
+def test_small_row_path_single_fp16_mode(hip_lib, cuda_device, monkeypatch, m):
+    """ML_PREC_F16 (one MFMA per product, the comparison mode) through both small-row kernels: same single-product
+    arithmetic as the tile kernel, so the two paths stay close to each other although both are ~1e-2 off fp64."""
+    from monoloco_amd import engine
+    sd = synth.make_state_dict(8)
+    rng = np.random.default_rng(m)
+    x = torch.tensor((rng.standard_normal((m, 34)) * 3).astype(np.float32), device=cuda_device)
+    eng = engine.LocoEngine(_sd_t(sd), device=cuda_device, precision='f16')
+    monkeypatch.setenv("ML_SMALL_ROWS", "0")
+    raw_tile = eng.forward_raw(x).cpu()
+    monkeypatch.setenv("ML_SMALL_ROWS", "2048")
+    raw_small = eng.forward_raw(x).cpu()
+    ref64 = O.loco_forward(_sd_t(sd), x.cpu(), dtype=torch.float64)
+    scale = max(1.0, ref64.abs().max().item())
+    assert (raw_small.double() - ref64).abs().max().item() <= 5e-2 * scale
+    assert (raw_small - raw_tile).abs().max().item() <= 2e-3 * scale
+    eng.close()
