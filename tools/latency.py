@@ -12,7 +12,7 @@ for m in [int(a) for a in (sys.argv[1:] or ['1', '16', '64', '256', '512', '1024
     kps = torch.tensor(synth.make_keypoints(m, seed=1)).to(dev)
     conf = torch.rand(m, device=dev)
     out = torch.empty((m, 16), device=dev); xyzds = torch.empty((m, 5), device=dev)
-    for _ in range(20):
+    for _ in range(300):  # long enough for the clocks to settle at this load
         eng.forward_mono(kps, kinv, box_conf=conf, out=out, xyzds=xyzds)
     torch.cuda.synchronize()
     n = 200
