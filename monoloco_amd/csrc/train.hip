@@ -146,8 +146,8 @@ unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 // column sums (fp64) of z (m x n) and of z*w2 (or z*z) into t->d_red[0..n) and [n..2n)
 int col_stats(ml_trainer* t, hipStream_t st, const float* z, const float* w2, int64_t m, int n) {
     T_TRY(hipMemsetAsync(t->d_red, 0, (size_t)2 * n * sizeof(double), st));
-    int gy = (int)((m + 255) / 256);
-    if (gy > 64) gy = 64;
+    int gy = (int)((m + 255) / 256);  // 16 rows per workgroup pass; enough workgroups to fill the chip, few atomics
+    if (gy > 128) gy = 128;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(mlt::col_stats_kernel, dim3((n + 63) / 64, gy), dim3(256), 0, st, z, w2, m, n, t->d_red, t->d_red + n);
     return 0;

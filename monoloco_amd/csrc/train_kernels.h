@@ -177,24 +177,48 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
                                                         int64_t m, int n, double* __restrict__ s1,
                                                         double* __restrict__ s2) {
     // s1[j] = sum_i z[i][j]; s2[j] = sum_i z[i][j] * (w2 ? w2[i][j] : z[i][j])
-    __shared__ double r1[4][64], r2[4][64];
-    const int cj = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + cj;
-    double a = 0.0, b = 0.0;
-    if (j < n)
-        for (int64_t i = blockIdx.y * 4 + rg; i < m; i += (int64_t)gridDim.y * 4) {
-            const double v = (double)z[i * n + j];
-            a += v;
-            b += v * (w2 ? (double)w2[i * n + j] : v);
+    // thread = (column group of 4 via one 16-byte load, row group): 16 x 16 per workgroup, 64 columns per workgroup
+    __shared__ double r1[16][64], r2[16][64];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j0 = blockIdx.x * 64 + cg * 4;
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t step = (int64_t)gridDim.y * 16;
+    if ((n & 3) == 0 && j0 + 3 < n) {
+        for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += step) {
+            const f32x4 v = *(const f32x4*)(z + i * n + j0);
+            const f32x4 u = w2 ? *(const f32x4*)(w2 + i * n + j0) : v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] += (double)v[e];
+                b[e] += (double)v[e] * (double)u[e];
+            }
         }
-    r1[rg][cj] = a;
-    r2[rg][cj] = b;
+    } else {
+        for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += step)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (j0 + e < n) {
+                    const double v = (double)z[i * n + j0 + e];
+                    a[e] += v;
+                    b[e] += v * (w2 ? (double)w2[i * n + j0 + e] : v);
+                }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r1[rg][cg * 4 + e] = a[e];
+        r2[rg][cg * 4 + e] = b[e];
+    }
     __syncthreads();
-    if (rg == 0 && j < n) {
-        a = r1[0][cj] + r1[1][cj] + r1[2][cj] + r1[3][cj];
-        b = r2[0][cj] + r2[1][cj] + r2[2][cj] + r2[3][cj];
-        atomicAdd(&s1[j], a);
-        atomicAdd(&s2[j], b);
+    const int cj = threadIdx.x;
+    if (cj < 64 && blockIdx.x * 64 + cj < n) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            sa += r1[g][cj];
+            sb += r2[g][cj];
+        }
+        atomicAdd(&s1[blockIdx.x * 64 + cj], sa);
+        atomicAdd(&s2[blockIdx.x * 64 + cj], sb);
     }
 }
 
