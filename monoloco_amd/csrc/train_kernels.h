@@ -37,14 +37,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct TileRegs {
     f32x4 v[2];
 };
-__device__ __forceinline__ TileRegs load_tile_fast(const float* base, long s_mn, long s_k, int mn0, int k0, int tid) {
+// (mn_last: the k-contiguous layout may run over the edge of the matrix in mn -- the row index is clamped, the
+// surplus rows are computed and never stored)
+__device__ __forceinline__ TileRegs load_tile_fast(const float* base, long s_mn, long s_k, int mn0, int k0, int tid,
+                                                   int mn_last) {
     TileRegs r;
     if (s_mn == 1) {  // mn contiguous: thread -> (k = tid/16, mn = 8*(tid%16) .. +7)
         const float* p = base + (long)(k0 + (tid >> 4)) * s_k + mn0 + (tid & 15) * 8;
         r.v[0] = *(const f32x4*)p;
         r.v[1] = *(const f32x4*)(p + 4);
     } else {          // k contiguous: thread -> (mn = tid/2, k = 8*(tid%2) .. +7)
-        const float* p = base + (long)(mn0 + (tid >> 1)) * s_mn + k0 + (tid & 1) * 8;
+        const int mn = mn0 + (tid >> 1);
+        const float* p = base + (long)(mn < mn_last ? mn : mn_last) * s_mn + k0 + (tid & 1) * 8;
         r.v[0] = *(const f32x4*)p;
         r.v[1] = *(const f32x4*)(p + 4);
     }
@@ -81,10 +85,12 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     const bool a_mn = (p.sai == 1), b_mn = (p.sbj == 1);
-    // fast path: whole tile in range, one unit stride per operand, 16-byte aligned rows
-    const bool fast = (i0 + GBM <= p.M) && (j0 + GBN <= p.N) && ((kend - kbeg) % GBK == 0) && (p.sai == 1 || p.sak == 1) &&
+    // fast path: one unit stride per operand, 16-byte aligned rows; an operand whose CONTIGUOUS dimension is mn
+    // must have its tile fully inside the matrix, a k-contiguous one may hang over the edge (rows clamped).
+    // Whole 16-wide k tiles go through the fast loads, a ragged k tail through the guarded element loads.
+    const bool fast = (a_mn ? (i0 + GBM <= p.M) : true) && (b_mn ? (j0 + GBN <= p.N) : true) && (p.sai == 1 || p.sak == 1) &&
                       (p.sbj == 1 || p.sbk == 1) && (((a_mn ? p.sak : p.sai) & 3) == 0) && (((b_mn ? p.sbk : p.sbj) & 3) == 0) &&
-                      ((((size_t)p.a) & 15) == 0) && ((((size_t)p.b) & 15) == 0);
+                      ((((size_t)p.a) & 15) == 0) && ((((size_t)p.b) & 15) == 0) && ((kbeg & 3) == 0);
     auto mma = [&]() {
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 2) {
@@ -101,36 +107,40 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmParams p) {
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
         }
     };
+    int k_done = kbeg;
     if (fast) {
-        TileRegs ra = load_tile_fast(p.a, p.sai, p.sak, i0, kbeg, tid);
-        TileRegs rb = load_tile_fast(p.b, p.sbj, p.sbk, j0, kbeg, tid);
-        for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-            store_tile_fast(As, ra, a_mn, tid);
-            store_tile_fast(Bs, rb, b_mn, tid);
-            __syncthreads();
-            if (k0 + GBK < kend) {  // prefetch the next k tile while this one is multiplied
-                ra = load_tile_fast(p.a, p.sai, p.sak, i0, k0 + GBK, tid);
-                rb = load_tile_fast(p.b, p.sbj, p.sbk, j0, k0 + GBK, tid);
+        const int kfull = kbeg + (kend - kbeg) / GBK * GBK;
+        if (kfull > kbeg) {
+            TileRegs ra = load_tile_fast(p.a, p.sai, p.sak, i0, kbeg, tid, p.M - 1);
+            TileRegs rb = load_tile_fast(p.b, p.sbj, p.sbk, j0, kbeg, tid, p.N - 1);
+            for (int k0 = kbeg; k0 < kfull; k0 += GBK) {
+                store_tile_fast(As, ra, a_mn, tid);
+                store_tile_fast(Bs, rb, b_mn, tid);
+                __syncthreads();
+                if (k0 + GBK < kfull) {  // prefetch the next k tile while this one is multiplied
+                    ra = load_tile_fast(p.a, p.sai, p.sak, i0, k0 + GBK, tid, p.M - 1);
+                    rb = load_tile_fast(p.b, p.sbj, p.sbk, j0, k0 + GBK, tid, p.N - 1);
+                }
+                mma();
+                __syncthreads();
             }
-            mma();
-            __syncthreads();
         }
-    } else {
-        for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        k_done = kfull;
+    }
+    for (int k0 = k_done; k0 < kend; k0 += GBK) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                int ia, ka, jb, kb;
-                const int id = e * 256 + tid;
-                if (a_mn) { ia = id & 127; ka = id >> 7; } else { ka = id & 15; ia = id >> 4; }
-                if (b_mn) { jb = id & 127; kb = id >> 7; } else { kb = id & 15; jb = id >> 4; }
-                const int gi = i0 + ia, gka = k0 + ka, gj = j0 + jb, gkb = k0 + kb;
-                As[ka * GLD + ia] = (gi < p.M && gka < kend) ? p.a[(long)gi * p.sai + (long)gka * p.sak] : 0.f;
-                Bs[kb * GLD + jb] = (gj < p.N && gkb < kend) ? p.b[(long)gkb * p.sbk + (long)gj * p.sbj] : 0.f;
-            }
-            __syncthreads();
-            mma();
-            __syncthreads();
+        for (int e = 0; e < 8; ++e) {
+            int ia, ka, jb, kb;
+            const int id = e * 256 + tid;
+            if (a_mn) { ia = id & 127; ka = id >> 7; } else { ka = id & 15; ia = id >> 4; }
+            if (b_mn) { jb = id & 127; kb = id >> 7; } else { kb = id & 15; jb = id >> 4; }
+            const int gi = i0 + ia, gka = k0 + ka, gj = j0 + jb, gkb = k0 + kb;
+            As[ka * GLD + ia] = (gi < p.M && gka < kend) ? p.a[(long)gi * p.sai + (long)gka * p.sak] : 0.f;
+            Bs[kb * GLD + jb] = (gj < p.N && gkb < kend) ? p.b[(long)gkb * p.sbk + (long)gj * p.sbj] : 0.f;
         }
+        __syncthreads();
+        mma();
+        __syncthreads();
     }
     const bool split = gridDim.z > 1;
     float* cbase = p.c + (split ? (size_t)blockIdx.z * p.M * p.ldc : 0);
