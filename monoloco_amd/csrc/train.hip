@@ -44,6 +44,8 @@ struct Slot {
 
 extern "C" const char* ml_train_last_error(void) { return t_err; }
 
+constexpr int RED_SLOTS = 64;  // fp64 reduction slots per step (25 BatchNorm statistics + a few bias sums)
+
 struct ml_trainer {
     int in_f, H, C, S;
     float p_drop, lr0, gamma;
@@ -58,7 +60,9 @@ struct ml_trainer {
     std::vector<float*> bufs;  // all (cap x H) fp32 buffers
     float *d_out = nullptr, *d_dout = nullptr, *d_y2aux = nullptr;
     float *bn_mean = nullptr, *bn_invstd = nullptr;  // (nbn x H)
-    double* d_red = nullptr;                          // scratch for fp64 reductions (2*H + 16)
+    double* d_red = nullptr;                          // current slot of the fp64 reduction scratch (2*H + 32 doubles)
+    double* d_red_base = nullptr;                     // RED_SLOTS slots, zeroed once per step (one memset instead of ~27)
+    int red_slot = 0;
     float* d_splitk = nullptr;                        // split-K partials of the weight-gradient GEMMs
     size_t splitk_cap = 0;                            // floats
     int nbn = 0;
@@ -145,7 +149,12 @@ unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 // column sums (fp64) of z (m x n) and of z*w2 (or z*z) into t->d_red[0..n) and [n..2n)
 int col_stats(ml_trainer* t, hipStream_t st, const float* z, const float* w2, int64_t m, int n) {
-    T_TRY(hipMemsetAsync(t->d_red, 0, (size_t)2 * n * sizeof(double), st));
+    // every reduction of a step gets a fresh, pre-zeroed slot (ml_trainer_step zeroes them all with one memset)
+    if (t->red_slot + 1 < RED_SLOTS) {
+        t->d_red = t->d_red_base + (size_t)(++t->red_slot) * (2 * t->H + 32);
+    } else {
+        T_TRY(hipMemsetAsync(t->d_red, 0, (size_t)(2 * t->H + 32) * sizeof(double), st));
+    }
     int gy = (int)((m + 255) / 256);  // 16 rows per workgroup pass; enough workgroups to fill the chip, few atomics
     if (gy > 128) gy = 128;
     if (gy < 1) gy = 1;
@@ -255,7 +264,8 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
     T_TRY(hipMalloc((void**)&t->stat, (size_t)t->n_stat * 4));
     T_TRY(hipMalloc((void**)&t->bn_mean, (size_t)t->nbn * hidden * 4));
     T_TRY(hipMalloc((void**)&t->bn_invstd, (size_t)t->nbn * hidden * 4));
-    T_TRY(hipMalloc((void**)&t->d_red, (size_t)(2 * hidden + 32) * sizeof(double)));
+    T_TRY(hipMalloc((void**)&t->d_red_base, (size_t)RED_SLOTS * (2 * hidden + 32) * sizeof(double)));
+    t->d_red = t->d_red_base;
     t->splitk_cap = (size_t)32 * hidden * (hidden > in_features ? hidden : in_features);
     T_TRY(hipMalloc((void**)&t->d_splitk, t->splitk_cap * 4));
     T_TRY(hipMemset(t->w, 0, (size_t)t->n_param * 4));
@@ -271,7 +281,7 @@ int ml_trainer_destroy(ml_trainer* t) {
     if (!t) return ML_OK;
     (void)hipDeviceSynchronize();
     for (float* p : t->bufs) (void)hipFree(p);
-    void* ptrs[] = {t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red, t->d_splitk};
+    void* ptrs[] = {t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -313,6 +323,9 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int H = t->H, S = t->S, C = t->C;
+    T_TRY(hipMemsetAsync(t->d_red_base, 0, (size_t)RED_SLOTS * (2 * H + 32) * sizeof(double), st));
+    t->red_slot = 0;
+    t->d_red = t->d_red_base;
     // buffer plan
     int bi = 0;
     auto nb = [&]() { return t->bufs[bi++]; };
@@ -350,8 +363,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
     if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
     // ---------------- loss and its gradient
-    double* d_loss = t->d_red + 2 * H;
-    T_TRY(hipMemsetAsync(d_loss, 0, 16 * sizeof(double), st));
+    double* d_loss = t->d_red + 2 * H;  // the tail of the current (pre-zeroed) slot
     T_TRY(hipMemsetAsync(t->d_dout, 0, (size_t)m * C * 4, st));
     hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
                        t->d_dout, d_loss);
@@ -388,8 +400,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     if ((rc = block_bwd(t, st, b0, m, gA, xhat))) return rc;
     // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)
     {
-        double* d_ss = t->d_red + 2 * H + 16;
-        T_TRY(hipMemsetAsync(d_ss, 0, sizeof(double), st));
+        double* d_ss = t->d_red + 2 * H + 16;  // pre-zeroed, never shared with d_loss (other offset)
         hipLaunchKernelGGL(mlt::sumsq_kernel, dim3(512), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
         const int64_t k = t->step + 1;
         const float lr = t->lr0 * std::pow(t->gamma, (float)(t->step / t->sched_step));
