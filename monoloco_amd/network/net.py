@@ -119,23 +119,20 @@ class Loco:
         dic_out = defaultdict(list)
         if dic_in is None:
             return dic_out
+        # ground-truth association (reference net.py:170-192): matched detections first (left to right when
+        # `reorder`), then the unmatched ones in input order
+        matches, boxes_gt, dds_gt = [], [], []
         if dic_gt:
             boxes_gt = dic_gt['boxes']
-            dds_gt = [el[3] for el in dic_gt['ys']]
+            dds_gt = [ys[3] for ys in dic_gt['ys']]
             matches = get_iou_matches(boxes, boxes_gt, iou_min=iou_min)
-            dic_out['gt'] = [True]
-            if verbose:
-                print("found {} matches with ground-truth".format(len(matches)))
-            matched = [el[0] for el in matches]
-            not_matches = [idx for idx, _ in enumerate(boxes) if idx not in matched]
-        else:
-            matches = []
-            not_matches = list(range(len(boxes)))
-            if verbose:
-                print("NO ground-truth associated")
+        if verbose:
+            print("found {} matches with ground-truth".format(len(matches)) if dic_gt else "NO ground-truth associated")
+        taken = {pair[0] for pair in matches}
+        not_matches = [idx for idx in range(len(boxes)) if idx not in taken]
         if reorder and matches:
             matches = reorder_matches(matches, boxes, mode='left_right')
-        all_idxs = [idx for idx, _ in matches] + not_matches
+        all_idxs = [pair[0] for pair in matches] + not_matches
         dic_out['gt'] = [True] * len(matches) + [False] * len(not_matches)
 
         # device geometry, whole image at once
@@ -155,27 +152,30 @@ class Loco:
         has_aux = 'aux' in dic_in
         if not has_yaw and all_idxs:
             dic_out['angles']  # the reference touches the key before the KeyError (net.py:231)
-        for idx in all_idxs:
-            box = boxes[idx]
-            bi = float(bi_all[idx])
-            dic_out['boxes'].append(box)
-            dic_out['confs'].append(0.035 * (box[-1]) / (bi / float(dist_all[idx])))
-            dic_out['dds_pred'].append(float(d_all[idx]))
-            dic_out['stds_ale'].append(bi)
-            dic_out['stds_epi'].append(float(dic_in['epi'][idx]))
-            dic_out['xyz_pred'].append(xyz_all[idx].tolist())
-            dic_out['uv_kps'].append(keypoints[idx])
-            dic_out['uv_centers'].append(uv_c[idx].tolist())
-            dic_out['uv_shoulders'].append(uv_s[idx].tolist())
-            dic_out['uv_heads'].append(uv_h[idx].tolist())
-            if not has_yaw:
-                continue
-            dic_out['angles'].append(float(dic_in['yaw'][0][idx]))
-            dic_out['angles_egocentric'].append(float(dic_in['yaw'][1][idx]))
-            if has_aux:
-                dic_out['aux'].append(float(dic_in['aux'][idx]))
-            else:
-                dic_out['aux']  # mono: the key exists and stays empty (reference net.py:237-240)
+        # assemble the output column by column (the reference appends person by person, net.py:206-240); key creation
+        # order is kept because the dictionary is dumped to json as it is
+        if all_idxs:
+            epi = dic_in['epi']
+            columns = [
+                ('boxes', [boxes[i] for i in all_idxs]),
+                ('confs', [0.035 * (boxes[i][-1]) / (float(bi_all[i]) / float(dist_all[i])) for i in all_idxs]),
+                ('dds_pred', [float(d_all[i]) for i in all_idxs]),
+                ('stds_ale', [float(bi_all[i]) for i in all_idxs]),
+                ('stds_epi', [float(epi[i]) for i in all_idxs]),
+                ('xyz_pred', xyz_all[all_idxs].tolist()),
+                ('uv_kps', [keypoints[i] for i in all_idxs]),
+                ('uv_centers', uv_c[all_idxs].tolist()),
+                ('uv_shoulders', uv_s[all_idxs].tolist()),
+                ('uv_heads', uv_h[all_idxs].tolist()),
+            ]
+            if has_yaw:
+                yaw_pred, yaw_ego = dic_in['yaw']
+                columns.append(('angles', [float(yaw_pred[i]) for i in all_idxs]))
+                columns.append(('angles_egocentric', [float(yaw_ego[i]) for i in all_idxs]))
+                # mono: the 'aux' key exists and stays empty (reference net.py:237-240)
+                columns.append(('aux', [float(dic_in['aux'][i]) for i in all_idxs] if has_aux else []))
+            for key, values in columns:
+                dic_out[key] = values
         for idx, idx_gt in matches:
             dd_real = dds_gt[idx_gt]
             xyz_real = xyz_from_distance(float(dd_real), xy_centers[idx])
