@@ -14,15 +14,20 @@ namespace mlk {
 
 // in-place inverted dropout on a line-format activation (m_pad x n): v = keep ? v/(1-p) : 0, one thread
 // per 8 values (a hi chunk and its lo chunk)
+// Several stochastic passes are batched along the rows: network row R = pass * m_per + person; pass k of a call
+// uses seed + k and the person index, so the masks do not depend on how the passes are grouped into launches.
 __global__ __launch_bounds__(256) void dropout_lines_kernel(char* __restrict__ act, int64_t rows, int n, float p,
-                                                           uint32_t seed, uint32_t site) {
+                                                           uint32_t seed0, uint32_t site, int64_t m_per) {
     const int gpr = n / 8;
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= rows * gpr) return;
-    const int64_t row = id / gpr;
-    const int g = (int)(id - row * gpr);
+    const int64_t grow = id / gpr;
+    const int64_t pass = grow / m_per;
+    const int64_t row = grow - pass * m_per;      // person
+    const uint32_t seed = seed0 + (uint32_t)pass;
+    const int g = (int)(id - grow * gpr);
     const int b = g >> 2, sub = g & 3;
-    char* q = act + row * (int64_t)n * 4 + b * LINE + sub * 16;
+    char* q = act + grow * (int64_t)n * 4 + b * LINE + sub * 16;
     half8 hi = *(const half8*)q;
     half8 lo = *(const half8*)(q + 64);
     const float inv = 1.0f / (1.0f - p);
@@ -43,13 +48,18 @@ __global__ __launch_bounds__(256) void dropout_lines_kernel(char* __restrict__ a
 // one pass: per person accumulate sum and sum of squares of  mu + |b| * L_i,  i < n_samples, where L_i are
 // standard Laplace draws that depend on (seed, person, i) only -- identical for every pass, like the
 // reference's re-seeding.  Inverse CDF: L = -sign(u-1/2) * ln(1 - 2|u-1/2|).
+// raw holds n_pass batched passes, row = pass * m + person.  One thread per (pass, person) draws the samples of that
+// pass and leaves (sum, sum of squares) in part[row]; mc_reduce_kernel adds the passes of a person in pass order
+// (deterministic, unlike atomics).
 __global__ __launch_bounds__(256) void mc_accumulate_kernel(const float* __restrict__ raw, int out_f, int col_d, int64_t m,
-                                                           int n_samples, uint32_t seed, double* __restrict__ sum,
-                                                           double* __restrict__ sumsq) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    const float mu = raw[i * out_f + col_d];
-    const float b = fabsf(expf(raw[i * out_f + col_d + 1]) * mu);
+                                                           int n_pass, int n_samples, uint32_t seed,
+                                                           double* __restrict__ part) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= m * n_pass) return;
+    const int64_t i = row % m;
+    const float* r = raw + row * out_f;
+    const float mu = r[col_d];
+    const float b = fabsf(expf(r[col_d + 1]) * mu);
     double s = 0.0, s2 = 0.0;
     for (int k = 0; k < n_samples; ++k) {
         const float u = u01(seed, (uint32_t)i, (uint32_t)k) - 0.5f;
@@ -58,8 +68,30 @@ __global__ __launch_bounds__(256) void mc_accumulate_kernel(const float* __restr
         s += x;
         s2 += x * x;
     }
-    sum[i] += s;
-    sumsq[i] += s2;
+    part[row * 2] = s;
+    part[row * 2 + 1] = s2;
+}
+
+__global__ __launch_bounds__(256) void mc_reduce_kernel(const double* __restrict__ part, int64_t m, int n_pass,
+                                                       double* __restrict__ sum, double* __restrict__ sumsq) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    double s = sum[i], s2 = sumsq[i];
+    for (int ps = 0; ps < n_pass; ++ps) {
+        s += part[((int64_t)ps * m + i) * 2];
+        s2 += part[((int64_t)ps * m + i) * 2 + 1];
+    }
+    sum[i] = s;
+    sumsq[i] = s2;
+}
+
+// copies of the first `bytes` bytes of a buffer behind themselves: buf[c * bytes + o] = buf[o], c = 1 .. copies-1
+__global__ __launch_bounds__(256) void replicate_kernel(char* __restrict__ buf, int64_t bytes, int copies) {
+    const int64_t chunks = bytes / 16;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= chunks * (copies - 1)) return;
+    const int64_t c = id / chunks + 1, o = id - (c - 1) * chunks;
+    *(f32x4*)(buf + c * bytes + o * 16) = *(const f32x4*)(buf + o * 16);
 }
 
 // laplace_sampling (reference process.py:101-122): n_samples draws of Laplace(mu, |b|) per person, laid out

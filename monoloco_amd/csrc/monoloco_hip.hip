@@ -530,12 +530,14 @@ int chunk_rows_env() {
 // MC-dropout: active when mc_p > 0 -- dropout after dense layer 0 and on the input of the w_fin head
 struct McPass {
     float p = 0.f;
-    uint32_t seed = 0;
+    uint32_t seed = 0;   // seed of the first batched pass; pass k uses seed + k
+    int64_t m_per = 0;   // persons per pass (rows = passes * m_per)
 };
 
 int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass mc = McPass()) {
     const int64_t m_pad_all = round_up64(rows, 256);
-    const int64_t chunk = chunk_rows_env() > 0 ? chunk_rows_env() : m_pad_all;
+    // (row chunking is an inference experiment knob; the batched MC-dropout passes index their masks by global row)
+    const int64_t chunk = (chunk_rows_env() > 0 && mc.p <= 0.f) ? chunk_rows_env() : m_pad_all;
     const bool small = use_small_path(rows);  // decided on the whole call, not per chunk
     for (int64_t r0 = 0; r0 < m_pad_all; r0 += chunk) {
         const int64_t m_pad = (m_pad_all - r0 < chunk) ? (m_pad_all - r0) : chunk;
@@ -594,7 +596,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                 if (site) {
                     const int64_t groups = m_pad * (L.n / 8);
                     hipLaunchKernelGGL(mlk::dropout_lines_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
-                                       at(L.dst), m_pad, L.n, mc.p, mc.seed, (uint32_t)li);
+                                       at(L.dst), m_pad, L.n, mc.p, mc.seed, (uint32_t)li, mc.m_per > 0 ? mc.m_per : m_pad_all);
                     HIP_TRY(hipGetLastError());
                 }
             }
@@ -1059,27 +1061,49 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
         return fail(ML_ERR_ARG, "bad argument");
     if ((rc = ensure_rows(h, m))) return rc;
     hipStream_t st = (hipStream_t)stream;
+    // The stochastic passes are independent network rows: batch as many as fit a ~128 k-row launch (a single image
+    // with 50 passes is ONE 800-row forward instead of 50 latency-bound 16-row ones).
+    int64_t per_chunk = 131072 / m;
+    if (per_chunk < 1) per_chunk = 1;
+    if (per_chunk > n_dropout) per_chunk = n_dropout;
+    if ((rc = ensure_rows(h, per_chunk * m))) return rc;
     double* acc = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&acc, (size_t)m * 2 * sizeof(double), st));
+    // acc: running (sum, sum of squares) per person, then per-(pass, person) partials of one chunk
+    HIP_TRY(hipMallocAsync((void**)&acc, (size_t)(m * 2 + per_chunk * m * 2) * sizeof(double), st));
     HIP_TRY(hipMemsetAsync(acc, 0, (size_t)m * 2 * sizeof(double), st));
-    const int64_t m_pad = round_up64(m, 256);
+    double* part = acc + m * 2;
     const mlk::Kinv ki = make_kinv(kinv_host);
     const unsigned grid_m = (unsigned)((m + 255) / 256);
-    for (int pass = 0; pass < n_dropout && !rc; ++pass) {
-        // the stochastic forward consumes the input lines afresh every pass (buffer A is overwritten)
+    const int64_t line_bytes = (int64_t)m * h->k0pad * 4;  // the m input rows in line format
+    for (int pass0 = 0; pass0 < n_dropout && !rc; pass0 += (int)per_chunk) {
+        const int pc = (int)((n_dropout - pass0 < per_chunk) ? (n_dropout - pass0) : per_chunk);
+        const int64_t rows = (int64_t)pc * m;
+        const int64_t rows_pad = round_up64(rows, 256);
+        // the stochastic forward consumes the input lines afresh every time (buffer A is overwritten); rows beyond
+        // the batched passes are zero-filled by the first prep launch only up to round_up(m), so clear the tail
         // legacy 'monoloco' (2 outputs = d, s) is fed zero-centred inputs (net.py:96)
-        hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(m_pad / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
-                           (float*)nullptr, (float*)nullptr, h->buf[0], h->k0pad, m_pad, (h->legacy && h->out_f == 2) ? 1 : 0);
+        hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(round_up64(m, 256) / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
+                           (float*)nullptr, (float*)nullptr, h->buf[0], h->k0pad, round_up64(m, 256),
+                           (h->legacy && h->out_f == 2) ? 1 : 0);
+        if (pc > 1) {
+            const int64_t n16 = line_bytes / 16 * (pc - 1);
+            hipLaunchKernelGGL(mlk::replicate_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, h->buf[0], line_bytes, pc);
+        }
+        if (rows_pad > rows)  // pad rows of the last 256-row panel: finite values so that nothing propagates NaN patterns
+            HIP_TRY(hipMemsetAsync(h->buf[0] + rows * (int64_t)h->k0pad * 4, 0, (size_t)(rows_pad - rows) * h->k0pad * 4, st));
         McPass mc;
         mc.p = p_dropout;
-        mc.seed = seed * 7919u + (uint32_t)pass + 1u;
-        rc = run_network(h, m, h->d_raw, st, mc);
+        mc.seed = seed * 7919u + (uint32_t)pass0 + 1u;
+        mc.m_per = m;
+        rc = run_network(h, rows, h->d_raw, st, mc);
         if (rc) break;
         if (raw_passes_dev)
-            HIP_TRY(hipMemcpyAsync(raw_passes_dev + (size_t)pass * m * h->out_f, h->d_raw, (size_t)m * h->out_f * 4,
+            HIP_TRY(hipMemcpyAsync(raw_passes_dev + (size_t)pass0 * m * h->out_f, h->d_raw, (size_t)rows * h->out_f * 4,
                                    hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(mlk::mc_accumulate_kernel, dim3(grid_m), dim3(256), 0, st, (const float*)h->d_raw, h->out_f,
-                           (h->legacy && h->out_f == 2) ? 0 : 2, m, n_samples, seed, acc, acc + m);  // net.py:148-151
+        hipLaunchKernelGGL(mlk::mc_accumulate_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st,
+                           (const float*)h->d_raw, h->out_f, (h->legacy && h->out_f == 2) ? 0 : 2, m, pc, n_samples, seed,
+                           part);  // net.py:148-151
+        hipLaunchKernelGGL(mlk::mc_reduce_kernel, dim3(grid_m), dim3(256), 0, st, (const double*)part, m, pc, acc, acc + m);
     }
     if (!rc) {
         hipLaunchKernelGGL(mlk::mc_finish_kernel, dim3(grid_m), dim3(256), 0, st, (const double*)acc, (const double*)(acc + m),
