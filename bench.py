@@ -119,16 +119,19 @@ def main():
     conf = torch.rand(n_out, device=dev)
     out = torch.empty((n_out, 16), dtype=torch.float32, device=dev)
     xyzds = torch.empty((n_out, 5), dtype=torch.float32, device=dev)
-    gather = parallel.RowGather(n_out * world, 5, dev) if world > 1 else None
+    sharded = parallel.ShardedRows(n_out * world, 5, dev) if world > 1 else None  # this rank's shard = its own batch
 
-    def step():
+    def local_block(lo=0, hi=0):
         if args.workload == 'mono':
             eng.forward_mono(kps, kinv, box_conf=conf, out=out, xyzds=xyzds)
-            res = xyzds
+            return xyzds
+        return eng.forward_stereo(kps, kps_r, kinv, box_conf=conf)['xyzds']
+
+    def step():
+        if sharded is not None:
+            sharded.run(local_block)   # local compute, then the single gather to rank 0
         else:
-            res = eng.forward_stereo(kps, kps_r, kinv, box_conf=conf)['xyzds']
-        if gather is not None:
-            gather(res)
+            local_block()
 
     def fence():
         torch.cuda.synchronize(dev)

@@ -76,3 +76,25 @@ class RowGather:
             elif local_block.numel():
                 dist.send(local_block, dst=self.dst, group=self.group)
         return self.full
+
+
+class ShardedRows:
+    """The whole N > 1 layout in one object: rows [0, total) cut into contiguous per-rank shards (``lo``, ``hi``), a
+    caller-supplied function computes the local (hi - lo, width) block -- no communication -- and ONE gather brings
+    the blocks to rank ``dst`` in row order.  bench.py and the gloo tests drive the same class."""
+
+    def __init__(self, total_rows, width, device, dtype=torch.float32, dst=0, group=None):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.lo, self.hi = shard_bounds(total_rows, self.world, self.rank)
+        self.gather = RowGather(total_rows, width, device, dtype=dtype, dst=dst, group=group)
+
+    @property
+    def local_rows(self):
+        return self.hi - self.lo
+
+    def run(self, fn):
+        """fn(lo, hi) -> (hi - lo, width) tensor on the gather's device; returns the gathered rows on rank dst."""
+        block = fn(self.lo, self.hi)
+        assert block.shape[0] == self.hi - self.lo, "the local block must cover exactly this rank's shard"
+        return self.gather(block)

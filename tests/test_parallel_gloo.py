@@ -36,9 +36,10 @@ def _worker(rank, world, port, total, q):
     lo, hi = parallel.shard_bounds(total, world, rank)
     # stand-in for the per-rank device pipeline: a deterministic function of the global row id
     rows = torch.arange(lo, hi, dtype=torch.float32).unsqueeze(1) * torch.tensor([[1., 2., 3., 4., 5.]])
-    gather = parallel.RowGather(total, 5, torch.device('cpu'))
-    for _ in range(2):  # the pre-allocated gather is reusable step after step
-        full = gather(rows)
+    sharded = parallel.ShardedRows(total, 5, torch.device('cpu'))
+    assert (sharded.lo, sharded.hi) == (lo, hi)
+    for _ in range(2):  # the pre-allocated gather is reusable step after step (this is bench.py's N > 1 step)
+        full = sharded.run(lambda a, b: rows)
     if rank == 0:
         ref = torch.arange(total, dtype=torch.float32).unsqueeze(1) * torch.tensor([[1., 2., 3., 4., 5.]])
         q.put(bool(torch.equal(full, ref)))
