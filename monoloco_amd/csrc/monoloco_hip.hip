@@ -898,8 +898,10 @@ int ml_preprocess_rows(const float* kps_dev, const float* kps_r_dev, int64_t m, 
     for (int i = 0; i < nk; ++i) table[i] = make_kinv(kinv_table_host + (size_t)i * 9);
     mlk::Kinv* d_table = nullptr;
     HIP_TRY(hipMallocAsync((void**)&d_table, (size_t)nk * sizeof(mlk::Kinv), st));
-    // pageable source: the copy is complete (staged) when the call returns, so `table` may go out of scope
+    // `table` lives on this stack frame: wait for the upload before returning (dataset preparation is not a
+    // latency-critical call)
     hipError_t e = hipMemcpyAsync(d_table, table.data(), (size_t)nk * sizeof(mlk::Kinv), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(mlk::prep_rows_kernel, ML_GRID(m * mlk::NKP), kps_dev, kps_r_dev, m, (const mlk::Kinv*)d_table,
                            k_index_dev, z_met, x_dev);
