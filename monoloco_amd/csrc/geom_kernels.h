@@ -52,7 +52,10 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ kps
     const int nfl = (int)nvalid * KPS_ROW;
     for (int i = t; i < nfl; i += 256) s_in[i] = src[i];
     __syncthreads();
-    if (t < nvalid) {
+    // (a) per person: box centre (and, for zero_center, its normalised image) -- only when somebody needs it
+    __shared__ float s_c[256][2];
+    const bool need_centre = centre != nullptr || zero_center;
+    if (need_centre && t < nvalid) {
         const float* u = s_in + t * KPS_ROW;
         const float* v = u + NKP;
         float umin = u[0], umax = u[0], vmin = v[0], vmax = v[0];
@@ -66,21 +69,22 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ kps
         const float uc = __fadd_rn(__fmul_rn(__fsub_rn(umax, umin), 0.5f), umin);  // camera.py:85
         const float vc = __fadd_rn(__fmul_rn(__fsub_rn(vmax, vmin), 0.5f), vmin);
         // zero_center (legacy MonoLoco, process.py:61-62): subtract the normalised box centre
-        const float cx = zero_center ? cam_row(uc, vc, ki.k + 0, z_met) : 0.0f;
-        const float cy = zero_center ? cam_row(uc, vc, ki.k + 3, z_met) : 0.0f;
-#pragma unroll
-        for (int j = 0; j < NKP; ++j) {
-            const float xj = cam_row(u[j], v[j], ki.k + 0, z_met);
-            const float yj = cam_row(u[j], v[j], ki.k + 3, z_met);
-            s_x[t * NIN + 2 * j] = zero_center ? __fsub_rn(xj, cx) : xj;
-            s_x[t * NIN + 2 * j + 1] = zero_center ? __fsub_rn(yj, cy) : yj;
-        }
+        s_c[t][0] = zero_center ? cam_row(uc, vc, ki.k + 0, z_met) : 0.0f;
+        s_c[t][1] = zero_center ? cam_row(uc, vc, ki.k + 3, z_met) : 0.0f;
         if (centre) {
             centre[(p0 + t) * 2 + 0] = uc;
             centre[(p0 + t) * 2 + 1] = vc;
         }
-    } else {
-        for (int j = 0; j < NIN; ++j) s_x[t * NIN + j] = 0.0f;
+    }
+    if (zero_center) __syncthreads();
+    // (b) one (person, joint) per thread and pass: a single image keeps 17 threads busy per person instead of one
+    for (int id = t; id < (int)nvalid * NKP; id += 256) {
+        const int pi = id / NKP, j = id - pi * NKP;
+        const float* u = s_in + pi * KPS_ROW;
+        const float xj = cam_row(u[j], u[NKP + j], ki.k + 0, z_met);
+        const float yj = cam_row(u[j], u[NKP + j], ki.k + 3, z_met);
+        s_x[pi * NIN + 2 * j] = zero_center ? __fsub_rn(xj, s_c[pi][0]) : xj;
+        s_x[pi * NIN + 2 * j + 1] = zero_center ? __fsub_rn(yj, s_c[pi][1]) : yj;
     }
     __syncthreads();
     if (x_f32) {
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ kps
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = k0 + e;
-                const float val = (k < NIN) ? s_x[pi * NIN + k] : 0.0f;
+                const float val = (k < NIN && pi < (int)nvalid) ? s_x[pi * NIN + k] : 0.0f;  // zero pad rows and k
                 _Float16 hi, lo;
                 split_f16(val, hi, lo);
                 o[e] = (sub < 4) ? hi : lo;
@@ -318,6 +322,51 @@ __global__ __launch_bounds__(256) void stereo_best_kernel(const float* __restric
     best[i] = bj;
     row_index[i] = (int32_t)(i * mr + bj);
     if (cnt > 1 || has_nan) atomicAdd(ties, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// heads for a single image's worth of rows: ONE launch for all heads (w_fin and w_aux read different activation
+// buffers), one workgroup per row, the outputs dealt round-robin to its 4 waves, weights read straight from L2
+// (no LDS staging: with a handful of rows nothing amortises it).  Same per-(row, output) arithmetic and reduction
+// order as heads_kernel.
+struct SmallHeads {
+    const char* act[2];   // line-format activations each head reads
+    const float* w[2];    // [nh][H]
+    const float* b[2];    // [nh]
+    int nh[2];            // outputs of each head (nh[1] may be 0)
+    int col0[2];          // first raw column of each head
+};
+
+__global__ __launch_bounds__(256) void heads_small_kernel(SmallHeads hp, int H, float* __restrict__ raw, int raw_stride,
+                                                          int64_t m) {
+    const int64_t row = blockIdx.x;
+    if (row >= m) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total = hp.nh[0] + hp.nh[1];
+    const int npairs = H / 8;
+    for (int o = wave; o < total; o += 4) {
+        const int hsel = o < hp.nh[0] ? 0 : 1;
+        const int oo = o - (hsel ? hp.nh[0] : 0);
+        const char* arow = hp.act[hsel] + row * (int64_t)H * 4;
+        const float* wrow = hp.w[hsel] + (size_t)oo * H;
+        float a = 0.0f;
+        for (int pr = lane; pr < npairs; pr += 64) {
+            const int bb = pr >> 2, sub = pr & 3;
+            const char* q = arow + bb * LINE + sub * 16;
+            const half8 hi = *(const half8*)q;
+            const half8 lo = *(const half8*)(q + 64);
+            const f32x4 wa = *(const f32x4*)(wrow + bb * 32 + sub * 8);
+            const f32x4 wb = *(const f32x4*)(wrow + bb * 32 + sub * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a = __builtin_fmaf((float)hi[e] + (float)lo[e], wa[e], a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a = __builtin_fmaf((float)hi[4 + e] + (float)lo[4 + e], wb[e], a);
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) a += __shfl_xor(a, sft, 64);
+        if (lane == 0) raw[row * raw_stride + hp.col0[hsel] + oo] = a + hp.b[hsel][oo];
+    }
 }
 
 // ------------------------------------------------------------------------------------------

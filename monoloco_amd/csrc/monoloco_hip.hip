@@ -600,12 +600,32 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                     HIP_TRY(hipGetLastError());
                 }
             }
-            if (rows_here > 0)
+            // a single image's worth of rows: all heads in ONE launch after the last dense layer (their source
+            // buffers are both still intact there), one workgroup per row
+            const bool one_launch = small && rows <= 128 && mc.p <= 0.f && h->heads.size() <= 2;
+            if (one_launch) {
+                if (li + 1 == h->layers.size() && rows_here > 0) {
+                    mlk::SmallHeads hp = {};
+                    int k = 0;
+                    for (const Head& hd : h->heads) {
+                        hp.act[k] = at(hd.src);
+                        hp.w[k] = hd.d_w;
+                        hp.b[k] = hd.d_b;
+                        hp.nh[k] = hd.nh;
+                        hp.col0[k] = hd.col0;
+                        ++k;
+                    }
+                    hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden,
+                                       raw_out + r0 * h->out_f, h->out_f, rows_here);
+                    HIP_TRY(hipGetLastError());
+                }
+            } else if (rows_here > 0) {
                 for (const Head& hd : h->heads)
                     if (hd.after_layer == (int)li && &hd != fused) {
                         rc = launch_heads(hd, at(hd.src), h->hidden, raw_out + r0 * h->out_f, h->out_f, rows_here, st);
                         if (rc) return rc;
                     }
+            }
         }
     }
     return ML_OK;
@@ -1003,8 +1023,9 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
     hipStream_t st = (hipStream_t)stream;
     const int64_t m_pad = round_up64(m, 256);
     const mlk::Kinv ki = make_kinv(kinv_host);
+    // the small-row dense kernels read whole 32-row tiles only: no need to zero-fill up to the 256-row panel
     hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(m_pad / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
-                       (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, m_pad, 0);
+                       (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, use_small_path(m) ? round_up64(m, 32) : m_pad, 0);
     HIP_TRY(hipGetLastError());
     float* raw = raw_dev ? raw_dev : h->d_raw;
     if ((rc = run_network(h, m, raw, st))) return rc;
