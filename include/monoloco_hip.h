@@ -128,6 +128,13 @@ int ml_pixel_to_camera(const float* uv_dev, int64_t n, const float* kinv_host, f
 /* get_keypoints (utils/camera.py:69-107): kps_dev (m,3,17) -> out_dev (m,2).  mode: 0 center, 1 bottom,
  * 2 head, 3 shoulder, 4 hip, 5 ankle. */
 int ml_get_keypoints(const float* kps_dev, int64_t m, int mode, float* out_dev, void* stream);
+/* The per-person geometry of Loco.post_process (network/net.py:195-215) in one launch: kps_dev (m,3,17), d_dev (m)
+ * predicted distances (NULL: xyz_pred = 0) -> out_dev (m, ML_POSTGEO_STRIDE = 12):
+ * uv_shoulder(2), uv_head(2), uv_center(2) (get_keypoints, utils/camera.py:69-107), xy_center(3) =
+ * pixel_to_camera(uv_center, K, 1) (:10-29), xyz_pred(3) = xyz_from_distance(d, xy_center) (:161-177). */
+#define ML_POSTGEO_STRIDE 12
+int ml_post_geometry(const float* kps_dev, int64_t m, const float* kinv_host, const float* d_dev, float* out_dev,
+                     void* stream);
 /* Dataset-preparation rows in one launch (prep/preprocess_kitti.py:190-253 calls preprocess_monoloco once per
  * matched annotation, each with the K of its image): kps_dev (m,3,17); kinv_table_host (nk,9) = inverses of the
  * distinct intrinsic matrices; k_index_dev (m) int32 = table entry of each row (not range-checked).  kps_r_dev

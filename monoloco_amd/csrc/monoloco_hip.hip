@@ -932,6 +932,15 @@ int ml_preprocess_rows(const float* kps_dev, const float* kps_r_dev, int64_t m, 
     return ML_OK;
 }
 
+int ml_post_geometry(const float* kps_dev, int64_t m, const float* kinv_host, const float* d_dev, float* out_dev,
+                     void* stream) {
+    if (m < 0 || !kinv_host || (m > 0 && (!kps_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    hipLaunchKernelGGL(mlk::post_geometry_kernel, ML_GRID(m), kps_dev, m, make_kinv(kinv_host), d_dev, out_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
 int ml_extract_outputs_mono(const float* raw_dev, int64_t m, float* out_dev, void* stream) {
     if (m < 0 || (m > 0 && (!raw_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
     if (m == 0) return ML_OK;

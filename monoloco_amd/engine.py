@@ -121,6 +121,22 @@ def extract_outputs_device(raw, centre=None, kk=None, box_conf=None, row_index=N
     return out, xyzds
 
 
+def post_geometry(kps, kk, d=None, device=None):
+    """(m,3,17) keypoints, K, predicted distances (m) -> (m,12) device tensor: uv_shoulder, uv_head, uv_center,
+    xy_center (3), xyz_pred (3) -- the geometry of Loco.post_process in one launch (ml_post_geometry)."""
+    lib = _lib.load()
+    dev = _require_cuda(device)
+    kps = _dev_f32(kps, dev)
+    assert kps.dim() == 3 and kps.shape[1] == 3 and kps.shape[2] == 17, "keypoints must be (m, 3, 17)"
+    m = kps.shape[0]
+    d = _dev_f32(d, dev).reshape(-1) if d is not None else None
+    assert d is None or d.shape[0] == m
+    out = torch.empty((m, 12), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ml_post_geometry(_ptr(kps), m, fptr(inverse_intrinsics(kk)), _ptr(d), _ptr(out), _stream(dev)))
+    return out
+
+
 def extract_outputs_mono_device(raw):
     """raw (m, 9) legacy 'monoloco_p' outputs -> packed (m,16) device tensor (ml_extract_outputs_mono)."""
     lib = _lib.load()

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import engine
-from ..utils import get_iou_matches, get_keypoints, pixel_to_camera, reorder_matches, xyz_from_distance
+from ..utils import get_iou_matches, reorder_matches, xyz_from_distance
 from .architectures import LocoModel, MonolocoModel
 from .process import extract_outputs_mono, packed_to_dict, unnormalize_bi
 
@@ -135,14 +135,18 @@ class Loco:
         all_idxs = [pair[0] for pair in matches] + not_matches
         dic_out['gt'] = [True] * len(matches) + [False] * len(not_matches)
 
-        # device geometry, whole image at once
-        uv_shoulders = get_keypoints(keypoints, mode='shoulder')
-        uv_heads = get_keypoints(keypoints, mode='head')
-        uv_centers = get_keypoints(keypoints, mode='center')
-        xy_centers = pixel_to_camera(uv_centers, kk, 1)
+        # device geometry, whole image in ONE launch and one copy back (ml_post_geometry): representative pixels,
+        # normalised centre, back-projected xyz
+        kps_t = keypoints if isinstance(keypoints, torch.Tensor) else torch.tensor(keypoints, dtype=torch.float32)
+        m_kp = kps_t.shape[0]
         d_all = torch.as_tensor(dic_in['d'], dtype=torch.float32).reshape(-1)
-        n_pred = min(d_all.shape[0], xy_centers.shape[0])
-        xyz_all = xyz_from_distance(d_all[:n_pred], xy_centers[:n_pred]).double().numpy()
+        n_pred = min(d_all.shape[0], m_kp)
+        d_fit = torch.zeros(m_kp, dtype=torch.float32)
+        d_fit[:n_pred] = d_all[:n_pred]
+        geo = engine.post_geometry(kps_t, kk.tolist() if isinstance(kk, torch.Tensor) else kk, d_fit).cpu()
+        uv_shoulders, uv_heads, uv_centers = geo[:, 0:2], geo[:, 2:4], geo[:, 4:6]
+        xy_centers = geo[:, 6:9]
+        xyz_all = geo[:n_pred, 9:12].double().numpy()
         dist_all = np.sqrt(xyz_all[:, 0] ** 2 + xyz_all[:, 1] ** 2 + xyz_all[:, 2] ** 2)
         bi_all = torch.as_tensor(dic_in['bi'], dtype=torch.float32).reshape(-1).double().numpy()
         uv_s = np.rint(uv_shoulders.double().numpy()).astype(int)
