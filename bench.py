@@ -62,6 +62,40 @@ def traffic_from_profiles(args):
     return json.load(open(path))['hbm_bytes_per_launch']
 
 
+def timed_steps(step, steps, warmup, world, device, begin=None, end=None):
+    """The timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by barrier + device
+    synchronisation on both sides; returns (seconds = MAX over ranks, whatever `end()` returned on this rank).
+    `device` is the rank's HIP device (a CPU device in the gloo tests of this very function)."""
+    import torch
+    import torch.distributed as dist
+    on_gpu = device.type == 'cuda'
+
+    def fence():
+        if on_gpu:
+            torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize(device)
+
+    for _ in range(warmup):
+        step()
+    fence()
+    if begin is not None:
+        begin()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    extra = end() if end is not None else None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, extra
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -133,27 +167,11 @@ def main():
         else:
             local_block()
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
     if not args.no_profile:
-        eng.profile_begin(args.steps * eng.num_layers * 16 + 8)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = eng.profile_end() if not args.no_profile else None
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        hooks = (lambda: eng.profile_begin(args.steps * eng.num_layers * 16 + 8), eng.profile_end)
+    else:
+        hooks = (None, None)
+    dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, begin=hooks[0], end=hooks[1])
 
     if rank == 0:
         total_rows = rows * world * args.steps

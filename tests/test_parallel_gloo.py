@@ -61,3 +61,46 @@ def test_row_gather_gloo(world, total):
         p.join(120)
         assert p.exitcode == 0
     assert q.get() is True
+
+
+def _bench_worker(rank, world, port, q):
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env('gloo')
+    calls = []
+    sharded = parallel.ShardedRows(8 * world, 5, torch.device('cpu'))
+
+    def step():  # bench.py's N > 1 step with a stand-in for the device pipeline; rank r is (r + 1) x slower
+        calls.append(1)
+        time.sleep(0.01 * (rank + 1))
+        sharded.run(lambda lo, hi: torch.full((hi - lo, 5), float(rank)))
+
+    marks = []
+    dt, extra = bench.timed_steps(step, 5, 2, world, torch.device('cpu'), begin=lambda: marks.append(len(calls)),
+                                  end=lambda: 'done')
+    q.put((rank, dt, len(calls), marks, extra))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timing_contract_gloo():
+    """bench.timed_steps: W untimed warm-up steps, exactly K timed ones between barriers, MAX over ranks."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get() for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (r0, dt0, n0, marks0, e0), (r1, dt1, n1, marks1, e1) = res
+    assert n0 == n1 == 7 and marks0 == marks1 == [2] and e0 == e1 == 'done'   # 2 warm-up + 5 timed, begin() after warm-up
+    assert dt0 == dt1                                                           # every rank reports the MAX
+    assert 5 * 0.02 <= dt0 < 5 * 0.02 + 0.5                                     # the slow rank's 5 x 20 ms
