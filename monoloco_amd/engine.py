@@ -45,11 +45,24 @@ def _dev_f32(x, dev, shape=None):
     return x
 
 
+_KINV_CACHE = {}
+
+
 def inverse_intrinsics(kk):
     """inverse(K) as 9 fp32 numbers, taken the way the reference takes it: torch.inverse on an
-    fp32 CPU tensor (reference monoloco/utils/camera.py:23)."""
-    k = torch.as_tensor(np.asarray(kk, dtype=np.float32)).reshape(3, 3).cpu()
-    return np.ascontiguousarray(torch.inverse(k).numpy().reshape(9).astype(np.float32))
+    fp32 CPU tensor (reference monoloco/utils/camera.py:23).  A camera's K is the same frame after frame:
+    the last few inverses are kept (the returned array must not be modified)."""
+    k32 = np.asarray(kk, dtype=np.float32).reshape(9)
+    key = k32.tobytes()
+    hit = _KINV_CACHE.get(key)
+    if hit is None:
+        if len(_KINV_CACHE) >= 64:
+            _KINV_CACHE.clear()
+        k = torch.as_tensor(k32.copy()).reshape(3, 3)
+        hit = np.ascontiguousarray(torch.inverse(k).numpy().reshape(9).astype(np.float32))
+        hit.setflags(write=False)
+        _KINV_CACHE[key] = hit
+    return hit
 
 
 # ------------------------------------------------------------------ stand-alone kernels

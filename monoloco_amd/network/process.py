@@ -137,16 +137,20 @@ def unnormalize_bi(loc):
 
 def packed_to_dict(out, n_cols, home=torch.device('cpu')):
     """The (m,16) packed device result -> the reference's extract_outputs dictionary of (m,k) tensors,
-    in the reference's key order (process.py:240-278)."""
+    in the reference's key order (process.py:240-278).  One copy off the device, then one contiguous re-pack
+    whose column groups become the (independent-looking, non-overlapping) output tensors."""
     o = out.to(home)
-    dic = {'h': o[:, 8:9].clone(), 'w': o[:, 9:10].clone(), 'l': o[:, 10:11].clone(),
-           'ori': o[:, 12:14].clone()}
+    # columns regrouped so that every output is a contiguous slice of its own row block
+    cols = [8, 9, 10, 12, 13, 7, 4, 0, 1, 2, 3, 5, 6]   # h w l | ori0 ori1 | aux | bi | x y z d | yaw | yaw_ego
+    t = o[:, cols].t().contiguous()                       # (13, m): each row one output column
+    col = lambda a, b: t[a:b].t()                         # (m, b-a) view of rows a..b (non-overlapping storage)
+    dic = {'h': col(0, 1), 'w': col(1, 2), 'l': col(2, 3), 'ori': col(3, 5).contiguous()}
     if n_cols == 10:
-        dic['aux'] = o[:, 7:8].clone()
-    dic['bi'] = o[:, 4:5].clone()
-    dic['xyzd'] = o[:, 0:4].clone()
-    dic['d'] = o[:, 3:4].clone()
-    dic['yaw'] = (o[:, 5:6].clone(), o[:, 6:7].clone())
+        dic['aux'] = col(5, 6)
+    dic['bi'] = col(6, 7)
+    dic['xyzd'] = col(7, 11).contiguous()
+    dic['d'] = dic['xyzd'][:, 3:4].clone()
+    dic['yaw'] = (col(11, 12), col(12, 13))
     return dic
 
 
