@@ -310,7 +310,9 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
         // Phase p (after the tile-start barrier): group 0 reads half-step h in phase 2h and computes it in
         // 2h+1; group 1 does the same one phase later.  Stage s (half-steps 2s, 2s+1) is read in phases
         // 4s..4s+3 and its buffer previously held stage s-2, last read in phase 4s-5.  Its four quarters
-        // are requested in four consecutive L phases:
+        // are requested in four consecutive phases (schedule A: all 4 instructions of a quarter in the L phase
+        // named here; schedule B, the default: NL of them there, the rest between the MFMAs of the same wave's
+        // next C phase -- group 0's W share starts one phase earlier so that nothing is issued in phase 4s-1):
         //   X rows 128.. : group 1, end of phase 4s-5 (after its own last reads of stage s-2)   window 5
         //   X rows   0.. : group 0, phase 4s-4                                                  window 4
         //   W rows   0.. : group 1, phase 4s-3                                                  window 3
