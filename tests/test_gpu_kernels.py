@@ -258,3 +258,33 @@ def test_small_row_path_single_fp16_mode(hip_lib, cuda_device, monkeypatch, m):
     assert (raw_small.double() - ref64).abs().max().item() <= 5e-2 * scale
     assert (raw_small - raw_tile).abs().max().item() <= 2e-3 * scale
     eng.close()
+
+
+def test_handles_do_not_leak_device_memory(hip_lib, cuda_device):
+    """ml_loco_create / finalize / reserve / forward / destroy in a loop (and the trainer likewise): the free device
+    memory must come back."""
+    from monoloco_amd import engine
+    from monoloco_amd.train import HipTrainer
+    sd = _sd_t(synth.make_state_dict(9))
+    kps = torch.tensor(synth.make_poses(3000, 2)).to(cuda_device)
+    kinv = engine.inverse_intrinsics(synth.KITTI_K)
+    x = torch.randn(400, 34, device=cuda_device)
+    y = torch.randn(400, 11, device=cuda_device).abs() + 0.5
+
+    def cycle():
+        eng = engine.LocoEngine(sd, device=cuda_device, reserve_rows=4096)
+        eng.forward_mono(kps, kinv)
+        eng.epistemic_mono(kps[:64], kinv, 5)
+        eng.close()
+        tr = HipTrainer(sd, p_dropout=0.2, lr=0.001, device=cuda_device)
+        tr.step(x, y)
+        tr.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(cuda_device)[0]
+    for _ in range(12):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(cuda_device)[0]
+    assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
