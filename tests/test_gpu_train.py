@@ -93,23 +93,28 @@ def test_dropout_training_runs_and_learns(hip_lib, cuda_device):
     tr.close()
 
 
-def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path):
-    """The reference's test flow (tests/test_train_mono.py:42-50): train on the sample joints, save a checkpoint,
-    load it into Loco and predict."""
+@pytest.mark.parametrize("mode", ["mono", "stereo"])
+def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path, mode):
+    """The reference's test flow (tests/test_train_mono.py:42-50, test_train_stereo.py): train on the sample joints,
+    save a checkpoint, load it into Loco and predict."""
     import json
     from monoloco_amd.train import Trainer
     from monoloco_amd.network import Loco
     g = dict(np.load(os.path.join(G, 'golden_train_inputs.npz')))
     joints = {'version': 'test', 'test': {'X': [], 'Y': [], 'names': [], 'kps': [], 'K': [], 'clst': {}}}
     gp = dict(np.load(os.path.join(G, 'golden_path.npz')))
+    if mode == 'mono':
+        kps_all = gp['mono_kps'][:, None]                                              # (N, 1, 3, 17)
+    else:
+        kps_all = np.concatenate((gp['stereo_kps_l'], gp['stereo_kps_r']), axis=2)[:, None]   # (N, 1, 3, 34)
     for ph, tag in (('train', ''), ('val', 'val')):
-        n = len(g['mono_x' + tag])
-        joints[ph] = {'X': g['mono_x' + tag].tolist(), 'Y': g['mono_y' + tag].tolist(), 'names': ['x.png'] * n,
-                      'kps': gp['mono_kps'][:n, None].tolist(), 'K': [], 'clst': {}}
+        n = len(g[mode + '_x' + tag])
+        joints[ph] = {'X': g[mode + '_x' + tag].tolist(), 'Y': g[mode + '_y' + tag].tolist(), 'names': ['x.png'] * n,
+                      'kps': kps_all[:n].tolist(), 'K': [], 'clst': {}}
     path = tmp_path / 'joints.json'
     path.write_text(json.dumps(joints))
     out = str(tmp_path / 'model.pkl')
-    args = argparse.Namespace(mode='mono', joints=str(path), epochs=4, no_save=False, lr=0.001, sched_step=30, sched_gamma=0.98,
+    args = argparse.Namespace(mode=mode, joints=str(path), epochs=4, no_save=False, lr=0.001, sched_step=30, sched_gamma=0.98,
                               hidden_size=256, n_stage=3, r_seed=1, out=out, bs=512, dropout=0.2)
     tr = Trainer(args)
     tr.train()
@@ -117,6 +122,10 @@ def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path
     assert os.path.exists(out) and 'd' in dic_err['val']['all']
     losses = tr.epoch_losses['train']['loss']
     assert len(losses) == 4 and losses[-1] < losses[0]
-    net = Loco(model=out, mode='mono', device=cuda_device, linear_size=256)
-    dic = net.forward(gp['mono_kps'][:8].tolist(), synth.KITTI_K)
+    net = Loco(model=out, mode=mode, device=cuda_device, linear_size=256)
+    if mode == 'mono':
+        dic = net.forward(gp['mono_kps'][:8].tolist(), synth.KITTI_K)
+    else:
+        dic = net.forward(gp['stereo_kps_l'][:8].tolist(), synth.KITTI_K, keypoints_r=gp['stereo_kps_r'][:5].tolist())
+        assert dic['aux'].shape == (8, 1)
     assert dic['d'].shape == (8, 1) and torch.isfinite(dic['d']).all()
