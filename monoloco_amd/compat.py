@@ -1,27 +1,123 @@
-"""Make ``import monoloco.network`` / ``monoloco.utils`` resolve to this package.
+"""Drop the MI355X hot path into the reference's own module tree.
 
-The reference's callers (monoloco/predict.py:31, visuals/webcam.py:25, eval/generate_kitti.py:14-15)
-import ``Loco``, ``preprocess_pifpaf`` ... from ``monoloco.network``.  ``install()`` registers the
-MI355X implementations under those module paths so such callers run unmodified:
+Two situations, one call (``monoloco_amd.compat.install()``):
 
-    import monoloco_amd.compat; monoloco_amd.compat.install()
+* **The reference package is importable** (``import monoloco`` works -- a checkout or a pip install).  Nothing is
+  replaced wholesale: the reference's modules keep every name this repository does not implement
+  (``monoloco.utils.get_task_error``, ``open_image``, ``monoloco.prep``, ``monoloco.eval`` ...).  Only the names of
+  the keypoint->3D path are re-bound -- on ``monoloco.network``, ``monoloco.network.net``,
+  ``monoloco.network.process``, ``monoloco.network.architectures``, ``monoloco.utils`` and
+  ``monoloco.utils.camera`` -- and in every already-imported ``monoloco.*`` module that holds a
+  ``from ..network import Loco``-style copy of one of them (``monoloco.predict``, ``monoloco.eval.generate_kitti``,
+  ``monoloco.visuals.printer`` ...).  Modules imported later pick the patched names up from the packages.
+  The reference callers (predict.py:31, visuals/webcam.py:25, eval/generate_kitti.py:14-18,
+  eval/eval_activity.py) then run unmodified on the HIP path.
+* **Stand-alone** (no reference on the path): ``monoloco`` becomes an alias of this package, so
+  ``from monoloco.network import Loco`` / ``from monoloco.utils import pixel_to_camera`` /
+  ``from monoloco.train import Trainer`` resolve to the implementations here.  Only what this repository implements
+  exists under that name.
+
+``uninstall()`` restores the reference's own functions (used by the tests).
 """
+import importlib
+import importlib.util
 import sys
-import types
+
+# names of the path, by the reference module that defines them
+_NET = ('Loco',)
+_PROCESS = ('preprocess_pifpaf', 'prepare_pif_kps', 'factory_for_gt', 'load_calibration', 'preprocess_monoloco',
+            'preprocess_monstereo', 'unnormalize_bi', 'extract_outputs', 'extract_outputs_mono', 'extract_labels',
+            'extract_labels_aux', 'cluster_outputs', 'filter_outputs', 'laplace_sampling')
+_ARCH = ('LocoModel', 'MonolocoModel')
+_CAMERA = ('pixel_to_camera', 'get_keypoints', 'xyz_from_distance', 'to_cartesian', 'back_correct_angles')
+
+_saved = []  # (module, name, original object, existed) of everything install() re-bound
+_pairs = []  # (name, our object, the reference's object)
 
 
-def install(force=False):
-    from . import network, utils
+def _reference_available():
+    """True if a real reference package (not an alias made by this module) is imported or importable."""
+    mod = sys.modules.get('monoloco')
+    if mod is not None:
+        return getattr(mod, '__name__', '') == 'monoloco' and not getattr(mod, '_monoloco_amd_alias', False)
+    try:
+        spec = importlib.util.find_spec('monoloco')
+    except (ImportError, ValueError):
+        spec = None
+    return spec is not None
+
+
+def _bind(mod, name, obj):
+    if getattr(mod, name, None) is obj:
+        return
+    _saved.append((mod, name, getattr(mod, name, None), hasattr(mod, name)))
+    setattr(mod, name, obj)
+
+
+def install():
+    """Re-bind the keypoint->3D path of ``monoloco`` to the MI355X implementations; returns the ``monoloco`` package."""
+    import importlib.util  # noqa: F401  (find_spec)
+    from . import activity, formats, network, train, utils  # noqa: F401  (import everything that gets an alias)
     from .network import architectures, net, process
-    if 'monoloco' in sys.modules and not force:
-        pkg = sys.modules['monoloco']
-    else:
-        pkg = types.ModuleType('monoloco')
-        pkg.__path__ = []
-        sys.modules['monoloco'] = pkg
-    for name, mod in (('network', network), ('utils', utils), ('network.net', net), ('network.process', process),
-                      ('network.architectures', architectures)):
-        sys.modules['monoloco.' + name] = mod
-    pkg.network = network
-    pkg.utils = utils
-    return pkg
+    from .utils import camera
+
+    if not _reference_available():
+        # stand-alone: `monoloco` IS this package; every loaded submodule gets the matching alias so that
+        # `import monoloco.network.process` finds the module object that already exists (no second copy)
+        pkg = sys.modules[__package__]
+        pkg._monoloco_amd_alias = True
+        for name, mod in list(sys.modules.items()):
+            if name == __package__ or name.startswith(__package__ + '.'):
+                sys.modules['monoloco' + name[len(__package__):]] = mod
+        return pkg
+
+    import monoloco  # the reference
+    ref = {key: importlib.import_module('monoloco.' + key)
+           for key in ('network', 'network.net', 'network.process', 'network.architectures', 'utils', 'utils.camera')}
+    new = {}
+    for names, src in ((_NET, net), (_PROCESS, process), (_ARCH, architectures), (_CAMERA, camera)):
+        for name in names:
+            if hasattr(src, name):
+                new[name] = getattr(src, name)
+    originals = {}
+    for names, key in ((_NET, 'network.net'), (_PROCESS, 'network.process'), (_ARCH, 'network.architectures'),
+                       (_CAMERA, 'utils.camera')):
+        for name in names:
+            if name in new and hasattr(ref[key], name):
+                originals[name] = getattr(ref[key], name)
+    # the defining modules and the packages that re-export (network/__init__.py:2-4, utils/__init__.py:8-9)
+    for name, obj in new.items():
+        for key, mod in ref.items():
+            if hasattr(mod, name):
+                _bind(mod, name, obj)
+    # copies taken by `from ..network import Loco` in modules that are already imported
+    for modname, mod in list(sys.modules.items()):
+        if mod is None or not (modname == 'monoloco' or modname.startswith('monoloco.')):
+            continue
+        for name, orig in originals.items():
+            if getattr(mod, name, None) is orig:
+                _bind(mod, name, new[name])
+    _pairs[:] = [(name, new[name], orig) for name, orig in originals.items()]
+    return monoloco
+
+
+def uninstall():
+    """Undo install(): restore the reference's own objects / remove the stand-alone aliases."""
+    while _saved:
+        mod, name, orig, had = _saved.pop()
+        if had:
+            setattr(mod, name, orig)
+        else:
+            delattr(mod, name)
+    # modules imported AFTER install() copied our objects straight from the patched packages
+    for modname, mod in list(sys.modules.items()):
+        if mod is not None and modname.startswith('monoloco.'):
+            for name, ours, orig in _pairs:
+                if getattr(mod, name, None) is ours:
+                    setattr(mod, name, orig)
+    del _pairs[:]
+    pkg = sys.modules.get(__package__)
+    if pkg is not None and getattr(pkg, '_monoloco_amd_alias', False):
+        for name in [n for n in sys.modules if n == 'monoloco' or n.startswith('monoloco.')]:
+            del sys.modules[name]
+        pkg._monoloco_amd_alias = False

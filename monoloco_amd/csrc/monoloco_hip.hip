@@ -137,6 +137,7 @@ struct Head {
 
 struct ml_loco {
     int in_f = 0, hidden = 0, out_f = 0, num_stage = 0;
+    int hidden_real = 0;  // the checkpoint's linear_size; `hidden` is that rounded up to the 256-column tile
     int precision = ML_PREC_F16X2, flags = 0;
     bool finalized = false;
     bool host_only = false;
@@ -220,21 +221,33 @@ int fold(const ml_loco* h, const std::string& lin, const std::string& bn, int n,
     return ML_OK;
 }
 
-void add_dense(ml_loco* h, const std::vector<double>& W, const std::vector<double>& B, int n, int k,
+// W is (n x k) as folded; the layer is stored as (np x kp) with np >= n, kp >= k: any linear_size runs on the
+// 256-column tiles -- padded output columns have zero weights and zero bias (relu(0) = 0, residual 0 + 0), padded
+// input columns multiply activations that are exactly zero
+void add_dense(ml_loco* h, const std::vector<double>& W, const std::vector<double>& B, int n, int k, int np, int kp,
                int relu, int src, int dst, int res) {
     DenseLayer L;
-    L.n = n;
-    L.k = k;
-    L.kpad = round_up(k, 32);
+    L.n = np;
+    L.k = kp;
+    L.kpad = round_up(kp, 32);
     L.relu = relu;
     L.src = src;
     L.dst = dst;
     L.res = res;
-    L.w.resize((size_t)n * k);
-    L.b.resize(n);
-    for (size_t i = 0; i < L.w.size(); ++i) L.w[i] = (float)W[i];
+    L.w.assign((size_t)np * kp, 0.0f);
+    L.b.assign(np, 0.0f);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) L.w[(size_t)i * kp + j] = (float)W[(size_t)i * k + j];
     for (int i = 0; i < n; ++i) L.b[i] = (float)B[i];
     h->layers.push_back(std::move(L));
+}
+
+// head weights (nh x k) -> (nh x kp), zero padded
+std::vector<float> pad_head(const float* w, int nh, int k, int kp) {
+    std::vector<float> out((size_t)nh * kp, 0.0f);
+    for (int o = 0; o < nh; ++o)
+        for (int j = 0; j < k; ++j) out[(size_t)o * kp + j] = w[(size_t)o * k + j];
+    return out;
 }
 
 // C (n x k) = A (n x p) * B (p x k), fp64, i-k-j order (unit stride inner loop)
@@ -660,14 +673,14 @@ int ml_device_count(void) {
 int ml_loco_create(int in_features, int hidden, int out_features, int num_stage, ml_loco** out) {
     if (!out) return fail(ML_ERR_ARG, "out is null");
     if (in_features <= 0 || in_features > 1024) return fail(ML_ERR_SHAPE, "in_features %d unsupported", in_features);
-    if (hidden <= 0 || hidden % 256 != 0 || hidden > 4096)
-        return fail(ML_ERR_SHAPE, "hidden size %d unsupported (must be a multiple of 256, <= 4096)", hidden);
+    if (hidden <= 0 || hidden > 4096) return fail(ML_ERR_SHAPE, "hidden size %d unsupported (1 .. 4096)", hidden);
     if (out_features < 2 || out_features > 11) return fail(ML_ERR_SHAPE, "out_features %d unsupported", out_features);
     if (num_stage < 0 || num_stage > 16) return fail(ML_ERR_SHAPE, "num_stage %d unsupported", num_stage);
     ml_loco* h = new (std::nothrow) ml_loco();
     if (!h) return fail(ML_ERR_HIP, "out of host memory");
     h->in_f = in_features;
-    h->hidden = hidden;
+    h->hidden_real = hidden;
+    h->hidden = round_up(hidden, 256);  // any linear_size (reference architectures.py:14): zero-padded to the tile
     h->out_f = out_features;
     h->num_stage = num_stage;
     *out = h;
@@ -693,20 +706,20 @@ int ml_loco_finalize(ml_loco* h, int precision, int flags) {
     h->flags = flags;
     h->host_only = (flags & ML_FLAG_HOST_ONLY) != 0;
     if (!h->host_only) HIP_TRY(hipGetDevice(&h->device));
-    const int H = h->hidden, IN = h->in_f;
+    const int H = h->hidden_real, HP = h->hidden, IN = h->in_f;
     const int NFIN = h->out_f - 1;  // w_fin rows; the aux head adds the last column (architectures.py:12,70)
     std::vector<double> W, B;
     int rc;
     // w1 + batch_norm1 + relu (architectures.py:50-53): input lines (buf0) -> A (buf1)
     if ((rc = fold(h, "w1", "batch_norm1", H, IN, W, B))) return rc;
-    add_dense(h, W, B, H, IN, 1, 0, 1, -1);
+    add_dense(h, W, B, H, IN, HP, IN, 1, 0, 1, -1);
     // residual stages (architectures.py:88-102): A -> B -> A (+A)
     for (int s = 0; s < h->num_stage; ++s) {
         const std::string p = "linear_stages." + std::to_string(s) + ".";
         if ((rc = fold(h, p + "w1", p + "batch_norm1", H, H, W, B))) return rc;
-        add_dense(h, W, B, H, H, 1, 1, 2, -1);
+        add_dense(h, W, B, H, H, HP, HP, 1, 1, 2, -1);
         if ((rc = fold(h, p + "w2", p + "batch_norm2", H, H, W, B))) return rc;
-        add_dense(h, W, B, H, H, 1, 2, 1, 1);
+        add_dense(h, W, B, H, H, HP, HP, 1, 2, 1, 1);
     }
     h->legacy = h->tensors.count("w_fin.weight") == 0 && h->tensors.count("w3.weight") == 0;
     if (h->legacy) {
@@ -721,7 +734,7 @@ int ml_loco_finalize(ml_loco* h, int precision, int flags) {
         out.col0 = 0;
         out.src = 1;
         out.after_layer = (int)h->layers.size() - 1;
-        out.w.assign(w2->begin(), w2->end());
+        out.w = pad_head(w2->data(), h->out_f, H, HP);
         out.b.assign(b2->begin(), b2->end());
         h->heads.push_back(std::move(out));
     } else {
@@ -737,7 +750,7 @@ int ml_loco_finalize(ml_loco* h, int precision, int flags) {
     aux.col0 = NFIN;
     fin.nh = NFIN;
     fin.col0 = 0;
-    fin.w.assign(wf->begin(), wf->end());
+    fin.w = pad_head(wf->data(), NFIN, H, HP);
     fin.b.assign(bf->begin(), bf->end());
     if (flags & ML_FLAG_MERGE_W2W3) {
         // y3 = relu(bn3(w3(w2 a + b2) + b3)) = relu((W3' W2) a + (W3' b2 + b3'));  aux = (wa W2) a + (wa b2 + ba)
@@ -752,22 +765,22 @@ int ml_loco_finalize(ml_loco* h, int precision, int flags) {
         double s = BA[0];
         for (int j = 0; j < H; ++j) s += WA[j] * B2[j];
         BAM[0] = s;
-        aux.w.resize(H);
+        aux.w.assign(HP, 0.0f);
         for (int j = 0; j < H; ++j) aux.w[j] = (float)WAM[j];
         aux.b.assign(1, (float)BAM[0]);
         aux.src = 1;  // reads a3 (buffer A) once the last stage is done
         aux.after_layer = (int)h->layers.size() - 1;
-        add_dense(h, W32, B32, H, H, 1, 1, 2, -1);  // A -> B
+        add_dense(h, W32, B32, H, H, HP, HP, 1, 1, 2, -1);  // A -> B
         fin.src = 2;
         fin.after_layer = (int)h->layers.size() - 1;
     } else {
-        add_dense(h, W2, B2, H, H, 0, 1, 2, -1);  // y2 = w2 a      A -> B   (architectures.py:59)
-        aux.w.resize(H);
+        add_dense(h, W2, B2, H, H, HP, HP, 0, 1, 2, -1);  // y2 = w2 a      A -> B   (architectures.py:59)
+        aux.w.assign(HP, 0.0f);
         for (int j = 0; j < H; ++j) aux.w[j] = (float)WA[j];
         aux.b.assign(1, (float)BA[0]);
         aux.src = 2;
         aux.after_layer = (int)h->layers.size() - 1;
-        add_dense(h, W3, B3, H, H, 1, 2, 1, -1);  // y3 = relu(bn3(w3 y2))  B -> A
+        add_dense(h, W3, B3, H, H, HP, HP, 1, 2, 1, -1);  // y3 = relu(bn3(w3 y2))  B -> A
         fin.src = 1;
         fin.after_layer = (int)h->layers.size() - 1;
     }
@@ -1088,7 +1101,9 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
     if (rc) return rc;
     if (h->in_f != mlk::NIN) return fail(ML_ERR_SHAPE, "epistemic uncertainty is defined for the mono nets (net.py:139)");
     if (m == 0) return ML_OK;
-    if (m < 0 || !kps_dev || !kinv_host || !epi_dev || n_dropout <= 0 || n_samples <= 0 || !(p_dropout > 0.f) ||
+    // p_dropout == 0 is legal (reference net.py:135-161 with a p = 0 model): the passes are then identical and the
+    // spread is the purely aleatoric one of the Laplace samples
+    if (m < 0 || !kps_dev || !kinv_host || !epi_dev || n_dropout <= 0 || n_samples <= 0 || !(p_dropout >= 0.f) ||
         !(p_dropout < 1.f))
         return fail(ML_ERR_ARG, "bad argument");
     if ((rc = ensure_rows(h, m))) return rc;
@@ -1121,8 +1136,14 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
             const int64_t n16 = line_bytes / 16 * (pc - 1);
             hipLaunchKernelGGL(mlk::replicate_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, h->buf[0], line_bytes, pc);
         }
+        // every error exit of the loop goes through the hipFreeAsync(acc) below
+        auto hip_rc = [&](hipError_t e, const char* what) {
+            return e == hipSuccess ? ML_OK : fail(ML_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        };
         if (rows_pad > rows)  // pad rows of the last 256-row panel: finite values so that nothing propagates NaN patterns
-            HIP_TRY(hipMemsetAsync(h->buf[0] + rows * (int64_t)h->k0pad * 4, 0, (size_t)(rows_pad - rows) * h->k0pad * 4, st));
+            rc = hip_rc(hipMemsetAsync(h->buf[0] + rows * (int64_t)h->k0pad * 4, 0, (size_t)(rows_pad - rows) * h->k0pad * 4, st),
+                        "hipMemsetAsync");
+        if (rc) break;
         McPass mc;
         mc.p = p_dropout;
         mc.seed = seed * 7919u + (uint32_t)pass0 + 1u;
@@ -1130,8 +1151,9 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
         rc = run_network(h, rows, h->d_raw, st, mc);
         if (rc) break;
         if (raw_passes_dev)
-            HIP_TRY(hipMemcpyAsync(raw_passes_dev + (size_t)pass0 * m * h->out_f, h->d_raw, (size_t)rows * h->out_f * 4,
-                                   hipMemcpyDeviceToDevice, st));
+            rc = hip_rc(hipMemcpyAsync(raw_passes_dev + (size_t)pass0 * m * h->out_f, h->d_raw, (size_t)rows * h->out_f * 4,
+                                       hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+        if (rc) break;
         hipLaunchKernelGGL(mlk::mc_accumulate_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st,
                            (const float*)h->d_raw, h->out_f, (h->legacy && h->out_f == 2) ? 0 : 2, m, pc, n_samples, seed,
                            part);  // net.py:148-151

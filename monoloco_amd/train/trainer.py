@@ -54,6 +54,7 @@ class Trainer:
     VAL_BS = 10000
     tasks = ('d', 'x', 'y', 'h', 'w', 'l', 'ori', 'aux')
     val_task = 'd'
+    clusters = ['10', '20', '30', '40']
     input_size = dict(mono=34, stereo=68)
     output_size = dict(mono=9, stereo=10)
 
@@ -83,21 +84,45 @@ class Trainer:
         self.hip = HipTrainer(self.model.state_dict(), p_dropout=args.dropout, lr=args.lr, sched_gamma=args.sched_gamma,
                               sched_step=int(args.sched_step), seed=args.r_seed, device=self.device)
         self.epoch_losses = defaultdict(lambda: defaultdict(list))
+        self._eval_eng, self._eval_version = None, -1
 
-    def _val_losses(self, inputs, labels):
-        """Validation metrics of the reference (losses.py:85-96): L1 from Laplace for d, L1, angle error for ori."""
+    # ---- validation: eval-mode forward (running statistics) on the inference engine, built ONCE per weight version
+    def _eval_engine(self):
+        """LocoEngine of the trainer's current weights; rebuilt only when a training step changed them.  w2/w3 are
+        kept as two layers (merge_w2w3=False): no host fp64 H x H x H product per rebuild."""
         from ..engine import LocoEngine
-        eng = LocoEngine(self.hip.state_dict(), device=self.device, merge_w2w3=True) if self.model.linear_size % 256 == 0 else None
-        if eng is None:
-            return {}
-        out = eng.forward_raw(inputs.to(self.device)).cpu()
-        eng.close()
-        lab = labels
+        version = self.hip.num_steps
+        if self._eval_eng is None or self._eval_version != version:
+            self._close_eval_engine()
+            self._eval_eng = LocoEngine(self.hip.state_dict(), device=self.device, merge_w2w3=False)
+            self._eval_version = version
+        return self._eval_eng
+
+    def _close_eval_engine(self):
+        if getattr(self, '_eval_eng', None) is not None:
+            self._eval_eng.close()
+        self._eval_eng, self._eval_version = None, -1
+
+    def _forward_eval(self, inputs):
+        return self._eval_engine().forward_raw(inputs.to(self.device)).cpu()
+
+    def _val_losses(self, out, lab):
+        """Validation values of the reference for raw outputs `out` and labels `lab` (CPU tensors): per task the
+        `losses_val` entries of CompositeLoss (losses.py:85-96: L1 from Laplace for d, angle error for ori, BCE for
+        aux, L1 otherwise) and 'all' = the training-type multi-task loss on these outputs (losses.py:59-73 with unit
+        lambdas; trainer.py:195)."""
         vals = {'d': (out[:, 2:3] - lab[:, 3:4]).abs().mean().item()}
         for t, c in (('x', 0), ('y', 1), ('h', 4), ('w', 5), ('l', 6)):
             vals[t] = (out[:, c] - lab[:, c]).abs().mean().item()
         ang = torch.atan2(out[:, 7], out[:, 8]) - torch.atan2(lab[:, 7], lab[:, 8])
         vals['ori'] = ang.abs().mean().item() * 180 / 3.14
+        norm = 1 - out[:, 2:3] / lab[:, 3:4]
+        laplace = (norm.abs() * torch.exp(-out[:, 3:4]) + 0.01 + out[:, 3:4] + 2).mean().item()   # losses.py:112-131
+        total = laplace + sum(vals[t] for t in ('x', 'y', 'h', 'w', 'l')) + (out[:, 7:9] - lab[:, 7:9]).abs().mean().item()
+        if 'aux' in self.tasks:
+            vals['aux'] = torch.nn.functional.binary_cross_entropy_with_logits(out[:, 9:10], lab[:, 10:11]).item()
+            total += vals['aux']
+        vals['all'] = total
         return vals
 
     def train(self):
@@ -111,28 +136,60 @@ class Trainer:
                 for k, v in losses.items():
                     running['train'][k] += v * inputs.size(0)
             for inputs, labels, _, _ in self.dataloaders['val']:
-                vals = self._val_losses(inputs, labels)
+                vals = self._val_losses(self._forward_eval(inputs), labels)
                 for k, v in vals.items():
                     running['val'][k] += v * inputs.size(0)
             for phase in running:
                 for k, v in running[phase].items():
                     self.epoch_losses[phase][k].append(v / self.dataset_sizes[phase])
-            val_d = self.epoch_losses['val'][self.val_task][-1] if self.epoch_losses['val'][self.val_task] else 0.0
+            val_d = self.epoch_losses['val'][self.val_task][-1]   # KeyError-free: every epoch appends every task
             if val_d < best_acc:
                 best_acc, best_epoch = val_d, epoch
                 best_wts = copy.deepcopy(self.hip.state_dict())
         self.training_time = time.time() - since
         self.hip.load_state_dict(best_wts)
+        self._close_eval_engine()   # the weights changed without a step: never reuse the engine of the last epoch
         return best_epoch
 
     def evaluate(self, load=False, model=None, debug=False):
+        """Reference trainer.py:197-246: statistics on the whole validation set ('all') and per distance cluster
+        ('10'..'40'), the model saved as a reference-compatible state_dict and returned in eval mode."""
         if load:
             self.hip.load_state_dict(torch.load(model, map_location=lambda storage, loc: storage))
+            self._close_eval_engine()
         sd = self.hip.state_dict()
         self.model.load_state_dict(sd, strict=False)
+        self.model.eval()
         dataset = KeypointsDataset(self.joints, phase='val')
+        dic_err = {'val': defaultdict(lambda: defaultdict(float))}
+        dic_err['val']['sigmas'] = [0.] * len(self.tasks)
+
+        def stats(inputs, labels, clst):
+            out = self._forward_eval(inputs)
+            vals = self._val_losses(out, labels)
+            entry = dic_err['val'][clst]
+            for t in self.tasks:
+                if t != 'aux':
+                    entry[t] = vals[t]
+            entry['all'] = vals['all']
+            errs = (out[:, 2:3] - labels[:, 3:4]).abs()
+            bis = torch.exp(out[:, 3:4]) * out[:, 2:3]                           # unnormalize_bi, process.py:125-133
+            entry['bi'] = bis.mean().item()
+            entry['bi%'] = float((errs <= bis).sum()) / errs.shape[0]
+            entry['std'] = errs.std()
+            if self.mode == 'mono':
+                entry['aux'] = 0
+            else:                                                                 # get_accuracy, trainer.py:384-389
+                mask = (torch.sigmoid(out[:, 9:10]) >= 0.5).float()
+                entry['aux'] = 1. - (mask - labels[:, 10:11]).abs().mean().item()
+
         inputs, labels, _, _ = dataset[0:len(dataset)]
-        dic_err = {'val': {'all': self._val_losses(inputs, labels)}}
+        stats(inputs, labels, 'all')
+        for clst in self.clusters:
+            if clst in dataset.dic_clst and len(dataset.dic_clst[clst]['Y']):
+                c_in, c_lab, _ = dataset.get_cluster_annotations(clst)
+                stats(c_in, c_lab, clst)
+        self._close_eval_engine()
         if not (self.no_save or load):
             torch.save({k: v.clone() for k, v in self.model.state_dict().items()}, self.path_model)
         return dic_err, self.model

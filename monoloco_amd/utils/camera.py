@@ -3,9 +3,11 @@ executed by the stand-alone HIP kernels of ``csrc/geom_ops.h`` through the C ABI
 
 Each function accepts what the reference accepts (lists, numpy arrays, torch tensors) and returns
 a torch tensor on the device of its input: host inputs give CPU tensors (computed on the GPU and
-copied back), device inputs stay on the device.  There is no host arithmetic path.
+copied back), device inputs stay on the device.  There is no host arithmetic path for tensors (the one-point
+Python-list form of ``to_cartesian`` is Python doubles in the reference and here).
 """
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -41,7 +43,7 @@ def pixel_to_camera(uv_tensor, kk, z_met):
     with torch.cuda.device(dev):
         check(_lib.load().ml_pixel_to_camera(_ptr(uv), n, fptr(kinv), float(z_met), _ptr(out), _stream(dev)))
     if squeeze:
-        out = out  # the reference also returns (1,3) for a single [u, v] (F.pad keeps the batch dim)
+        out = out.reshape(3)  # reference: F.pad of a 1-D [u, v] then matmul with (3,3) -> shape (3,)
     return out.to(home)
 
 
@@ -87,19 +89,18 @@ def to_cartesian(rtp, mode=None):
     """reference camera.py:223-248.  Tensor input: mode 'x'/'y' take rows (theta, psi, r) and return
     (m,1); any other mode takes rows (r, theta, psi) and returns (m,3).  A plain [r, theta, psi] list
     returns a python list like the reference."""
-    is_list = not isinstance(rtp, torch.Tensor)
+    if not isinstance(rtp, torch.Tensor):
+        # the reference's list branch (camera.py:245-248) is three Python-double expressions on one point (dataset
+        # preparation labels); same expressions, same doubles -- not a device path
+        r, t, p = float(rtp[0]), float(rtp[1]), float(rtp[2])
+        return [r * math.sin(p) * math.cos(t), r * math.cos(p), r * math.sin(p) * math.sin(t)]
     home, dev = _home(rtp)
     t = _dev_f32(rtp, dev)
-    if is_list:
-        t = t.reshape(1, 3)
     m = t.shape[0]
     code = {'x': 0, 'y': 1}.get(mode, 2)
     out = torch.empty((m, 1) if code < 2 else (m, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.load().ml_to_cartesian(_ptr(t[:, 0:3].contiguous()), m, code if not is_list else 2, _ptr(out),
-                                          _stream(dev)))
-    if is_list:
-        return out.reshape(-1).cpu().tolist()
+        check(_lib.load().ml_to_cartesian(_ptr(t[:, 0:3].contiguous()), m, code, _ptr(out), _stream(dev)))
     return out.to(home)
 
 

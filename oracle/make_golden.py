@@ -508,3 +508,76 @@ def golden_activity():
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'activity':
     import math
     golden_activity()
+
+
+def golden_wb1024():
+    """Headline-width parity pins.
+
+    * W-B at the reference's DEFAULT width: its own fixture training at hidden 1024 (run.py:101; the recipe of
+      tests/test_train_mono.py / test_train_stereo.py: lr 0.001, -e 10 mono / -e 20 stereo, r_seed 1).  The two
+      checkpoints are committed (ckpt_{mono,stereo}_h1024.npz, exact fp32) together with the reference's outputs on
+      the 500 / 556 fixture poses, through Loco.forward and through the bare model in fp32 and fp64.
+    * The hyper-parameter-search widths 512 and 2048 (train/hyp_tuning.py:52) and a width that is not a multiple of
+      256 (the reference accepts any linear_size): seeded synthetic weights (regenerated on the GPU box by
+      tests/synth.py, checksum-pinned here), reference fp32 + fp64 outputs stored.
+    """
+    tmp = '/tmp/make_golden'
+    os.makedirs(tmp, exist_ok=True)
+    torch.set_num_threads(8)
+    g = {}
+    kk = synth.KITTI_K
+    dj = json.load(open(os.path.join(REF, 'tests', 'sample_joints-kitti-mono.json')))
+    kps = torch.tensor(dj['train']['kps'] + dj['val']['kps'])[:, 0]        # (500, 3, 17)
+    ds = json.load(open(os.path.join(REF, 'tests', 'sample_joints-kitti-stereo.json')))
+    kps_s = torch.tensor(ds['train']['kps'] + ds['val']['kps'])[:, 0]     # (556, 3, 34)
+    x_s = torch.tensor(ds['train']['X'] + ds['val']['X'])                 # (556, 68)
+    kl, kr = kps_s[:, :, :17].contiguous(), kps_s[:, :, 17:].contiguous()
+    conf = np.linspace(0.2, 1.0, len(kps)).astype(np.float32)
+
+    sd_m = np_sd(train('mono', 1024, 10, tmp))
+    sd_s = np_sd(train('stereo', 1024, 20, tmp))
+    for name, sd in (('mono', sd_m), ('stereo', sd_s)):
+        np.savez_compressed(os.path.join(OUT, 'ckpt_%s_h1024.npz' % name),
+                            **{k: v for k, v in sd.items() if not k.endswith('num_batches_tracked')})
+    with torch.no_grad():
+        x = preprocess_monoloco(kps, torch.tensor(kk))
+        net = Loco(model=ref_model(sd_m, 34, 9, 1024), mode='mono', linear_size=1024)
+        dic = net.forward(kps.tolist(), kk)
+        g['mono_raw'] = net.model(x).numpy()
+        g['mono_raw64'] = ref_model(sd_m, 34, 9, 1024, torch.float64)(
+            preprocess_monoloco(kps.double(), torch.tensor(kk, dtype=torch.float64))).numpy()
+    g.update(dic_to_np(dic, 'mono_'))
+    g['mono_xyz_pred'], g['mono_conf'] = geometry(kps, kk, dic['d'], dic['bi'], conf)
+    with torch.no_grad():
+        g['stereo_raw_fixture'] = ref_model(sd_s, 68, 10, 1024)(x_s).numpy()
+        g['stereo_raw64_fixture'] = ref_model(sd_s, 68, 10, 1024, torch.float64)(x_s.double()).numpy()
+        nl, nr = 40, 7
+        net = Loco(model=ref_model(sd_s, 68, 10, 1024), mode='stereo', linear_size=1024)
+        dic = net.forward(kl[:nl].tolist(), kk, keypoints_r=kr[:nr].tolist())
+        inputs, _ = preprocess_monstereo(kl[:nl], kr[:nr], torch.tensor(kk))
+        g['stereo_ava_raw_all'] = net.model(inputs).numpy()
+    g.update(dic_to_np(dic, 'stereo_ava_'))
+    g['stereo_ava_nl_nr'] = np.array([nl, nr])
+
+    # other widths on seeded synthetic weights: (seed, in, out, hidden)
+    for seed, in_f, out_f, hidden in ((21, 34, 9, 512), (22, 34, 9, 2048), (23, 34, 9, 600), (24, 68, 10, 200)):
+        sd = synth.make_state_dict(seed, in_f, out_f, hidden)
+        tag = 'w%d_' % hidden
+        g[tag + 'checksum'] = np.float64(synth.checksum(sd))
+        with torch.no_grad():
+            xin = x if in_f == 34 else x_s
+            g[tag + 'raw'] = ref_model(sd, in_f, out_f, hidden)(xin).numpy()
+            g[tag + 'raw64'] = ref_model(sd, in_f, out_f, hidden, torch.float64)(xin.double()).numpy()
+    np.savez_compressed(os.path.join(OUT, 'golden_wb1024.npz'), **g)
+    d = g['mono_d']
+    print('W-B-1024 mono: d %.2f..%.2f m, bi %.3f..%.3f, NaN z rows %d' %
+          (d.min(), d.max(), g['mono_bi'].min(), g['mono_bi'].max(), int(np.isnan(g['mono_xyzd'][:, 2]).sum())))
+    print('fp32-vs-fp64 noise of the reference: mono %.3e, stereo %.3e' %
+          (np.abs(g['mono_raw'] - g['mono_raw64']).max(), np.abs(g['stereo_raw_fixture'] - g['stereo_raw64_fixture']).max()))
+    for f in sorted(os.listdir(OUT)):
+        if '1024' in f:
+            print('  %-28s %8.1f KiB' % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'wb1024':
+    golden_wb1024()
