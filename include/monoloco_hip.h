@@ -39,9 +39,14 @@ extern "C" {
 /* Arithmetic of the dense layers (the MFMA kernels).
  *   ML_PREC_F16X2 : operands split into fp16 hi+lo, 3 MFMA products per term, fp32
  *                   accumulate -- fp32-class accuracy (the default; meets 1e-4 abs).
- *   ML_PREC_F16   : plain fp16 operands, 1 MFMA per term (fast, ~1e-2 abs deviation). */
+ *   ML_PREC_F16   : plain fp16 operands, 1 MFMA per term (fast, ~1e-2 abs deviation).
+ *   ML_PREC_BF16  : plain bf16 operands (v_mfma_f32_32x32x16_bf16), 1 MFMA per term -- the mode
+ *                   BASELINE configs[1] names; a COMPARISON mode (misses the 1e-4 bar by orders of
+ *                   magnitude, bench.py reports its measured deviation); tile path and plain forward only
+ *                   (no MC-dropout, no small-row kernels). */
 #define ML_PREC_F16X2 0
 #define ML_PREC_F16 1
+#define ML_PREC_BF16 2
 
 /* flags for ml_loco_finalize */
 #define ML_FLAG_MERGE_W2W3 1 /* pre-multiply w3*w2 and w_aux*w2 on the host in fp64
@@ -80,7 +85,8 @@ int ml_device_count(void);
 
 /* ---- model lifetime: stands in for Loco.__init__ (monoloco/network/net.py:30-81) --- */
 /* Shape of LocoModel (monoloco/network/architectures.py:8-46): in_features 34 (mono) or
- * 68 (stereo), hidden a multiple of 256, out_features 9 or 10 (includes the auxiliary
+ * 68 (stereo), hidden = any linear_size 1..4096 (run.py:101 default 1024; zero-padded internally to the
+ * 256-column tile), out_features 9 or 10 (includes the auxiliary
  * head, architectures.py:70), num_stage residual stages.  The legacy MonolocoModel
  * (architectures.py:105-176: the same stages followed by one Linear w2 -> out_features, 2 or 9; no w3 /
  * w_aux / w_fin keys) is recognised at ml_loco_finalize from the tensors that were fed; it runs through
@@ -254,7 +260,10 @@ int ml_loco_profile_end(ml_loco* h, int64_t* launches, double* total_ms, double*
 
 /* ---- test hooks (exercise single kernels / host packing; used by tests/ only) ------ */
 /* Dense layer on its own: y = [relu](x . W^T + b) [+ res]; x (m,k), w (n,k), b (n), res (m,n)
- * or NULL, y (m,n); all fp32 device pointers except w/b which are host.  k, n: n multiple of 256. */
+ * or NULL, y (m,n); all fp32 device pointers except w/b which are host.  k, n: n multiple of 256.
+ * The 256x256-tile kernel runs it unless ML_DEBUG_SMALL_PATH is or-ed into `precision` (then the
+ * small-row kernels the model path takes for <= 2048 rows). */
+#define ML_DEBUG_SMALL_PATH 256
 int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, const float* b_host,
                     int n, int relu, const float* res_dev, float* y_dev, int precision, void* stream);
 /* Host fp32 -> fp16 hi/lo split used by the packer (round-to-nearest-even), for unit tests. */
@@ -264,6 +273,10 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
 int ml_debug_get_layer(const ml_loco* h, int layer, float* w_host, float* b_host, int* n, int* k,
                        int* scale_pow2);
 int ml_debug_num_layers(const ml_loco* h);
+/* Process-global path selection, for tests that compare the paths (negative = leave unchanged; defaults
+ * 2048 / 128 / 0): rows <= small_rows take the small-row dense kernels, above small32_rows those use
+ * 32x32 tiles; chunk_rows > 0 walks the batch in row chunks of that size through all layers. */
+int ml_debug_set_tuning(int small_rows, int small32_rows, int chunk_rows);
 /* Packed fp16 hi|lo line image of a dense layer's weights (n * kpad * 2 uint16); only kept for
  * models finalized with ML_FLAG_HOST_ONLY. */
 int ml_debug_get_packed(const ml_loco* h, int layer, uint16_t* lines_host, int64_t capacity);

@@ -19,6 +19,8 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libmonoloco_hip.so')
 
 ML_PREC_F16X2 = 0
 ML_PREC_F16 = 1
+ML_PREC_BF16 = 2
+ML_DEBUG_SMALL_PATH = 256
 ML_FLAG_MERGE_W2W3 = 1
 ML_FLAG_HOST_ONLY = 256
 ML_OUT_STRIDE = 16
@@ -81,6 +83,7 @@ SIGNATURES = {
     'ml_debug_get_layer': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
                                    POINTER(c_int)]),
     'ml_debug_num_layers': (c_int, [_P]),
+    'ml_debug_set_tuning': (c_int, [c_int, c_int, c_int]),
     'ml_debug_get_packed': (c_int, [_P, c_int, POINTER(c_uint16), c_int64]),
     'ml_debug_get_head': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_int), POINTER(c_int)]),

@@ -66,9 +66,10 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     float c = __builtin_fminf(__builtin_fmaxf(v, -65504.0f), 65504.0f);
     hi = (_Float16)c;
-    lo = (_Float16)(v - (float)hi);
+    lo = (_Float16)(c - (float)hi);  // of the CLAMPED value: beyond the range the pair saturates at +-65504, lo = 0
 }
 
+#ifdef ML_BRINGUP  // the first-generation kernel (one tile per workgroup, one barrier per k-step): A/B reference only
 template <int NSPLIT>
 __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[DENSE_LDS];
@@ -238,5 +239,6 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel(DenseParams p) 
         __builtin_amdgcn_wave_barrier();
     }
 }
+#endif  // ML_BRINGUP
 
 }  // namespace mlk

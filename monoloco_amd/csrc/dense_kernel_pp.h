@@ -43,7 +43,16 @@
 #define ML_L_ORDER 0   // 1: in an L phase the fragment reads are issued before the DMA instructions
 #endif
 
+// bring-up / ablation bits are compiled out of release builds (make EXTRA=-DML_BRINGUP brings them back)
+#ifdef ML_BRINGUP
+#define ML_DBG(p, bit) (((p).debug & (bit)) != 0)
+#else
+#define ML_DBG(p, bit) (0)
+#endif
+
 namespace mlk {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PP_LDS = DENSE_LDS + 8 * 4096;  // 160 KiB: 2 stages + 8 x 4 KiB epilogue scratch
 
@@ -99,6 +108,29 @@ __device__ __forceinline__ void split2_res(float a0, float a1, float d, unsigned
     asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v1), "v"(h));
 }
 
+// bf16 comparison mode (NSPLIT == 0): one bf16 value in the hi slot of the line, lo slot unused
+template <bool RELU>
+__device__ __forceinline__ void bf16_2_scaled(float a0, float a1, float d, unsigned& h) {
+    float v0 = a0 * d, v1 = a1 * d;
+    if (RELU) {
+        v0 = __builtin_fmaxf(v0, 0.0f);
+        v1 = __builtin_fmaxf(v1, 0.0f);
+    }
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(v0), "v"(v1));
+}
+template <bool RELU>
+__device__ __forceinline__ void bf16_2_res(float a0, float a1, float d, unsigned rh, unsigned& h) {
+    float c0 = a0, c1 = a1;
+    if (RELU) {
+        c0 = __builtin_fmaxf(c0, 0.0f);
+        c1 = __builtin_fmaxf(c1, 0.0f);
+    }
+    const float v0 = __builtin_fmaf(c0, d, __builtin_bit_cast(float, rh << 16));
+    const float v1 = __builtin_fmaf(c1, d, __builtin_bit_cast(float, rh & 0xffff0000u));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(v0), "v"(v1));
+}
+
+// NSPLIT: 3 = fp16 hi+lo operands, three products per term (the product mode); 1 = plain fp16; 0 = plain bf16
 template <int NSPLIT, bool RELU, bool RES, int HEAD>
 __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
@@ -115,8 +147,8 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
     const int q = ntiles >> 3, r8 = ntiles & 7;
     const size_t rowb = (size_t)p.K * 4;
     const size_t yrowb = (size_t)p.N * 4;
-    const int nk = (p.debug & 2) ? 0 : p.K / 32;
-    const bool loads = !(p.debug & 4);
+    const int nk = ML_DBG(p, 2) ? 0 : p.K / 32;
+    const bool loads = !ML_DBG(p, 4);
     const float lim = 65504.0f / p.descale;  // fp16 range in the accumulator's scale (descale is a power of two)
 
     // ---- LDS-DMA duty: per stage a wave fetches 32 rows of X and 32 rows of W (4 instructions of 8
@@ -136,7 +168,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             if (q4 < qa || q4 >= qb) continue;
-            if ((p.debug & 64) && q4 >= 2) break;
+            if (ML_DBG(p, 64) && q4 >= 2) break;
             glds16(src + ((q4 & 1) ? goff_o : goff_e) + q4 * row8, sb + q4 * 8 * LINE);
         }
     };
@@ -302,7 +334,11 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
                         acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[it], xlo[jt], acc[it][jt], 0, 0, 0);
                         acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[it], xhi[jt], acc[it][jt], 0, 0, 0);
                     }
-                    acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[it], xhi[jt], acc[it][jt], 0, 0, 0);
+                    if (NSPLIT == 0)
+                        acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, whi[it]),
+                                                                              __builtin_bit_cast(bf16x8, xhi[jt]), acc[it][jt], 0, 0, 0);
+                    else
+                        acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[it], xhi[jt], acc[it][jt], 0, 0, 0);
                 }
             if (ML_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
         };
@@ -424,12 +460,12 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
         const int rd_off = (elane >> 3) * LINE + (((elane & 7) ^ ((elane >> 3) & 7)) * 16);  // + qq*1024
         auto fetch_res = [&](int pass) {
             // debug bit 16 (timing only): every tile reads the residual of the first row panel -> L2 resident
-            const char* src = p.res + ((p.debug & 16) ? (line0_of(pass) % ((size_t)BM * yrowb)) : line0_of(pass));
+            const char* src = p.res + (ML_DBG(p, 16) ? (line0_of(pass) % ((size_t)BM * yrowb)) : line0_of(pass));
             char* dst = resbuf + (pass & 1) * 4096;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) glds16(src + (size_t)(qq * 8) * yrowb + res_goff, dst + qq * 1024);
         };
-        const bool has_res = RES && !(p.debug & 1);
+        const bool has_res = RES && !ML_DBG(p, 1);
         if (has_res) fetch_res(0);  // ahead of the next tile's DMA so that it does not queue behind it
         if (HEAD > 0) {
             // this wave's slice of the head weights, hw[o][128] = head_w[o][nbase .. nbase+127].  Rows 0..7 live
@@ -467,7 +503,7 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
             }
         }
 
-        if (p.debug & 1) {
+        if (ML_DBG(p, 1)) {
             float s = 0.f;
 #pragma unroll
             for (int it = 0; it < 4; ++it)
@@ -547,7 +583,11 @@ __global__ __launch_bounds__(DENSE_THREADS, 2) void dense_kernel_pp(DenseParams 
                     for (int e2 = 0; e2 < 2; ++e2) {
                         const float a0 = acc[it][jt][g * 4 + 2 * e2], a1 = acc[it][jt][g * 4 + 2 * e2 + 1];
                         unsigned hh, ll;
-                        if (RES) split2_res<RELU>(a0, a1, p.descale, rh[g][e2], rl[g][e2], hh, ll);
+                        if (NSPLIT == 0) {
+                            ll = 0u;
+                            if (RES) bf16_2_res<RELU>(a0, a1, p.descale, rh[g][e2], hh);
+                            else bf16_2_scaled<RELU>(a0, a1, p.descale, hh);
+                        } else if (RES) split2_res<RELU>(a0, a1, p.descale, rh[g][e2], rl[g][e2], hh, ll);
                         else split2_scaled<RELU>(a0, a1, p.descale, lim, hh, ll);
                         oh[g][e2] = hh;
                         ol[g][e2] = ll;

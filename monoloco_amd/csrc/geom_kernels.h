@@ -142,8 +142,12 @@ __global__ __launch_bounds__(256) void f32_to_lines_kernel(const float* __restri
 }
 
 // line format (m_pad, n) -> fp32 (m, n): value = hi + lo.  One thread per 8 values.
+__device__ __forceinline__ float bf16_bits_to_f32(_Float16 hslot) {
+    return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, hslot) << 16);
+}
+
 __global__ __launch_bounds__(256) void lines_to_f32_kernel(const char* __restrict__ lines, int64_t m, int n,
-                                                          float* __restrict__ y) {
+                                                          float* __restrict__ y, int bf16) {
     const int gpr = n / 8;  // groups of 8 values per row
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= m * gpr) return;
@@ -154,7 +158,29 @@ __global__ __launch_bounds__(256) void lines_to_f32_kernel(const char* __restric
     const half8 hi = *(const half8*)p;
     const half8 lo = *(const half8*)(p + 64);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) y[row * n + b * 32 + sub * 8 + e] = (float)hi[e] + (float)lo[e];
+    for (int e = 0; e < 8; ++e)
+        y[row * n + b * 32 + sub * 8 + e] = bf16 ? bf16_bits_to_f32(hi[e]) : (float)hi[e] + (float)lo[e];
+}
+
+// bf16 comparison mode: fp16 hi|lo lines -> one bf16 (round-to-nearest-even of hi + lo) in the hi slot, lo slot
+// zeroed, in place.  One thread per (line, 16-byte hi chunk): `pairs` = lines * 4.
+__global__ __launch_bounds__(256) void lines_to_bf16_kernel(char* __restrict__ lines, int64_t pairs) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= pairs) return;
+    char* p = lines + (id >> 2) * LINE + (id & 3) * 16;
+    const half8 hi = *(const half8*)p;
+    const half8 lo = *(const half8*)(p + 64);
+    half8 o, z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = (float)hi[e] + (float)lo[e];
+        unsigned x = __builtin_bit_cast(unsigned, v);
+        x += 0x7fffu + ((x >> 16) & 1u);  // round to nearest even (inputs are finite)
+        o[e] = __builtin_bit_cast(_Float16, (unsigned short)(x >> 16));
+        z[e] = (_Float16)0.0f;
+    }
+    *(half8*)p = o;
+    *(half8*)(p + 64) = z;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -210,7 +236,7 @@ template <int NH>
 __global__ __launch_bounds__(256) void heads_kernel(const char* __restrict__ act, int H,
                                                     const float* __restrict__ wh, const float* __restrict__ bh,
                                                     float* __restrict__ raw, int raw_stride, int col0,
-                                                    int64_t m) {
+                                                    int64_t m, int bf16) {
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     float* s_w = (float*)dyn_smem;  // [NH][H]
     for (int i = threadIdx.x; i < NH * H; i += 256) s_w[i] = wh[i];
@@ -237,7 +263,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const char* __restrict__ act
                 const half8 hi = *(const half8*)p;
                 const half8 lo = *(const half8*)(p + 64);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xv[r][e] = (float)hi[e] + (float)lo[e];
+                for (int e = 0; e < 8; ++e) xv[r][e] = bf16 ? bf16_bits_to_f32(hi[e]) : (float)hi[e] + (float)lo[e];
             }
 #pragma unroll
             for (int o = 0; o < NH; ++o) {

@@ -97,12 +97,21 @@ float f16_bits_to_f32(uint16_t h) {
     return f;
 }
 
+// fp32 -> bf16 bits, round-to-nearest-even (what v_cvt_pk_bf16_f32 does on the device)
+uint16_t f32_to_bf16_bits(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x40u);  // quiet NaN
+    x += 0x7fffu + ((x >> 16) & 1u);
+    return (uint16_t)(x >> 16);
+}
+
 void split_host(float v, uint16_t& hi, uint16_t& lo) {
     float c = v;
     if (c > 65504.0f) c = 65504.0f;
     if (c < -65504.0f) c = -65504.0f;
     hi = f32_to_f16_bits(c);
-    lo = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+    lo = f32_to_f16_bits(c - f16_bits_to_f32(hi));
 }
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
@@ -283,6 +292,10 @@ void pack_layer(int precision, DenseLayer& L) {
             uint16_t hi, lo;
             split_host(L.w[(size_t)i * L.k + j] * sc, hi, lo);
             const int b = j >> 5, o = j & 31;
+            if (precision == ML_PREC_BF16) {  // one bf16 value in the hi slot (the scale is a power of two: exact)
+                hi = f32_to_bf16_bits(L.w[(size_t)i * L.k + j] * sc);
+                lo = 0;
+            }
             row[b * 64 + o] = hi;
             row[b * 64 + 32 + o] = (precision == ML_PREC_F16X2) ? lo : 0;
         }
@@ -361,6 +374,9 @@ mlk::Kinv make_kinv(const float* k) {
     return ki;
 }
 
+// ---- bring-up knobs.  Release builds have none: no getenv in a hot call, no debug branch in the kernels, no
+// first-generation kernel.  `make EXTRA=-DML_BRINGUP` compiles them back in (tools/gpu_exp1.sh, trace_summary.py).
+#ifdef ML_BRINGUP
 int dense_debug_bits() {
     static int bits = -1;
     if (bits < 0) {
@@ -369,10 +385,8 @@ int dense_debug_bits() {
     }
     return bits;
 }
-
 int dense_variant() {
-    // ML_DENSE_VARIANT=1 selects the first-generation kernel (one tile per workgroup, one barrier
-    // per k-step); default is the persistent ping-pong kernel.
+    // ML_DENSE_VARIANT=1 selects the first-generation kernel (one tile per workgroup, one barrier per k-step)
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("ML_DENSE_VARIANT");
@@ -380,6 +394,10 @@ int dense_variant() {
     }
     return v;
 }
+#else
+constexpr int dense_debug_bits() { return 0; }
+constexpr int dense_variant() { return 2; }
+#endif
 
 int num_cus() {
     static int n = 0;
@@ -393,6 +411,7 @@ int num_cus() {
     return n;
 }
 
+#ifdef ML_BRINGUP
 // ML_DENSE_TRACE=<file>: every pp dense launch records per-wave s_memtime stamps, which are appended
 // to the file after a stream sync (bring-up tool; serialises the stream).
 int trace_after_launch(unsigned long long* buf, size_t n, int grid, const mlk::DenseParams& p, hipStream_t st) {
@@ -409,21 +428,20 @@ int trace_after_launch(unsigned long long* buf, size_t n, int grid, const mlk::D
     return ML_OK;
 }
 
-int small_rows_env() {
-    // rows <= ML_SMALL_ROWS take dense_small_kernel (16x16 output tiles, no LDS staging) instead of the
-    // 256x256-tile persistent kernel; 0 disables the small path
-    const char* e = getenv("ML_SMALL_ROWS");  // read per call (cheap) so that tests can switch paths in-process
-    const int v = e ? atoi(e) : 2048;
-    return v < 0 ? 0 : v;
-}
+#endif
 
-int small32_rows_env() {
-    const char* e = getenv("ML_SMALL32_ROWS");  // above this row count the small path uses 32x32 tiles
-    const int v = e ? atoi(e) : 128;
-    return v < 0 ? 0 : v;
-}
+// Path selection (process-global; ml_debug_set_tuning is the only writer -- tests switch paths through it):
+//   rows <= g_small_rows take the small-row dense kernels (no LDS staging) instead of the 256x256-tile persistent
+//   kernel; above g_small32_rows those use 32x32 output tiles (16x16 below); g_chunk_rows > 0 walks the batch in row
+//   chunks through all layers (Infinity-Cache residency experiment, off by default).
+int g_small_rows = 2048, g_small32_rows = 128, g_chunk_rows = 0;
+int small_rows_env() { return g_small_rows; }
+int small32_rows_env() { return g_small32_rows; }
 
-bool use_small_path(int64_t rows) { return dense_variant() != 1 && !dense_debug_bits() && rows <= small_rows_env(); }
+bool use_small_path(int precision, int64_t rows) {
+    // (the bf16 comparison mode exists on the tile path only)
+    return dense_variant() != 1 && !dense_debug_bits() && precision != ML_PREC_BF16 && rows <= small_rows_env();
+}
 
 int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0, int64_t rows = -1) {
     mlk::DenseParams p = p_in;
@@ -461,20 +479,24 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, in
     }
 
     const int tiles = (p.M_pad / mlk::BM) * (p.N / mlk::BN);
+#ifdef ML_BRINGUP
     if (dense_variant() == 1) {
         if (precision == ML_PREC_F16X2)
             hipLaunchKernelGGL(mlk::dense_kernel<3>, dim3(tiles), dim3(mlk::DENSE_THREADS), 0, st, p);
         else
             hipLaunchKernelGGL(mlk::dense_kernel<1>, dim3(tiles), dim3(mlk::DENSE_THREADS), 0, st, p);
-    } else {
-        const int grid = tiles < num_cus() ? tiles : num_cus();
-        static unsigned long long* trace_buf = nullptr;
-        const size_t trace_n = (size_t)num_cus() * 8 * 64;
-        if (getenv("ML_DENSE_TRACE")) {
-            if (!trace_buf) HIP_TRY(hipMalloc((void**)&trace_buf, trace_n * 8));
-            HIP_TRY(hipMemsetAsync(trace_buf, 0, trace_n * 8, st));
-            p.trace = trace_buf;
-        }
+        HIP_TRY(hipGetLastError());
+        return ML_OK;
+    }
+    static unsigned long long* trace_buf = nullptr;
+    const size_t trace_n = (size_t)num_cus() * 8 * 64;
+    if (getenv("ML_DENSE_TRACE")) {
+        if (!trace_buf) HIP_TRY(hipMalloc((void**)&trace_buf, trace_n * 8));
+        HIP_TRY(hipMemsetAsync(trace_buf, 0, trace_n * 8, st));
+        p.trace = trace_buf;
+    }
+#endif
+    const int grid = tiles < num_cus() ? tiles : num_cus();
 #define ML_PP(NS, RL, RS, HD) \
     hipLaunchKernelGGL((mlk::dense_kernel_pp<NS, RL, RS, HD>), dim3(grid), dim3(mlk::DENSE_THREADS), 0, st, p)
 #define ML_PP_NS(NS)                                              \
@@ -489,18 +511,20 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, in
             else ML_PP(NS, false, false, 0);                      \
         }                                                         \
     } while (0)
-        if (precision == ML_PREC_F16X2) ML_PP_NS(3);
-        else ML_PP_NS(1);
+    if (precision == ML_PREC_F16X2) ML_PP_NS(3);
+    else if (precision == ML_PREC_F16) ML_PP_NS(1);
+    else ML_PP_NS(0);  // ML_PREC_BF16
 #undef ML_PP_NS
 #undef ML_PP
-        if (p.trace) return trace_after_launch(trace_buf, trace_n, grid, p, st);
-    }
+#ifdef ML_BRINGUP
+    if (p.trace) return trace_after_launch(trace_buf, trace_n, grid, p, st);
+#endif
     HIP_TRY(hipGetLastError());
     return ML_OK;
 }
 
 int launch_heads(const Head& hd, const char* act, int H, float* raw, int raw_stride, int64_t m,
-                 hipStream_t st) {
+                 hipStream_t st, int bf16 = 0) {
     const size_t lds = (size_t)hd.nh * H * 4;
     int64_t nquads = (m + 3) / 4;
     int grid = (int)((nquads + 3) / 4);
@@ -512,7 +536,7 @@ int launch_heads(const Head& hd, const char* act, int H, float* raw, int raw_str
             HIP_TRY(hipFuncSetAttribute((const void*)mlk::heads_kernel<NH>,                          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL(mlk::heads_kernel<NH>, dim3(grid), dim3(256), lds, st, act, H, hd.d_w,    \
-                           hd.d_b, raw, raw_stride, hd.col0, m);                                     \
+                           hd.d_b, raw, raw_stride, hd.col0, m, bf16);                               \
         break;
     switch (hd.nh) {
         ML_HEADS(1)
@@ -528,15 +552,7 @@ int launch_heads(const Head& hd, const char* act, int H, float* raw, int raw_str
     return ML_OK;
 }
 
-int chunk_rows_env() {
-    // ML_CHUNK_ROWS=n (multiple of 256): walk the batch in row chunks through ALL layers so that the
-    // two activation buffers of a chunk (2 x n x hidden x 4 B) stay resident in the 256 MiB Infinity
-    // Cache between layers.  0 = whole batch per layer.
-    const char* e = getenv("ML_CHUNK_ROWS");  // read per call so that tests can switch it in-process
-    int v = e ? atoi(e) : 0;
-    if (v < 0) v = 0;
-    return v / 256 * 256;
-}
+int chunk_rows_env() { return g_chunk_rows / 256 * 256; }
 
 // Runs the dense chain + heads on `rows` network rows whose line-format input already sits in
 // buf[0]; leaves raw (rows, out_f) fp32 in raw_out.
@@ -551,7 +567,15 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
     const int64_t m_pad_all = round_up64(rows, 256);
     // (row chunking is an inference experiment knob; the batched MC-dropout passes index their masks by global row)
     const int64_t chunk = (chunk_rows_env() > 0 && mc.p <= 0.f) ? chunk_rows_env() : m_pad_all;
-    const bool small = use_small_path(rows);  // decided on the whole call, not per chunk
+    const bool small = use_small_path(h->precision, rows);  // decided on the whole call, not per chunk
+    if (h->precision == ML_PREC_BF16) {
+        // the pre-process kernels write fp16 hi|lo lines; the bf16 comparison mode re-rounds them once (hi + lo -> one
+        // bf16 in the hi slot, 16 B per row chunk; 17 MB at 65536 rows -- < 0.5 % of a step, counted in its time)
+        if (mc.p > 0.f) return fail(ML_ERR_ARG, "MC-dropout is not available in the bf16 comparison mode");
+        const int64_t pairs = m_pad_all * (int64_t)(h->k0pad / 32) * 4;
+        hipLaunchKernelGGL(mlk::lines_to_bf16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, h->buf[0], pairs);
+        HIP_TRY(hipGetLastError());
+    }
     for (int64_t r0 = 0; r0 < m_pad_all; r0 += chunk) {
         const int64_t m_pad = (m_pad_all - r0 < chunk) ? (m_pad_all - r0) : chunk;
         const int64_t rows_here = (rows - r0 < m_pad) ? (rows - r0) : m_pad;
@@ -635,7 +659,8 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             } else if (rows_here > 0) {
                 for (const Head& hd : h->heads)
                     if (hd.after_layer == (int)li && &hd != fused) {
-                        rc = launch_heads(hd, at(hd.src), h->hidden, raw_out + r0 * h->out_f, h->out_f, rows_here, st);
+                        rc = launch_heads(hd, at(hd.src), h->hidden, raw_out + r0 * h->out_f, h->out_f, rows_here, st,
+                                          h->precision == ML_PREC_BF16);
                         if (rc) return rc;
                     }
             }
@@ -701,7 +726,8 @@ int ml_loco_set_tensor(ml_loco* h, const char* key, const float* host_data, int6
 int ml_loco_finalize(ml_loco* h, int precision, int flags) {
     if (!h) return fail(ML_ERR_ARG, "null model handle");
     if (h->finalized) return fail(ML_ERR_STATE, "model already finalized");
-    if (precision != ML_PREC_F16X2 && precision != ML_PREC_F16) return fail(ML_ERR_ARG, "unknown precision %d", precision);
+    if (precision != ML_PREC_F16X2 && precision != ML_PREC_F16 && precision != ML_PREC_BF16)
+        return fail(ML_ERR_ARG, "unknown precision %d", precision);
     h->precision = precision;
     h->flags = flags;
     h->host_only = (flags & ML_FLAG_HOST_ONLY) != 0;
@@ -1047,7 +1073,7 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
     const mlk::Kinv ki = make_kinv(kinv_host);
     // the small-row dense kernels read whole 32-row tiles only: no need to zero-fill up to the 256-row panel
     hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(m_pad / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
-                       (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, use_small_path(m) ? round_up64(m, 32) : m_pad, 0);
+                       (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, use_small_path(h->precision, m) ? round_up64(m, 32) : m_pad, 0);
     HIP_TRY(hipGetLastError());
     float* raw = raw_dev ? raw_dev : h->d_raw;
     if ((rc = run_network(h, m, raw, st))) return rc;
@@ -1175,6 +1201,14 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
     return ML_OK;
 }
 
+int ml_debug_set_tuning(int small_rows, int small32_rows, int chunk_rows) {
+    // negative = keep; the defaults are 2048 / 128 / 0
+    if (small_rows >= 0) g_small_rows = small_rows;
+    if (small32_rows >= 0) g_small32_rows = small32_rows;
+    if (chunk_rows >= 0) g_chunk_rows = chunk_rows;
+    return ML_OK;
+}
+
 int ml_debug_num_layers(const ml_loco* h) { return h ? (int)h->layers.size() : 0; }
 
 int ml_debug_get_layer(const ml_loco* h, int layer, float* w_host, float* b_host, int* n, int* k, int* scale_pow2) {
@@ -1214,6 +1248,10 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
                     const float* res_dev, float* y_dev, int precision, void* stream) {
     if (!x_dev || !w_host || !b_host || !y_dev || m <= 0 || k <= 0 || n <= 0 || n % 256 != 0)
         return fail(ML_ERR_ARG, "bad argument (n must be a multiple of 256)");
+    // the tile kernel unless ML_DEBUG_SMALL_PATH is or-ed into `precision` (then the small-row kernels, any m)
+    const bool small_path = (precision & ML_DEBUG_SMALL_PATH) != 0;
+    precision &= ~ML_DEBUG_SMALL_PATH;
+    if (small_path && precision == ML_PREC_BF16) return fail(ML_ERR_ARG, "the bf16 mode has no small-row kernels");
     hipStream_t st = (hipStream_t)stream;
     ml_loco tmp;
     tmp.precision = precision;
@@ -1256,11 +1294,19 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
         p.trace = nullptr;
         p.head_w = nullptr;
         p.head_part = nullptr;
-        rc = launch_dense(precision, p, st);
+        if (precision == ML_PREC_BF16) {
+            int64_t pairs = m_pad * (int64_t)(L.kpad / 32) * 4;
+            hipLaunchKernelGGL(mlk::lines_to_bf16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, xl, pairs);
+            if (res_dev) {
+                pairs = m_pad * (int64_t)(n / 32) * 4;
+                hipLaunchKernelGGL(mlk::lines_to_bf16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, rl, pairs);
+            }
+        }
+        rc = launch_dense(precision, p, st, 0, small_path ? m : -1);
         if (!rc) {
             const int64_t groups = m * (n / 8);
             hipLaunchKernelGGL(mlk::lines_to_f32_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, p.y, m,
-                               n, y_dev);
+                               n, y_dev, precision == ML_PREC_BF16 ? 1 : 0);
             if (hipGetLastError() != hipSuccess) rc = fail(ML_ERR_HIP, "lines_to_f32 launch failed");
         }
         if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(ML_ERR_HIP, "debug_linear: stream sync failed");

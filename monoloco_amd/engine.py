@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import MonolocoHipError, check, fptr
 
-PRECISIONS = {'f16x2': _lib.ML_PREC_F16X2, 'f16': _lib.ML_PREC_F16}
+PRECISIONS = {'f16x2': _lib.ML_PREC_F16X2, 'f16': _lib.ML_PREC_F16, 'bf16': _lib.ML_PREC_BF16}
 
 
 def _require_cuda(device):
@@ -174,8 +174,13 @@ def laplace_sampling_device(mu_b, n_samples, seed=1):
     return out
 
 
-def debug_linear(x, w, b, relu=False, res=None, precision='f16x2'):
-    """Single dense layer through the MFMA kernel (test hook)."""
+def set_tuning(small_rows=-1, small32_rows=-1, chunk_rows=-1):
+    """Path-selection thresholds of the library (test hook, process-global; negative = unchanged)."""
+    check(_lib.load().ml_debug_set_tuning(int(small_rows), int(small32_rows), int(chunk_rows)))
+
+
+def debug_linear(x, w, b, relu=False, res=None, precision='f16x2', small_path=False):
+    """Single dense layer through the MFMA kernel (test hook): the tile kernel, or the small-row kernels."""
     lib = _lib.load()
     dev = _require_cuda(x.device)
     x = _dev_f32(x, dev)
@@ -186,7 +191,7 @@ def debug_linear(x, w, b, relu=False, res=None, precision='f16x2'):
     res = _dev_f32(res, dev) if res is not None else None
     with torch.cuda.device(dev):
         check(lib.ml_debug_linear(_ptr(x), x.shape[0], k, fptr(w), fptr(b), n, int(bool(relu)), _ptr(res), _ptr(y),
-                                  PRECISIONS[precision], _stream(dev)))
+                                  PRECISIONS[precision] | (_lib.ML_DEBUG_SMALL_PATH if small_path else 0), _stream(dev)))
     return y
 
 

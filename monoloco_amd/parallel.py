@@ -39,28 +39,37 @@ def init_from_env(backend=None):
 
 
 class RowGather:
-    """Pre-allocated gather of per-rank (rows_r, width) blocks to rank `dst`, in rank order."""
+    """Pre-allocated gather of per-rank (rows_r, width) blocks to rank `dst`, in rank order.
 
-    def __init__(self, total_rows, width, device, dtype=torch.float32, dst=0, group=None):
+    ``mode='gather'`` (default): direct all-to-one, only rank `dst` holds the result.  ``mode='all_gather'``: one
+    ``all_gather_into_tensor`` on equal shards -- every rank ends up with the full block (7x the traffic, but a
+    single fused RCCL kernel; bench.py --gather all_gather times it against the default)."""
+
+    def __init__(self, total_rows, width, device, dtype=torch.float32, dst=0, group=None, mode='gather'):
+        assert mode in ('gather', 'all_gather')
         self.group = group
         self.dst = dst
+        self.mode = mode
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bounds = [shard_bounds(total_rows, self.world, r) for r in range(self.world)]
         self.full = None
         self.parts = None
-        if self.rank == dst:
-            self.full = torch.empty((total_rows, width), dtype=dtype, device=device)
-            self.parts = [self.full[lo:hi] for lo, hi in self.bounds]
         equal = len({hi - lo for lo, hi in self.bounds}) == 1
         self._equal = equal
+        self._all = mode == 'all_gather' and equal and dist.is_initialized()   # ragged shards fall back to the p2p gather
+        if self.rank == dst or self._all:
+            self.full = torch.empty((total_rows, width), dtype=dtype, device=device)
+            self.parts = [self.full[lo:hi] for lo, hi in self.bounds]
 
     def __call__(self, local_block):
         """Collective: returns the (total_rows, width) tensor on rank dst, None elsewhere."""
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             self.full.copy_(local_block)
             return self.full
-        if self._equal:
+        if self._all:
+            dist.all_gather_into_tensor(self.full, local_block.contiguous(), group=self.group)
+        elif self._equal:
             dist.gather(local_block, gather_list=self.parts if self.rank == self.dst else None, dst=self.dst,
                         group=self.group)
         else:  # ragged shards: point-to-point (gather needs equal sizes)
@@ -83,11 +92,11 @@ class ShardedRows:
     caller-supplied function computes the local (hi - lo, width) block -- no communication -- and ONE gather brings
     the blocks to rank ``dst`` in row order.  bench.py and the gloo tests drive the same class."""
 
-    def __init__(self, total_rows, width, device, dtype=torch.float32, dst=0, group=None):
+    def __init__(self, total_rows, width, device, dtype=torch.float32, dst=0, group=None, mode='gather'):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.lo, self.hi = shard_bounds(total_rows, self.world, self.rank)
-        self.gather = RowGather(total_rows, width, device, dtype=dtype, dst=dst, group=group)
+        self.gather = RowGather(total_rows, width, device, dtype=dtype, dst=dst, group=group, mode=mode)
 
     @property
     def local_rows(self):

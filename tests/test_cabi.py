@@ -26,8 +26,10 @@ def test_header_symbols_exported_and_bound(hip_lib):
 def test_version_and_error_string(hip_lib):
     assert hip_lib.ml_version() >= 100
     h = ctypes.c_void_p()
-    assert hip_lib.ml_loco_create(34, 1000, 9, 3, ctypes.byref(h)) == 4          # ML_ERR_SHAPE
-    assert b'multiple of 256' in hip_lib.ml_last_error()
+    assert hip_lib.ml_loco_create(34, 5000, 9, 3, ctypes.byref(h)) == 4          # ML_ERR_SHAPE
+    assert b'hidden size 5000 unsupported' in hip_lib.ml_last_error()
+    assert hip_lib.ml_loco_create(34, 1000, 9, 3, ctypes.byref(h)) == 0          # any linear_size: padded to the tile
+    assert hip_lib.ml_loco_destroy(h) == 0
     assert hip_lib.ml_loco_create(34, 256, 9, 3, None) == 1                      # ML_ERR_ARG
     assert hip_lib.ml_loco_create(34, 256, 9, 3, ctypes.byref(h)) == 0
     assert hip_lib.ml_loco_finalize(h, 0, _lib.ML_FLAG_HOST_ONLY) == 3           # tensors missing: ML_ERR_STATE

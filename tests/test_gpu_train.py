@@ -93,8 +93,8 @@ def test_dropout_training_runs_and_learns(hip_lib, cuda_device):
     tr.close()
 
 
-@pytest.mark.parametrize("mode", ["mono", "stereo"])
-def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path, mode):
+@pytest.mark.parametrize("mode,hidden", [("mono", 256), ("stereo", 256), ("mono", 200)])
+def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path, mode, hidden):
     """The reference's test flow (tests/test_train_mono.py:42-50, test_train_stereo.py): train on the sample joints,
     save a checkpoint, load it into Loco and predict."""
     import json
@@ -111,18 +111,34 @@ def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path
         n = len(g[mode + '_x' + tag])
         joints[ph] = {'X': g[mode + '_x' + tag].tolist(), 'Y': g[mode + '_y' + tag].tolist(), 'names': ['x.png'] * n,
                       'kps': kps_all[:n].tolist(), 'K': [], 'clst': {}}
+        # distance clusters as the reference's dataset preparation stores them (prep/preprocess_kitti.py: '10'..'40', '>40')
+        yy = g[mode + '_y' + tag]
+        for name, lo, hi in (('10', 0, 10), ('20', 10, 20), ('30', 20, 30), ('40', 30, 1e9)):
+            sel = (yy[:, 3] >= lo) & (yy[:, 3] < hi)
+            joints[ph]['clst'][name] = {'X': g[mode + '_x' + tag][sel].tolist(), 'Y': yy[sel].tolist()}
     path = tmp_path / 'joints.json'
     path.write_text(json.dumps(joints))
     out = str(tmp_path / 'model.pkl')
     args = argparse.Namespace(mode=mode, joints=str(path), epochs=4, no_save=False, lr=0.001, sched_step=30, sched_gamma=0.98,
-                              hidden_size=256, n_stage=3, r_seed=1, out=out, bs=512, dropout=0.2)
+                              hidden_size=hidden, n_stage=3, r_seed=1, out=out, bs=512, dropout=0.2)
     tr = Trainer(args)
     tr.train()
     dic_err, model = tr.evaluate()
-    assert os.path.exists(out) and 'd' in dic_err['val']['all']
+    assert os.path.exists(out)
+    # reference trainer.py:197-246: per-task errors, bi statistics, per-cluster entries, model returned in eval mode
+    all_ = dic_err['val']['all']
+    assert all(k in all_ for k in ('d', 'x', 'y', 'h', 'w', 'l', 'ori', 'bi', 'bi%', 'std', 'aux', 'all'))
+    assert np.isfinite(all_['d']) and all_['d'] > 0 and 0 <= all_['bi%'] <= 1
+    assert any(c in dic_err['val'] for c in ('10', '20', '30', '40'))
+    assert model.training is False
+    x_val = torch.tensor(g[mode + '_xval'][:5])
+    assert model(x_val).shape == (5, 9 if mode == 'mono' else 10)      # callers such as hyp_tuning call the returned model
+    # every epoch recorded a validation value (never the silent 0.0 that froze best_wts at epoch 0)
+    assert len(tr.epoch_losses['val']['d']) == 4 and all(v > 0 for v in tr.epoch_losses['val']['d'])
+    assert len(tr.epoch_losses['val']['all']) == 4
     losses = tr.epoch_losses['train']['loss']
     assert len(losses) == 4 and losses[-1] < losses[0]
-    net = Loco(model=out, mode=mode, device=cuda_device, linear_size=256)
+    net = Loco(model=out, mode=mode, device=cuda_device, linear_size=hidden)
     if mode == 'mono':
         dic = net.forward(gp['mono_kps'][:8].tolist(), synth.KITTI_K)
     else:

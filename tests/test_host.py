@@ -114,8 +114,10 @@ def test_f16_split_matches_numpy(hip_lib):
                                    dtype=np.float32)])
     hi, lo = _split(hip_lib, x)
     with np.errstate(over='ignore'):
-        hi_ref = np.clip(x, -65504, 65504).astype(np.float16)
-        lo_ref = (x - hi_ref.astype(np.float32)).astype(np.float16)
+        xc = np.clip(x, -65504, 65504)                    # the pair saturates: lo is taken from the CLAMPED value
+        hi_ref = xc.astype(np.float16)
+        lo_ref = (xc - hi_ref.astype(np.float32)).astype(np.float16)
+    assert np.isfinite(lo.astype(np.float32)).all()
     assert np.array_equal(hi.view(np.uint16), hi_ref.view(np.uint16))
     assert np.array_equal(lo.view(np.uint16), lo_ref.view(np.uint16))
     ok = np.abs(x) < 6e4
@@ -155,19 +157,25 @@ def _head(lib, h, hi, hidden):
     return w, b, c0.value, sb.value, al.value
 
 
-@pytest.mark.parametrize("merge", [True, False])
-def test_fold_merge_pack_emulated_forward(hip_lib, merge):
+@pytest.mark.parametrize("merge,hidden", [(True, 256), (False, 256), (True, 200), (False, 300)])
+def test_fold_merge_pack_emulated_forward(hip_lib, merge, hidden):
     """Fold + merge + pack in the library (host only), then emulate the kernels' arithmetic in numpy from
     the PACKED fp16 hi|lo images (3 products per term) and compare with the oracle: validates the
     whole host-side weight preparation and the precision design without a GPU."""
     from oracle import monoloco_oracle as O
-    hidden = 256
     sd = synth.make_state_dict(5, 34, 9, hidden)
     h = _host_model(hip_lib, sd, 34, 9, hidden, _lib.ML_FLAG_MERGE_W2W3 if merge else 0)
     nl = hip_lib.ml_debug_num_layers(h)
     assert nl == (8 if merge else 9)
     layers = [_layer(hip_lib, h, i) for i in range(nl)]
-    heads = [_head(hip_lib, h, i, hidden) for i in range(2)]
+    # any linear_size runs on 256-column tiles: zero weights/bias in the padded rows and columns
+    hp = (hidden + 255) // 256 * 256
+    assert layers[0][0].shape == (hp, 34) and layers[1][0].shape == (hp, hp)
+    if hp != hidden:
+        for w, b, _, _ in layers:
+            assert not w[hidden:].any() and not b[hidden:].any() and (w.shape[1] == 34 or not w[:, hidden:].any())
+    heads = [_head(hip_lib, h, i, hp) for i in range(2)]
+    assert all(not hd[0][:, hidden:].any() for hd in heads)
     kps = torch.tensor(synth.make_poses(200, 3))
     ref = O.forward_mono({k: torch.tensor(v) for k, v in sd.items()}, kps, synth.KITTI_K)
     ref64 = O.forward_mono({k: torch.tensor(v) for k, v in sd.items()}, kps, synth.KITTI_K, dtype=torch.float64)

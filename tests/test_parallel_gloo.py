@@ -104,3 +104,81 @@ def test_bench_timing_contract_gloo():
     assert n0 == n1 == 7 and marks0 == marks1 == [2] and e0 == e1 == 'done'   # 2 warm-up + 5 timed, begin() after warm-up
     assert dt0 == dt1                                                           # every rank reports the MAX
     assert 5 * 0.02 <= dt0 < 5 * 0.02 + 0.5                                     # the slow rank's 5 x 20 ms
+
+
+def _stereo_worker(rank, world, port, q):
+    """Stereo shards by LEFT person: each rank runs the all-vs-all pairing of ITS left persons against
+    ALL right persons, the per-left arg-max over the aux logit stays local, one gather of the (ml, 5) block."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    import synth
+    from oracle import monoloco_oracle as O
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env('gloo')
+    torch.set_num_threads(1)
+    import numpy as np
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    ml = 23                                                           # ragged over 2 and 3 ranks
+    # the reference-trained fixture net and fixture poses: the aux head really discriminates the right candidates
+    sd = {k: torch.tensor(v) for k, v in np.load(os.path.join(gdir, 'ckpt_stereo_h256.npz')).items()}
+    g = np.load(os.path.join(gdir, 'golden_path.npz'))
+    kl = torch.tensor(g['stereo_kps_l'][:ml])
+    kr = torch.tensor(g['stereo_kps_r'][[2, 5, 8, 11, 14, 20]])    # six distinct right poses (no exact ties)
+    sharded = parallel.ShardedRows(ml, 5, torch.device('cpu'))
+
+    def local(lo, hi):  # stand-in for LocoEngine.forward_stereo on this rank's left persons
+        return O.forward_stereo(sd, kl[lo:hi], kr, synth.KITTI_K)['xyzds'] if hi > lo else torch.empty((0, 5))
+
+    full = sharded.run(local)
+    if rank == 0:
+        ref = O.forward_stereo(sd, kl, kr, synth.KITTI_K)
+        # non-trivial selection: the winners are not all the same right person
+        best = ref['mask'].float().argmax(1)
+        q.put((bool(torch.equal(full, ref['xyzds'])), int(best.unique().numel())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_stereo_shard_by_left_gloo(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stereo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    same, distinct = q.get()
+    assert same and distinct >= 3
+
+
+def _allgather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env('gloo')
+    total = 4096
+    lo, hi = parallel.shard_bounds(total, world, rank)
+    rows = torch.arange(lo, hi, dtype=torch.float32).unsqueeze(1) * torch.tensor([[1., 2., 3., 4., 5.]])
+    sharded = parallel.ShardedRows(total, 5, torch.device('cpu'), mode='all_gather')
+    full = sharded.run(lambda a, b: rows)
+    ref = torch.arange(total, dtype=torch.float32).unsqueeze(1) * torch.tensor([[1., 2., 3., 4., 5.]])
+    q.put(bool(torch.equal(full, ref)))          # every rank holds the full block in this mode
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_all_gather_mode_gloo():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allgather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get() is True and q.get() is True
