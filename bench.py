@@ -56,14 +56,24 @@ def cpu_baseline(sd, kps_np, kk, budget_s):
     import torch
     from oracle import monoloco_oracle as O
     ncpu = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = ncpu
+    quota = None
+    try:  # a container may be capped well below the cores it can see (cgroup v2 cpu.max = "<quota> <period>")
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
     sd_t = {k: torch.tensor(v) for k, v in sd.items()}
-    sweep = sorted({t for t in (1, 8, 16, 32, 64, ncpu) if t <= ncpu})
     results = {}
     t_start = time.perf_counter()
     prev = torch.get_num_threads()
 
     def measure(t):
-        n = min(2048 if t == 1 else 16384, len(kps_np))
+        n = min(2048 if t <= 2 else (8192 if t <= 8 else 16384), len(kps_np))
         kps = torch.tensor(kps_np[:n])
         torch.set_num_threads(t)
         for _ in range(3):
@@ -75,20 +85,23 @@ def cpu_baseline(sd, kps_np, kk, budget_s):
             times.append(time.perf_counter() - t0)
         results[t] = n / statistics.median(times)
 
-    # all cores first, then downwards; the mandatory 1-thread point last; the middle of the sweep yields to the budget
-    for t in [s for s in sweep if s != 1][::-1]:
-        if results and time.perf_counter() - t_start > 0.6 * budget_s:
-            break
+    # ascending powers of two up to the usable cores: the sweep stops once it is past the knee (oversubscribed or
+    # quota-capped boxes get SLOWER with more threads) or out of budget; the 1-thread point always exists
+    t = 1
+    while t <= usable:
         measure(t)
-    measure(1)
+        if results[t] < 0.8 * max(results.values()) or time.perf_counter() - t_start > budget_s:
+            break
+        t *= 2
     torch.set_num_threads(prev)
     best_t = max(results, key=results.get)
     return {"value": round(results[best_t], 1), "unit": "persons/s", "cores": best_t, "kind": "port",
-            "one_thread": round(results.get(1, 0.0), 1), "host_cores": ncpu, "cpu_model": cpu_model(),
+            "one_thread": round(results.get(1, 0.0), 1), "host_cores": ncpu, "usable_cores": usable,
+            "cgroup_cpu_quota": quota, "cpu_model": cpu_model(),
             "sweep": {str(t): round(v, 1) for t, v in sorted(results.items())},
-            "sample": "oracle/monoloco_oracle.forward_mono (torch %s CPU fp32) on the first 16384 persons (2048 for the "
-                      "1-thread run) of the same synthetic batch; per thread count 3 warm-ups + 5 repetitions, median; "
-                      "value = best of the sweep; %.1f s" % (torch.__version__, time.perf_counter() - t_start)}
+            "sample": "oracle/monoloco_oracle.forward_mono (torch %s CPU fp32) on the first 2048 / 8192 / 16384 persons "
+                      "(<= 2 / <= 8 / more threads) of the same synthetic batch; ascending thread sweep, per thread count "
+                      "3 warm-ups + 5 repetitions, median; value = best of the sweep; %.1f s" % (torch.__version__, time.perf_counter() - t_start)}
 
 
 def traffic_from_profiles(args):

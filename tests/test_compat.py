@@ -149,8 +149,10 @@ def test_generate_kitti_call_sequence_through_compat(hip_lib, cuda_device):
         xyz = xyz_from_distance(dic_out['d'], pixel_to_camera(uv_c, kk, 1))
         assert np.abs(xyz.numpy() - np.array(cj['post_B']['xyz_pred'])).max() <= 1e-4
         path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'compat_002282.txt')
-        formats.save_txts(path, copy.deepcopy(boxes), all_outputs, [kk, None], net='monoloco_pp')
+        formats.save_txts(path, copy.deepcopy(boxes), all_outputs, [kk, None], net='monoloco_pp',
+                          cat=[0.0] * 15 + [1.0])        # get_category's per-person cyclist score (generate_kitti.py:110)
         lines = open(path).read().strip().split('\n')
-        assert len(lines) == 16 and all(ln.split()[0] in ('Pedestrian', 'Cyclist') and len(ln.split()) == 18 for ln in lines)
+        assert len(lines) == 16 and all(len(ln.split()) == 18 for ln in lines)
+        assert [ln.split()[0] for ln in lines] == ['Pedestrian'] * 15 + ['Cyclist']
     finally:
         C.uninstall()

@@ -80,7 +80,14 @@ def test_wb1024_mono_loco_surface(hip_lib, cuda_device, wb, gold):
     for key in ('h', 'w', 'l', 'ori', 'bi', 'd'):
         assert np.abs(dic[key].numpy() - wb['mono_' + key]).max() <= TOL, key
     assert np.abs(dic['yaw'][0].numpy() - wb['mono_yaw_pred']).max() <= TOL
-    assert np.abs(dic['yaw'][1].numpy() - wb['mono_yaw_ego']).max() <= 2 * TOL
+    # yaw_ego = yaw + atan2(x, z) with the ill-conditioned spherical z = sqrt(d^2 - x^2 - y^2) (process.py:265):
+    # a deviation dz <= TOL * d/z moves atan2 by |x| / (x^2 + z^2) * dz
+    x, z, d = wb['mono_xyzd'][:, 0:1], wb['mono_xyzd'][:, 2:3], wb['mono_xyzd'][:, 3:4]
+    ok = ~np.isnan(z)
+    allowed = 2 * TOL + np.abs(x) / (x ** 2 + z ** 2) * TOL * d / np.maximum(z, 1e-3)
+    err = np.abs(dic['yaw'][1].numpy() - wb['mono_yaw_ego'])
+    err = np.minimum(err, np.abs(err - 2 * np.pi))          # the +-2 pi wrap may flip exactly at the branch cut
+    assert (err[ok] <= allowed[ok]).all(), (err[ok] / allowed[ok]).max()
 
 
 def test_wb1024_stereo_reference_trained(hip_lib, cuda_device, wb, gold):
@@ -173,9 +180,11 @@ def test_config5_training_step_hidden_1024(hip_lib, cuda_device):
     res, out = tr.step(x, y, update=False, want_outputs=True)
     o32 = OracleTrainer(sd0, lr=0.001)
     o64 = OracleTrainer(sd0, lr=0.001, dtype=torch.float64)
-    l32, _ = o32.step(x, y, update=False)
+    l32, out32 = o32.step(x, y, update=False)
     l64, out64 = o64.step(x.double(), y.double(), update=False)
-    assert (out.cpu().double() - out64).abs().max().item() <= 1e-4
+    e_out, e_out32 = (out.cpu().double() - out64).abs().max().item(), (out32.double() - out64).abs().max().item()
+    print("config 5 train-mode outputs vs fp64: HIP %.2e, torch fp32 %.2e (|out| up to %.1f)" % (e_out, e_out32, out64.abs().max().item()))
+    assert e_out <= max(4 * e_out32, 1e-4)     # batch-statistics BN at random init amplifies fp32 rounding; same class as torch
     assert abs(res['loss'] - l64['loss']) <= max(4 * abs(l32['loss'] - l64['loss']), 1e-5 * abs(l64['loss']))
     g_hip, g32, g64 = tr.grads(), o32.grads(), o64.grads()
     worst = 0.0

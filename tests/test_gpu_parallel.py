@@ -52,4 +52,5 @@ print('ok')
 def test_sharded_rows_on_nccl_world1(hip_lib, cuda_device):
     code = _CODE % (ROOT, os.path.join(ROOT, 'tests'))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout[-2000:] + r.stderr[-4000:]
+    # (RCCL prints its version banner to stdout at teardown)
+    assert r.returncode == 0 and 'ok' in r.stdout.split(), r.stdout[-2000:] + r.stderr[-4000:]
