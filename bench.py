@@ -329,6 +329,11 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--no-profile', action='store_true', help='do not bracket dense launches with HIP events')
     ap.add_argument('--no-extra', action='store_true', help='skip the `extra` legs (other configs, bf16 mode, e2e)')
+    ap.add_argument('--tile-kernel', type=int, default=0, choices=[0, 2, 4, 260],
+                    help='A/B: 2 = dense_kernel_pp everywhere, 260 = dense_kernel_w4 everywhere, 0 / 4 = library default (w4 '
+                         'for the long-K layers, pp for the input and fused-head layers)')
+    ap.add_argument('--chunk-rows', type=int, default=-1,
+                    help='walk the batch in row chunks of this size through all layers (-1 = library default)')
     ap.add_argument('--gather', default='gather', choices=['gather', 'all_gather'], help='N > 1: the final collective')
     args = ap.parse_args()
 
@@ -349,6 +354,10 @@ def main():
             time.sleep(2.0)  # let the linker finish writing
     from monoloco_amd import engine, parallel
 
+    if args.tile_kernel:
+        engine.set_tile_kernel(args.tile_kernel & 255, everywhere=bool(args.tile_kernel & 256))
+    if args.chunk_rows >= 0:
+        engine.set_tuning(chunk_rows=args.chunk_rows)
     rank, world, local = parallel.init_from_env('nccl' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else None)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
@@ -439,7 +448,7 @@ def main():
             line["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16_DENSE, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_F16_DENSE, 4), "traffic": traffic_from_profiles(args),
-                "kernel": "mlk::dense layer kernel (tile path), precision %s" % args.precision,
+                "kernel": "mlk::dense_kernel_%s<%d,*,*,*>" % ({2: "pp", 260: "w4"}.get(args.tile_kernel, "w4 (6 long-K layers) + dense_kernel_pp (input and fused-head layers)"), {'f16x2': 3, 'f16': 1, 'bf16': 0}[args.precision]),
                 "launches": prof['launches'], "avg_launch_ms": round(prof['total_ms'] / prof['launches'], 5),
                 "per_layer_avg_ms": [round(a / max(n, 1), 5) for a, n in zip(prof['per_layer_ms'], prof['per_layer_n'])],
                 "note": "achieved = algorithmic FLOP of the reference layer structure (%d/row) / summed dense-kernel "

@@ -277,6 +277,10 @@ int ml_debug_num_layers(const ml_loco* h);
  * 2048 / 128 / 0): rows <= small_rows take the small-row dense kernels, above small32_rows those use
  * 32x32 tiles; chunk_rows > 0 walks the batch in row chunks of that size through all layers. */
 int ml_debug_set_tuning(int small_rows, int small32_rows, int chunk_rows);
+/* Which kernel runs the 256x256-tile path: 4 = dense_kernel_w4 for the long-K layers, dense_kernel_pp for the short
+ * input layer and the fused-head layer (default); 2 = dense_kernel_pp everywhere; 4 | 256 = dense_kernel_w4 wherever it
+ * can run (tests). */
+int ml_debug_set_tile_kernel(int which);
 /* Packed fp16 hi|lo line image of a dense layer's weights (n * kpad * 2 uint16); only kept for
  * models finalized with ML_FLAG_HOST_ONLY. */
 int ml_debug_get_packed(const ml_loco* h, int layer, uint16_t* lines_host, int64_t capacity);

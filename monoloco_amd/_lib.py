@@ -15,7 +15,8 @@ import torch  # noqa: F401  (import order matters, see above)
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint16, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmonoloco_hip.so')
+# MONOLOCO_HIP_LIB: another build of the same library (tools/ use it for the -DML_BRINGUP ablation build)
+LIB_PATH = os.environ.get('MONOLOCO_HIP_LIB') or os.path.join(_HERE, 'lib', 'libmonoloco_hip.so')
 
 ML_PREC_F16X2 = 0
 ML_PREC_F16 = 1
@@ -84,6 +85,7 @@ SIGNATURES = {
                                    POINTER(c_int)]),
     'ml_debug_num_layers': (c_int, [_P]),
     'ml_debug_set_tuning': (c_int, [c_int, c_int, c_int]),
+    'ml_debug_set_tile_kernel': (c_int, [c_int]),
     'ml_debug_get_packed': (c_int, [_P, c_int, POINTER(c_uint16), c_int64]),
     'ml_debug_get_head': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_int), POINTER(c_int)]),

@@ -1,0 +1,509 @@
+// dense_kernel_w4.h -- third generation of the dense layer: 4 waves per workgroup, ONE wave per SIMD with the whole
+// 512-register file (256 accumulators in AGPRs + 192 fragment registers), 128 x 128 wave tiles, a 4-slot LDS ring fed by
+// LDS-DMA three slots ahead, and a k-stream that never restarts between the tiles a persistent workgroup walks.
+//
+// Why (round-2 measurements, profiles/r02_*): in dense_kernel_pp the bf16 comparison mode -- one third of the MFMA work --
+// still needs 0.245 ms per layer against 0.355 ms for the 3-product mode: a k-step costs ~3800 cycles whatever the MFMA
+// count.  The loop is bound by the L2 -> LDS feed LATENCY, not by MFMA issue: with two 64 KiB stages only one stage is
+// ever in flight and its last quarter is requested < 1000 cycles before it is needed.  This kernel
+//   * splits a k32 step of the line format into an H slot (the 64-byte hi halves of 256 W rows + 256 X rows = 32 KiB) and
+//     an L slot (the lo halves): 4 slots = 128 KiB ring = TWO k-steps; a slot is requested 4000-5000 cycles before its
+//     first read and ~96 KiB per CU are in flight at any time (was: 64 KiB sawtooth, average 32);
+//   * reads fragments one phase ahead into a second register set, so a wave never waits for LDS in front of an MFMA and
+//     the slot a phase has just read is free for the next request at the following barrier;
+//   * runs the three products of the split precision as  phase A: hi.hi (32 MFMAs, needs only the H slot)  and
+//     phase B: hi.lo + lo.hi (64 MFMAs, needs the L slot and the hi fragments A already holds) -- per k32 step a wave
+//     issues 96 MFMAs, 32 ds_read_b128 (12 -> 8 fragment reads per 24 MFMAs), 16 LDS-DMA instructions and 2 barriers;
+//   * 128 x 128 wave tiles: half the LDS read traffic per MFMA of the 128 x 64 tiles of dense_kernel_pp;
+//   * keeps streaming across tile boundaries: the last phases of a tile already request (and read the first fragments
+//     of) the next tile, so there is no per-tile prologue and the epilogue's store burst overlaps the next tile's loads.
+// Same math, operand format, XCD-aware tile map and epilogue arithmetic as dense_kernel_pp; the fp32 summation order
+// inside a k32 step differs (hh k0, hh k1, [hl, lh] k0, [hl, lh] k1 instead of [hl, lh, hh] per k16), and the bias is
+// added in the epilogue (fma(acc, 2^-e, bias)) instead of starting the accumulators at bias * 2^e.
+//
+// vmcnt discipline: LDS-DMA and stores retire in issue order on one counter (CDNA4 vmcnt counts stores too); every wait
+// is a counted one placed by hand:  phase start = "the slot read in THIS phase has landed" = at most the DMA groups of the
+// previous two phases (8 instructions each) still outstanding.  No ordinary vector load exists between the first DMA and
+// the drain in front of an epilogue (hipcc would wait vmcnt(0) for it); the bias comes through the scalar cache.
+#pragma once
+#include "dense_kernel_pp.h"
+
+// timing ablations are COMPILE-TIME (-DML_W4_ABL=<bits>): a run-time debug branch per DMA / fragment read distorts exactly
+// what is being measured.  1 no epilogue, 4 no DMA in the loop, 8 no fragment reads in the loop, 32 no barrier / vmcnt
+// wait per phase, 64 epilogue without global stores, 128 epilogue stores to one L2-resident tile, 256 epilogue stores tile-contiguous (results are garbage)
+#ifndef ML_W4_ABL
+#define ML_W4_ABL 0
+#endif
+#define W4_DBG(bit) (((ML_W4_ABL) & (bit)) != 0)
+
+namespace mlk {
+
+constexpr int W4_THREADS = 256;
+constexpr int W4_SLOT = 32768;                 // 256 W rows x 64 B, then 256 X rows x 64 B
+constexpr int W4_XOFF = 16384;
+constexpr int W4_RING = 4 * W4_SLOT;           // H(t), L(t), H(t+1), L(t+1)
+constexpr int W4_LDS = W4_RING + 4 * 8192;     // + 2 x 4 KiB epilogue buffers per wave = all 160 KiB
+
+// one 32x32x16 MFMA of the mode: fp16 operands, or bf16 (NSPLIT == 0)
+template <int NSPLIT>
+__device__ __forceinline__ f32x16 w4_mfma(half8 a, half8 b, f32x16 c) {
+    if (NSPLIT == 0)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// fp32 pair -> packed fp16 hi pair + packed fp16 lo pair, hi clamped to the fp16 range (same bits as split2_res' tail)
+__device__ __forceinline__ void w4_split2(float v0, float v1, unsigned& h, unsigned& l) {
+    const float big = 65504.0f;
+    asm("v_med3_f32 %0, %1, -%2, %2" : "=v"(v0) : "v"(v0), "v"(big));
+    asm("v_med3_f32 %0, %1, -%2, %2" : "=v"(v1) : "v"(v1), "v"(big));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(v0), "v"(v1));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v1), "v"(h));
+}
+
+// 8 consecutive floats through the scalar cache (s_load_dwordx8): the bias of one (row block, register group) for both
+// lane halves.  An ordinary vector load here would make hipcc drain vmcnt(0) and break the epilogue's counted waits.
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x8 w4_sload8(const float* base_uniform, int byte_off_uniform) {
+    f32x8 v;
+    asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base_uniform), "s"(byte_off_uniform) : "memory");
+    return v;
+}
+
+// One accumulator element, AGPR -> VGPR, exactly where it is consumed.  Left to itself hipcc splits the accumulators'
+// live ranges at the loop exit and copies dozens of them to VGPRs up front (spilling the epilogue's own registers).
+__device__ __forceinline__ float w4_acc(float a) {
+    float v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+
+struct W4Frag {          // the fragments of one k32 step of one half (hi or lo): [tile][k16 step]
+    half8 w[4][2];       // weights:     rows wn*128 + 32*it + (lane & 31)
+    half8 x[4][2];       // activations: rows wm*128 + 32*jt + (lane & 31)
+};
+
+template <int NSPLIT, bool RELU, bool RES, int HEAD>
+__global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_kernel_w4(DenseParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[W4_LDS];
+    constexpr bool SPLIT = NSPLIT == 3;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w & 1;    // 2 waves along n (128 weight rows each)
+    const int wm = w >> 1;   // 2 waves along m (128 persons each)
+
+    const int NT = p.N / BN;
+    const int ntiles = (p.M_pad / BM) * NT;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const size_t rowb = (size_t)p.K * 4;
+    const size_t yrowb = (size_t)p.N * 4;
+    const int nk = p.K / 32;   // even (K % 64 == 0, guaranteed by the host)
+
+    // ---- LDS-DMA duty: per slot a wave fetches 64 W rows and 64 X rows, 4 instructions of 16 rows x 64 B each.
+    // lane -> (row = lane / 4, position = lane % 4); the LDS image is lane-linear, the bank swizzle
+    // chunk ^= (row >> 2) & 3 is applied on the SOURCE address (and again on the ds_read address).
+    // Source address = wave-uniform 64-bit base (request-stream pointer) + one of four lane offsets (+ 64 for lo halves).
+    unsigned goffq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        goffq[q] = (unsigned)(((lane >> 2) + 16 * q) * (int)rowb + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+    // instruction q (0..3 = W rows, 4..7 = X rows) of this wave's share of ring slot `slot` (odd = lo halves) from the
+    // request-stream pointers (rw, rx) = this wave's first row of the k32 step being requested
+    int dma_base = (w * 64) * 64;   // this wave's first row inside a slot's W part (made opaque per phase, see phase_wait)
+    auto issue1 = [&](const char* rw, const char* rx, int slot, int q) {
+        if (W4_DBG(4)) return;
+        char* sb = smem + dma_base + slot * W4_SLOT + (q < 4 ? 0 : W4_XOFF) + (q & 3) * 1024;
+        glds16((q < 4 ? rw : rx) + ((slot & 1) ? 64 : 0) + goffq[q & 3], sb);
+    };
+
+    // ---- fragment addressing: MFMA 32x32x16, lane l supplies row (l & 31), k = 8 * (l >> 5) .. + 7 of the k16 step,
+    // i.e. 16-byte chunk 2 * kk + (l >> 5) of the row's 64-byte half line
+    const int ml = lane & 31, hh = lane >> 5;
+    const int swz = (ml >> 2) & 3;
+    const int wrow = (wn * 128 + ml) * 64;
+    const int xrow = W4_XOFF + (wm * 128 + ml) * 64;
+    const int c0 = ((0 + hh) ^ swz) * 16, c1 = ((2 + hh) ^ swz) * 16;
+
+    // read quarter `qr` (0..7) of a fragment set from slot `slot`: 2 ds_read_b128 (both k16 steps of one 32-row tile)
+    auto read_q = [&](W4Frag& f, int slot, int qr) {
+        if (W4_DBG(8)) return;
+        const char* sb = smem + slot * W4_SLOT;
+        if (qr < 4) {
+            f.w[qr][0] = *(const half8*)(sb + wrow + qr * 2048 + c0);
+            f.w[qr][1] = *(const half8*)(sb + wrow + qr * 2048 + c1);
+        } else {
+            f.x[qr - 4][0] = *(const half8*)(sb + xrow + (qr - 4) * 2048 + c0);
+            f.x[qr - 4][1] = *(const half8*)(sb + xrow + (qr - 4) * 2048 + c1);
+        }
+    };
+
+    // virtual block id -> tile: the XCD-aware bijective map of dense_kernel.h
+    auto tile_of = [&](int vb, int& m0, int& n0) {
+        const int xcd = vb & 7, idx = vb >> 3;
+        const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        const int mt = tile / NT, nt = tile - mt * NT;
+        m0 = mt * BM;
+        n0 = nt * BN;
+    };
+
+    int vb = blockIdx.x;
+    if (vb >= ntiles) return;
+    int m0, n0;
+    tile_of(vb, m0, n0);
+
+    char* const scr = smem + W4_RING + w * 8192;   // two 4 KiB epilogue buffers of this wave
+
+    // ---- the request stream: it runs two k32 steps ahead of the compute stream and simply continues into the next
+    // tile of this workgroup; behind the last tile it re-requests that tile (valid memory, data never read), so that no
+    // request is conditional and every phase has the same vmcnt arithmetic.
+    int rq_vb = vb, rq_left = nk;
+    const size_t wave_rows = (size_t)(w * 64) * rowb;
+    const char* rq_w = p.w + (size_t)n0 * rowb + wave_rows;
+    const char* rq_x = p.x + (size_t)m0 * rowb + wave_rows;
+    auto rq_advance = [&]() {   // after both slots of a k32 step have been requested
+        rq_w += LINE;
+        rq_x += LINE;
+        if (--rq_left == 0) {
+            if (rq_vb + (int)gridDim.x < ntiles) rq_vb += (int)gridDim.x;
+            int rm0, rn0;
+            tile_of(rq_vb, rm0, rn0);
+            rq_w = p.w + (size_t)rn0 * rowb + wave_rows;
+            rq_x = p.x + (size_t)rm0 * rowb + wave_rows;
+            rq_left = nk;
+        }
+    };
+
+    // ---- prologue of the stream (once per workgroup): the first two k-steps, then the first hi fragments
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            issue1(rq_w, rq_x, 2 * st, q);
+            if (SPLIT) issue1(rq_w, rq_x, 2 * st + 1, q);
+        }
+        rq_advance();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    W4Frag fa, fb, fl;   // hi fragments of even / odd k-steps, lo fragments of the current step
+#pragma unroll
+    for (int qr = 0; qr < 8; ++qr) read_q(fa, 0, qr);
+
+    // optional timeline (bring-up builds, -DML_BRINGUP -DML_DENSE_TRACE): per tile 16 slots of this wave <- s_memtime:
+    //   0 tile start, 1..8 end of the first 8 phases, 9 end of main loop, 10 stream drained, 11 epilogue issued
+#ifdef ML_DENSE_TRACE
+    unsigned long long* const trc = p.trace ? p.trace + ((size_t)blockIdx.x * 8 + w) * 64 : nullptr;
+    int ttile = 0;
+    auto stamp = [&](int slot) {
+        if (trc && ttile < 4) {
+            const unsigned long long ts = __builtin_amdgcn_s_memtime();
+            if (lane == 0) trc[ttile * 16 + slot] = ts;
+        }
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
+    while (true) {
+        const int vb_next = vb + (int)gridDim.x;
+        const bool more = vb_next < ntiles;   // workgroup-uniform
+
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[it][jt][e] = 0.0f;
+
+        // The slot a phase reads was requested three phases earlier (split mode; one phase earlier in the single-product
+        // modes): in steady state exactly the DMA groups (8 instructions per wave each) of the two phases in between are
+        // younger.  The first phases after a drain (prologue / epilogue) read slots that were drained: no vmcnt wait at
+        // all there, so the epilogue's stores keep retiring behind the next tile's MFMAs.
+        int since_drain = 0;          // phases since the last vmcnt(0)
+        stamp(0);
+        auto phase_wait = [&]() {
+#ifdef ML_DENSE_TRACE
+            if (since_drain >= 1 && since_drain <= 8) stamp(since_drain);
+#endif
+            asm volatile("" : "+s"(since_drain));   // (opaque: keeps hipcc from peeling a copy of the loop body)
+            asm volatile("" : "+s"(dma_base));      // (opaque: m0 = base + constant per DMA instead of 32 hoisted SGPRs)
+            if (W4_DBG(32)) return;
+            if (since_drain >= (SPLIT ? 3 : 1)) {
+                if (SPLIT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            ++since_drain;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of the slot that is about to be refilled
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        // One k32 step.  FH = hi fragments of this step (already in registers), FN = the other hi set (receives the next
+        // step's), S = 0 / 2: ring slots of this step's H (S) and L (S + 1); the next step's are S ^ 2.
+        auto kstep = [&](W4Frag& FH, W4Frag& FN, const int S) {
+            // ---------------- phase A: hi.hi, 32 MFMAs; reads the lo fragments of this step; requests H(t+2) into this
+            // step's H slot (its fragments are in FH since the previous phase)
+            phase_wait();
+            // per block of 4 MFMAs one DMA instruction and two fragment reads, issued BEHIND the block (a read in front
+            // of the first block would make hipcc's own lgkmcnt(0) for FH wait for it); blocks 4 and 5 carry two quarters
+            // each so that blocks 6 and 7 (8 MFMAs, 256 cycles) cover the last reads' latency before the next phase's wait
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int blk = kk * 4 + it;   // 8 blocks of 4 MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) acc[it][jt] = w4_mfma<NSPLIT>(FH.w[it][kk], FH.x[jt][kk], acc[it][jt]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int qd = (blk < 4 ? blk : (blk < 6 ? 4 + 2 * (blk - 4) : 8)); qd < (blk < 4 ? blk + 1 : (blk < 6 ? 6 + 2 * (blk - 4) : 8)); ++qd) {
+                        issue1(rq_w, rq_x, S, qd);
+                        if (SPLIT) read_q(fl, S + 1, qd);
+                        else read_q(FN, S ^ 2, qd);   // single-product modes: the next step's hi fragments are read here
+                    }
+                }
+            if (SPLIT) {
+                // ---------------- phase B: hi.lo + lo.hi, 64 MFMAs; reads the NEXT step's hi fragments; requests L(t+2)
+                phase_wait();
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int blk = (kk * 2 + half) * 4 + it;   // 16 blocks of 4 MFMAs
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int jt = 0; jt < 4; ++jt) {
+                                if (half == 0) acc[it][jt] = w4_mfma<NSPLIT>(FH.w[it][kk], fl.x[jt][kk], acc[it][jt]);
+                                else acc[it][jt] = w4_mfma<NSPLIT>(fl.w[it][kk], FH.x[jt][kk], acc[it][jt]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            // quarters behind blocks 0, 2, .., 10, 11, 12: blocks 13-15 cover the last reads
+                            const int qd = (blk <= 10) ? ((blk & 1) == 0 ? blk >> 1 : -1) : (blk <= 12 ? blk - 5 : -1);
+                            if (qd >= 0) {
+                                issue1(rq_w, rq_x, S + 1, qd);
+                                read_q(FN, S ^ 2, qd);
+                            }
+                        }
+            }
+            rq_advance();
+        };
+
+#pragma clang loop unroll(disable)
+        for (int t = 0; t < nk; t += 2) {
+            kstep(fa, fb, 0);
+            kstep(fb, fa, 2);
+        }
+        // every request of this tile's loop is now waited for except the last one or two groups; the epilogue below
+        // counts its own vector-memory operations, so drain the stream first (the youngest group was requested a whole
+        // phase ago)
+        stamp(9);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(10);
+        // the last MFMAs' results are read by hand-placed v_accvgpr_read below and no hazard padding is inserted for asm
+        // operands: 16-pass MFMA -> AGPR read needs up to 18 wait states
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- epilogue of the finished tile, one 32 (n) x 32 (m) MFMA tile per pass, it-major (4 passes share a bias)
+        const int nbase = n0 + wn * 128;
+        const int mbase = m0 + wm * 128;
+        int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(elane));   // lane-dependent epilogue addresses are derived here, per tile (not hoisted)
+        const int eml = elane & 31, eh = elane >> 5;
+        const unsigned st_off = (unsigned)((elane >> 3) * (int)yrowb + ((elane & 7) * 16));
+        const int scr_row = eml * LINE + eh * 8;                       // + ((chunk ^ (eml & 7)) * 16)
+        const int rd_off = (elane >> 3) * LINE + (((elane & 7) ^ ((elane >> 3) & 7)) * 16);  // + qq * 1024
+        // addresses of a pass = one wave-uniform 64-bit tile base + a 32-bit offset (kept as a running, opaque value so
+        // that hipcc does not pre-compute 16 + 16 address pairs into SGPRs and spill them)
+        const size_t tile_off = (size_t)mbase * yrowb + (size_t)nbase * 4;
+        const unsigned row8 = (unsigned)(8 * (int)yrowb);
+        auto pass_off = [&](int pass) {   // pass = it * 4 + jt
+            unsigned o = (unsigned)((pass & 3) * 32) * (unsigned)yrowb + (unsigned)((pass >> 2) * 128);
+            asm volatile("" : "+s"(o));
+            return o;
+        };
+        const float* bs = p.bias + nbase;   // wave-uniform: scalar loads
+
+        if (W4_DBG(1)) {   // ablation: keep the accumulators live, store (almost) nothing
+            float sdbg = 0.f;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) sdbg += w4_acc(acc[it][jt][(it * 4 + jt) & 15]);
+            if (sdbg == 123456.789f) p.y[tid] = 1;
+        } else if (HEAD > 0) {
+            // the activation tile is not stored: each wave multiplies its relu'd 128-column slice with the HEAD x 128
+            // slice of the head weights (staged in its 8 KiB epilogue area: ordinary loads, the stream is drained)
+            float* hw = (float*)scr;
+            for (int idx = elane; idx < HEAD * 32; idx += 64) {
+                const int o = idx >> 5, c4 = idx & 31;
+                *(f32x4*)(hw + o * 128 + c4 * 4) = *(const f32x4*)(p.head_w + (size_t)o * p.N + nbase + c4 * 4);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int slice = (n0 / BN) * 2 + wn;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                float part[HEAD > 0 ? HEAD : 1];
+#pragma unroll
+                for (int o = 0; o < HEAD; ++o) part[o] = 0.0f;
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+                        const f32x8 b8 = w4_sload8(bs, (it * 32 + g * 8) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float b = eh ? b8[4 + e] : b8[e];
+                            v[e] = __builtin_fmaf(w4_acc(acc[it][jt][g * 4 + e]), p.descale, b);
+                            if (RELU) v[e] = __builtin_fmaxf(v[e], 0.0f);
+                        }
+#pragma unroll
+                        for (int o = 0; o < HEAD; ++o) {
+                            const f32x4 w4 = *(const f32x4*)(hw + o * 128 + it * 32 + g * 8 + eh * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) part[o] = __builtin_fmaf(v[e], w4[e], part[o]);
+                        }
+                    }
+#pragma unroll
+                for (int o = 0; o < HEAD; ++o) part[o] += __shfl_xor(part[o], 32, 64);
+                if (eh == 0) {
+                    float* dst = p.head_part + ((size_t)slice * p.M_pad + (mbase + jt * 32 + eml)) * 16;
+#pragma unroll
+                    for (int o4 = 0; o4 < (HEAD + 3) / 4; ++o4) {
+                        f32x4 q4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) q4[e] = (o4 * 4 + e < HEAD) ? part[o4 * 4 + e] : 0.0f;
+                        *(f32x4*)(dst + o4 * 4) = q4;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the staging loads' and these few stores' waits are hipcc's)
+        } else {
+            // Software-pipelined over the 16 passes (two 4 KiB buffers per wave):
+            //   region p:  [residual tile p+3 requested: plain 16-byte loads in store layout, three passes ahead, so that
+            //               the in-order vmcnt wait for tile p only needs the stores of pass p-4 to have retired]
+            //              [residual tile p: registers -> buffer p&1 -> MFMA layout]   [arithmetic of pass p]
+            //              [global stores of pass p-1 (its transposed lines were read in region p-1: latency hidden)]
+            //              [packed hi|lo of pass p -> buffer p&1 -> 16-byte lines read back for region p+1]
+            // hipcc counts these loads and stores itself (no LDS-DMA is in flight here), in issue order.
+            f32x4 rq[RES ? 16 : 1][4];
+            auto load_res = [&](int pass) {
+                const char* src = p.res + tile_off;
+                const unsigned o = pass_off(pass) + st_off;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) rq[RES ? pass : 0][qq] = *(const f32x4*)(src + (o + qq * row8));
+            };
+            if (RES) {
+                load_res(0);
+                load_res(1);
+                load_res(2);
+            }
+            f32x4 d[4];
+            auto flush = [&](int pass) {   // the transposed lines of `pass` (in d[]) -> global memory
+                char* dst = p.y + tile_off;
+                const unsigned o = pass_off(pass) + st_off;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {  // rows 8qq + lane/8, chunk lane%8: full 128-byte lines
+                    if (W4_DBG(64)) asm volatile("" :: "v"(d[qq]));
+                    else if (W4_DBG(128)) *(f32x4*)(p.y + (size_t)(blockIdx.x * 4 + w) * 4096 + qq * 1024 + elane * 16) = d[qq];
+                    else *(f32x4*)(dst + (o + qq * row8)) = d[qq];
+                }
+            };
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                float bsel[16];   // bias of this lane's 16 weight rows of row block `it`
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x8 b8 = w4_sload8(bs, (it * 32 + g * 8) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bsel[g * 4 + e] = eh ? b8[4 + e] : b8[e];
+                }
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const int pass = it * 4 + jt;
+                    char* const buf = scr + (pass & 1) * 4096;
+                    u32x2 rh[4], rl[4];
+                    if (RES) {
+                        if (pass + 3 < 16) load_res(pass + 3);
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) *(f32x4*)(buf + rd_off + qq * 1024) = rq[pass][qq];
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            rh[g] = *(const u32x2*)(buf + scr_row + ((g ^ (eml & 7)) * 16));
+                            rl[g] = *(const u32x2*)(buf + scr_row + (((g + 4) ^ (eml & 7)) * 16));
+                        }
+                    }
+                    u32x2 oh[4], ol[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            float v0 = __builtin_fmaf(w4_acc(acc[it][jt][g * 4 + 2 * e2]), p.descale, bsel[g * 4 + 2 * e2]);
+                            float v1 = __builtin_fmaf(w4_acc(acc[it][jt][g * 4 + 2 * e2 + 1]), p.descale, bsel[g * 4 + 2 * e2 + 1]);
+                            if (RELU) {
+                                asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
+                                asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
+                            }
+                            unsigned hq, lq;
+                            if (NSPLIT == 0) {   // bf16 lines: one bf16 in the hi slot
+                                if (RES) {
+                                    v0 += __builtin_bit_cast(float, rh[g][e2] << 16);
+                                    v1 += __builtin_bit_cast(float, rh[g][e2] & 0xffff0000u);
+                                }
+                                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hq) : "v"(v0), "v"(v1));
+                                lq = 0u;
+                            } else {
+                                if (RES) {
+                                    float r0, r1;
+                                    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r0) : "v"(rh[g][e2]), "v"(rl[g][e2]));
+                                    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r1) : "v"(rh[g][e2]), "v"(rl[g][e2]));
+                                    v0 += r0;
+                                    v1 += r1;
+                                }
+                                w4_split2(v0, v1, hq, lq);
+                            }
+                            oh[g][e2] = hq;
+                            ol[g][e2] = lq;
+                        }
+                    }
+                    if (pass > 0) flush(pass - 1);
+                    // transpose through the buffer (its residual image, if any, is in registers: LDS operations of one wave
+                    // execute in order)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        *(u32x2*)(buf + scr_row + ((g ^ (eml & 7)) * 16)) = oh[g];
+                        *(u32x2*)(buf + scr_row + (((g + 4) ^ (eml & 7)) * 16)) = ol[g];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) d[qq] = *(const f32x4*)(buf + rd_off + qq * 1024);
+                    __builtin_amdgcn_sched_barrier(0);  // one region per pass: interleaving more of them costs registers
+                }
+            }
+            flush(15);
+        }
+
+        stamp(11);
+#ifdef ML_DENSE_TRACE
+        ++ttile;
+#endif
+        if (!more) break;
+        vb = vb_next;
+        tile_of(vb, m0, n0);
+        // the next tile's first hi fragments again (the copy read in the last phase is not kept live across the
+        // epilogue: 64 registers the epilogue needs; slot 0 is untouched until the next request behind the barrier)
+#pragma unroll
+        for (int qr = 0; qr < 8; ++qr) read_q(fa, 0, qr);
+    }
+}
+
+}  // namespace mlk

@@ -19,6 +19,7 @@
 
 #include "dense_kernel.h"
 #include "dense_kernel_pp.h"
+#include "dense_kernel_w4.h"
 #include "dense_small.h"
 #include "geom_kernels.h"
 #include "geom_ops.h"
@@ -238,7 +239,7 @@ void add_dense(ml_loco* h, const std::vector<double>& W, const std::vector<doubl
     DenseLayer L;
     L.n = np;
     L.k = kp;
-    L.kpad = round_up(kp, 32);
+    L.kpad = round_up(kp, 64);  // whole k64 double steps: the w4 kernel's ring holds two k32 steps
     L.relu = relu;
     L.src = src;
     L.dst = dst;
@@ -435,6 +436,8 @@ int trace_after_launch(unsigned long long* buf, size_t n, int grid, const mlk::D
 //   kernel; above g_small32_rows those use 32x32 output tiles (16x16 below); g_chunk_rows > 0 walks the batch in row
 //   chunks through all layers (Infinity-Cache residency experiment, off by default).
 int g_small_rows = 2048, g_small32_rows = 128, g_chunk_rows = 0;
+int g_tile_kernel = 4;
+int g_tile_kernel_all = 0;  // test hook: 1 = dense_kernel_w4 for EVERY layer it supports (ml_debug_set_tile_kernel(4 | 256))  // 4 = dense_kernel_w4 (one wave per SIMD, 4-slot ring), 2 = dense_kernel_pp (ping-pong)
 int small_rows_env() { return g_small_rows; }
 int small32_rows_env() { return g_small32_rows; }
 
@@ -496,7 +499,40 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, in
         p.trace = trace_buf;
     }
 #endif
-    const int grid = tiles < num_cus() ? tiles : num_cus();
+    int grid = tiles < num_cus() ? tiles : num_cus();
+#ifdef ML_BRINGUP
+    if (getenv("ML_GRID_CAP") && atoi(getenv("ML_GRID_CAP")) > 0 && grid > atoi(getenv("ML_GRID_CAP"))) grid = atoi(getenv("ML_GRID_CAP"));
+    if (getenv("ML_TILE_KERNEL")) g_tile_kernel = atoi(getenv("ML_TILE_KERNEL"));  
+#endif
+    // dense_kernel_w4 for the long-K layers; the short input layer (K <= 128: two or four k-steps per tile, all epilogue)
+    // and the layer with the fused output head stay on dense_kernel_pp, whose two waves per SIMD overlap those
+    // VALU-heavy epilogues (measured: 0.063 vs 0.077 ms and 0.351 vs 0.381 ms per layer at 65536 rows)
+    if (g_tile_kernel == 4 && p.K % 64 == 0 && (g_tile_kernel_all || (p.K > 128 && head_nh == 0))) {
+#define ML_W4(NS, RL, RS, HD) \
+    hipLaunchKernelGGL((mlk::dense_kernel_w4<NS, RL, RS, HD>), dim3(grid), dim3(mlk::W4_THREADS), 0, st, p)
+#define ML_W4_NS(NS)                                              \
+    do {                                                          \
+        if (head_nh == 8) ML_W4(NS, true, false, 8);              \
+        else if (head_nh == 9) ML_W4(NS, true, false, 9);         \
+        else if (p.relu) {                                        \
+            if (p.res) ML_W4(NS, true, true, 0);                  \
+            else ML_W4(NS, true, false, 0);                       \
+        } else {                                                  \
+            if (p.res) ML_W4(NS, false, true, 0);                 \
+            else ML_W4(NS, false, false, 0);                      \
+        }                                                         \
+    } while (0)
+        if (precision == ML_PREC_F16X2) ML_W4_NS(3);
+        else if (precision == ML_PREC_F16) ML_W4_NS(1);
+        else ML_W4_NS(0);
+#undef ML_W4_NS
+#undef ML_W4
+#ifdef ML_BRINGUP
+        if (p.trace) return trace_after_launch(trace_buf, trace_n, grid, p, st);
+#endif
+        HIP_TRY(hipGetLastError());
+        return ML_OK;
+    }
 #define ML_PP(NS, RL, RS, HD) \
     hipLaunchKernelGGL((mlk::dense_kernel_pp<NS, RL, RS, HD>), dim3(grid), dim3(mlk::DENSE_THREADS), 0, st, p)
 #define ML_PP_NS(NS)                                              \
@@ -1201,6 +1237,15 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
     return ML_OK;
 }
 
+int ml_debug_set_tile_kernel(int which) {
+    const int all = (which & 256) ? 1 : 0;
+    which &= 255;
+    if (which != 2 && which != 4) return fail(ML_ERR_ARG, "tile kernel must be 2 (ping-pong) or 4 (one wave per SIMD)");
+    g_tile_kernel = which;
+    g_tile_kernel_all = all;
+    return ML_OK;
+}
+
 int ml_debug_set_tuning(int small_rows, int small32_rows, int chunk_rows) {
     // negative = keep; the defaults are 2048 / 128 / 0
     if (small_rows >= 0) g_small_rows = small_rows;
@@ -1258,7 +1303,7 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
     DenseLayer L;
     L.n = n;
     L.k = k;
-    L.kpad = round_up(k, 32);
+    L.kpad = round_up(k, 64);
     L.relu = relu;
     L.w.assign(w_host, w_host + (size_t)n * k);
     L.b.assign(b_host, b_host + n);

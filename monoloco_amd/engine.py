@@ -179,6 +179,13 @@ def set_tuning(small_rows=-1, small32_rows=-1, chunk_rows=-1):
     check(_lib.load().ml_debug_set_tuning(int(small_rows), int(small32_rows), int(chunk_rows)))
 
 
+def set_tile_kernel(which, everywhere=False):
+    """Which kernel runs the tile path (test hook, process-global): 4 = dense_kernel_w4 for the long-K layers and
+    dense_kernel_pp for the input / fused-head layers (default); 2 = dense_kernel_pp everywhere; everywhere=True with 4 =
+    dense_kernel_w4 for every layer it supports."""
+    check(_lib.load().ml_debug_set_tile_kernel(int(which) | (256 if everywhere else 0)))
+
+
 def debug_linear(x, w, b, relu=False, res=None, precision='f16x2', small_path=False):
     """Single dense layer through the MFMA kernel (test hook): the tile kernel, or the small-row kernels."""
     lib = _lib.load()

@@ -1,0 +1,110 @@
+"""-m gpu: dense_kernel_w4 (4 waves x 128x128 wave tiles, one wave per SIMD, 4-slot hi/lo LDS ring, continuous k-stream)
+against fp64 and against dense_kernel_pp, layer by layer and through whole models, incl. several tiles per workgroup."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_kernel():
+    from monoloco_amd import engine
+    yield
+    engine.set_tile_kernel(4)
+
+
+@pytest.mark.parametrize("m,k,n", [(256, 64, 256), (700, 96, 256), (1000, 1024, 1024), (3000, 256, 512), (70000, 128, 1024)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
+def test_w4_single_layer(hip_lib, cuda_device, m, k, n, relu, res):
+    """One layer: fp32-class accuracy against fp64, and the same operands through dense_kernel_pp (only the fp32
+    summation order differs).  70000 x 1024 outputs = 1096 tiles: every workgroup walks 4-5 tiles of the stream."""
+    from monoloco_amd import engine
+    rng = np.random.default_rng(m + k + n)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    x = (rng.standard_normal((m, k)) * 2).astype(np.float32)
+    r = (rng.standard_normal((m, n)) * 3).astype(np.float32) if res else None
+    xd = torch.tensor(x).to(cuda_device)
+    rd = torch.tensor(r).to(cuda_device) if res else None
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    if res:
+        ref = ref + r
+    out = {}
+    for kern in (4, 2):
+        engine.set_tile_kernel(kern, everywhere=True)
+        out[kern] = engine.debug_linear(xd, w, b, relu=relu, res=rd).cpu().numpy()
+        err = np.abs(out[kern] - ref).max()
+        assert err <= 4e-6 * max(1.0, np.abs(ref).max()), (kern, err)
+    assert np.abs(out[4] - out[2]).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_w4_single_product_modes(hip_lib, cuda_device, precision):
+    from monoloco_amd import engine
+    rng = np.random.default_rng(3)
+    m, k, n = 2500, 512, 512
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    xd = torch.tensor(x).to(cuda_device)
+    out = {}
+    for kern in (4, 2):
+        engine.set_tile_kernel(kern, everywhere=True)
+        out[kern] = engine.debug_linear(xd, w, b, relu=True, precision=precision).cpu().numpy()
+    ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + b, 0)
+    tol = 2e-2 if precision == 'f16' else 1.5e-1
+    assert np.abs(out[4] - ref).max() <= tol
+    # same rounded operands, same single product per term: only the summation order (and, for bf16, a final-ulp tie)
+    assert np.abs(out[4] - out[2]).max() <= (1e-4 if precision == 'f16' else 2 ** -6 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("mode", ["mono", "stereo"])
+def test_w4_whole_model_vs_pp_and_oracle(hip_lib, cuda_device, mode):
+    from monoloco_amd import engine
+    from oracle import monoloco_oracle as O
+    in_f, out_f = (34, 9) if mode == "mono" else (68, 10)
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(4, in_features=in_f, out_features=out_f).items()}
+    rng = np.random.default_rng(11)
+    m = 20000   # 79 row panels x 4 column tiles = 316 tiles > 256 workgroups: the stream crosses tile boundaries
+    x = torch.tensor((rng.standard_normal((m, in_f)) * 3).astype(np.float32), device=cuda_device)
+    raw = {}
+    for merge in (True, False):
+        eng = engine.LocoEngine(sd, device=cuda_device, merge_w2w3=merge)
+        for kern in (4, 2):
+            engine.set_tile_kernel(kern, everywhere=True)   # incl. the input layer and the fused-head layer
+            raw[(merge, kern)] = eng.forward_raw(x).cpu()
+        engine.set_tile_kernel(4)                           # the default mix of the two kernels
+        raw[(merge, 'mix')] = eng.forward_raw(x).cpu()
+        eng.close()
+    idx = torch.arange(0, m, 41)
+    ref64 = O.loco_forward(sd, x.cpu()[idx], dtype=torch.float64)
+    scale = max(1.0, ref64.abs().max().item())
+    for key, r in raw.items():
+        assert (r[idx].double() - ref64).abs().max().item() <= 1e-4, key
+    assert (raw[(True, 4)] - raw[(True, 2)]).abs().max().item() <= 4e-6 * scale
+    assert (raw[(False, 4)] - raw[(False, 2)]).abs().max().item() <= 4e-6 * scale
+
+
+def test_w4_is_deterministic_and_row_independent(hip_lib, cuda_device):
+    """Same bits run after run and under a row permutation (rows are independent; a race between the DMA ring and the
+    fragment reads would show up as run-to-run differences in some tile)."""
+    from monoloco_amd import engine
+    engine.set_tile_kernel(4, everywhere=True)
+    eng = engine.LocoEngine({k: torch.tensor(v) for k, v in synth.make_state_dict(1).items()}, device=cuda_device)
+    kinv = engine.inverse_intrinsics(synth.KITTI_K)
+    m = 65536
+    kps = torch.tensor(synth.make_keypoints(m, seed=21)).to(cuda_device)
+    _, x0, r0 = eng.forward_mono(kps, kinv, want_raw=True)
+    x0, r0 = x0.clone(), r0.clone()
+    for _ in range(5):
+        _, x1, r1 = eng.forward_mono(kps, kinv, want_raw=True)
+        assert torch.equal(r1, r0) and torch.equal(x1, x0)
+    perm = torch.randperm(m, device=cuda_device)
+    _, x2, r2 = eng.forward_mono(kps[perm].contiguous(), kinv, want_raw=True)
+    assert torch.equal(r2, r0[perm])
+    eng.close()
