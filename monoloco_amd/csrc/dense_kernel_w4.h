@@ -18,8 +18,7 @@
 //   * keeps streaming across tile boundaries: the last phases of a tile already request (and read the first fragments
 //     of) the next tile, so there is no per-tile prologue and the epilogue's store burst overlaps the next tile's loads.
 // Same math, operand format, XCD-aware tile map and epilogue arithmetic as dense_kernel_pp; the fp32 summation order
-// inside a k32 step differs (hh k0, hh k1, [hl, lh] k0, [hl, lh] k1 instead of [hl, lh, hh] per k16), and the bias is
-// added in the epilogue (fma(acc, 2^-e, bias)) instead of starting the accumulators at bias * 2^e.
+// inside a k32 step differs (hh k0, hh k1, [hl, lh] k0, [hl, lh] k1 instead of [hl, lh, hh] per k16).
 //
 // vmcnt discipline: LDS-DMA and stores retire in issue order on one counter (CDNA4 vmcnt counts stores too); every wait
 // is a counted one placed by hand:  phase start = "the slot read in THIS phase has landed" = at most the DMA groups of the
@@ -71,12 +70,75 @@ __device__ __forceinline__ f32x8 w4_sload8(const float* base_uniform, int byte_o
     return v;
 }
 
+// Epilogue arithmetic of one value PAIR in ONE asm statement each (hipcc pads every asm statement with an s_nop and knows
+// nothing about the AGPR reads; 38 s_nop per 32x32 pass with one statement per instruction).  The accumulators start at
+// bias * 2^e, so v = acc * 2^-e is exact and needs no bias add; results are bit-identical to dense_kernel_pp's
+// split2_scaled / split2_res (same instructions on the same values).
+//   plain:    c = med3(acc, lo_lim, lim) [ReLU and the fp16-range clamp in the accumulator's scale];
+//             h = packed rn_f16(c * d);  l = packed rn_f16(c * d - h)
+__device__ __forceinline__ void w4_pair_plain(float a0, float a1, float d, float lo_lim, float lim, unsigned& h, unsigned& l) {
+    float t0, t1;
+    asm("v_accvgpr_read_b32 %2, %4\n\t"
+        "v_accvgpr_read_b32 %3, %5\n\t"
+        "v_med3_f32 %2, %2, %6, %7\n\t"
+        "v_med3_f32 %3, %3, %6, %7\n\t"
+        "v_fma_mixlo_f16 %0, %2, %8, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %8, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h), "=&v"(l), "=&v"(t0), "=&v"(t1)
+        : "a"(a0), "a"(a1), "v"(lo_lim), "v"(lim), "v"(d));
+}
+//   residual: v = relu(acc) * d + (rh + rl), clamped to the fp16 range; h = rn_f16(v); l = rn_f16(v - h)
+template <bool RELU>
+__device__ __forceinline__ void w4_pair_res(float a0, float a1, float d, unsigned rh, unsigned rl, unsigned& h, unsigned& l) {
+    float t0, t1, r0, r1;
+    const float big = 65504.0f;
+    if (RELU)
+        asm("v_accvgpr_read_b32 %2, %6\n\t"
+            "v_accvgpr_read_b32 %3, %7\n\t"
+            "v_fma_mix_f32 %4, %8, 1.0, %9 op_sel_hi:[1,0,1]\n\t"
+            "v_fma_mix_f32 %5, %8, 1.0, %9 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n\t"
+            "v_max_f32 %2, 0, %2\n\t"
+            "v_max_f32 %3, 0, %3\n\t"
+            "v_fma_f32 %2, %2, %10, %4\n\t"
+            "v_fma_f32 %3, %3, %10, %5\n\t"
+            "v_med3_f32 %2, %2, -%11, %11\n\t"
+            "v_med3_f32 %3, %3, -%11, %11\n\t"
+            "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+            "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(h), "=&v"(l), "=&v"(t0), "=&v"(t1), "=&v"(r0), "=&v"(r1)
+            : "a"(a0), "a"(a1), "v"(rh), "v"(rl), "v"(d), "v"(big));
+    else
+        asm("v_accvgpr_read_b32 %2, %6\n\t"
+            "v_accvgpr_read_b32 %3, %7\n\t"
+            "v_fma_mix_f32 %4, %8, 1.0, %9 op_sel_hi:[1,0,1]\n\t"
+            "v_fma_mix_f32 %5, %8, 1.0, %9 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n\t"
+            "v_fma_f32 %2, %2, %10, %4\n\t"
+            "v_fma_f32 %3, %3, %10, %5\n\t"
+            "v_med3_f32 %2, %2, -%11, %11\n\t"
+            "v_med3_f32 %3, %3, -%11, %11\n\t"
+            "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+            "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(h), "=&v"(l), "=&v"(t0), "=&v"(t1), "=&v"(r0), "=&v"(r1)
+            : "a"(a0), "a"(a1), "v"(rh), "v"(rl), "v"(d), "v"(big));
+}
+
 // One accumulator element, AGPR -> VGPR, exactly where it is consumed.  Left to itself hipcc splits the accumulators'
 // live ranges at the loop exit and copies dozens of them to VGPRs up front (spilling the epilogue's own registers).
 __device__ __forceinline__ float w4_acc(float a) {
     float v;
     asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
     return v;
+}
+
+// four of them with ONE wait: 32 consecutive weight rows' worth (4 register groups x both lane halves)
+__device__ __forceinline__ void w4_sload32(const float* base_uniform, int byte_off_uniform, f32x8& v0, f32x8& v1, f32x8& v2, f32x8& v3) {
+    asm volatile("s_load_dwordx8 %0, %4, %5\n\ts_load_dwordx8 %1, %4, %5 offset:32\n\ts_load_dwordx8 %2, %4, %5 offset:64\n\t"
+                 "s_load_dwordx8 %3, %4, %5 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3) : "s"(base_uniform), "s"(byte_off_uniform) : "memory");
 }
 
 struct W4Frag {          // the fragments of one k32 step of one half (hi or lo): [tile][k16 step]
@@ -210,13 +272,26 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         const int vb_next = vb + (int)gridDim.x;
         const bool more = vb_next < ntiles;   // workgroup-uniform
 
+        // accumulators start at bias * 2^e (pre-scaled on the host, exact): the epilogue is (bias * 2^e + sum) * 2^-e with
+        // no bias add.  Register r of MFMA tile (it, *) is weight row nbase + 32 it + 8 (r >> 2) + 4 (lane >> 5) + (r & 3):
+        // eight consecutive floats per (it, r >> 2) through the scalar cache, the lane half selects four of them.
         f32x16 acc[4][4];
+        {
+            const float* bsc = p.bias_scaled + n0 + wn * 128;   // wave-uniform
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+            for (int it = 0; it < 4; ++it) {
+                f32x8 b8[4];
+                w4_sload32(bsc, it * 128, b8[0], b8[1], b8[2], b8[3]);   // one scalar-cache round trip per row block
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[it][jt][e] = 0.0f;
+                    for (int e = 0; e < 4; ++e) {
+                        const float b = hh ? b8[g][4 + e] : b8[g][e];
+#pragma unroll
+                        for (int jt = 0; jt < 4; ++jt) acc[it][jt][g * 4 + e] = b;
+                    }
+            }
+        }
 
         // The slot a phase reads was requested three phases earlier (split mode; one phase earlier in the single-product
         // modes): in steady state exactly the DMA groups (8 instructions per wave each) of the two phases in between are
@@ -328,7 +403,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             asm volatile("" : "+s"(o));
             return o;
         };
-        const float* bs = p.bias + nbase;   // wave-uniform: scalar loads
+        const float lim = 65504.0f / p.descale;   // the fp16 range in the accumulator's scale (descale is a power of two)
 
         if (W4_DBG(1)) {   // ablation: keep the accumulators live, store (almost) nothing
             float sdbg = 0.f;
@@ -357,11 +432,9 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         float v[4];
-                        const f32x8 b8 = w4_sload8(bs, (it * 32 + g * 8) * 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float b = eh ? b8[4 + e] : b8[e];
-                            v[e] = __builtin_fmaf(w4_acc(acc[it][jt][g * 4 + e]), p.descale, b);
+                            v[e] = w4_acc(acc[it][jt][g * 4 + e]) * p.descale;
                             if (RELU) v[e] = __builtin_fmaxf(v[e], 0.0f);
                         }
 #pragma unroll
@@ -419,13 +492,6 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             };
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                float bsel[16];   // bias of this lane's 16 weight rows of row block `it`
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x8 b8 = w4_sload8(bs, (it * 32 + g * 8) * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bsel[g * 4 + e] = eh ? b8[4 + e] : b8[e];
-                }
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
                     const int pass = it * 4 + jt;
@@ -447,29 +513,24 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     for (int g = 0; g < 4; ++g) {
 #pragma unroll
                         for (int e2 = 0; e2 < 2; ++e2) {
-                            float v0 = __builtin_fmaf(w4_acc(acc[it][jt][g * 4 + 2 * e2]), p.descale, bsel[g * 4 + 2 * e2]);
-                            float v1 = __builtin_fmaf(w4_acc(acc[it][jt][g * 4 + 2 * e2 + 1]), p.descale, bsel[g * 4 + 2 * e2 + 1]);
-                            if (RELU) {
-                                asm("v_max_f32 %0, 0, %1" : "=v"(v0) : "v"(v0));
-                                asm("v_max_f32 %0, 0, %1" : "=v"(v1) : "v"(v1));
-                            }
+                            const float a0 = acc[it][jt][g * 4 + 2 * e2], a1 = acc[it][jt][g * 4 + 2 * e2 + 1];
                             unsigned hq, lq;
                             if (NSPLIT == 0) {   // bf16 lines: one bf16 in the hi slot
+                                float v0 = w4_acc(a0) * p.descale, v1 = w4_acc(a1) * p.descale;
+                                if (RELU) {
+                                    v0 = __builtin_fmaxf(v0, 0.0f);
+                                    v1 = __builtin_fmaxf(v1, 0.0f);
+                                }
                                 if (RES) {
                                     v0 += __builtin_bit_cast(float, rh[g][e2] << 16);
                                     v1 += __builtin_bit_cast(float, rh[g][e2] & 0xffff0000u);
                                 }
                                 asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hq) : "v"(v0), "v"(v1));
                                 lq = 0u;
+                            } else if (RES) {
+                                w4_pair_res<RELU>(a0, a1, p.descale, rh[g][e2], rl[g][e2], hq, lq);
                             } else {
-                                if (RES) {
-                                    float r0, r1;
-                                    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r0) : "v"(rh[g][e2]), "v"(rl[g][e2]));
-                                    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r1) : "v"(rh[g][e2]), "v"(rl[g][e2]));
-                                    v0 += r0;
-                                    v1 += r1;
-                                }
-                                w4_split2(v0, v1, hq, lq);
+                                w4_pair_plain(a0, a1, p.descale, RELU ? 0.0f : -lim, lim, hq, lq);
                             }
                             oh[g][e2] = hq;
                             ol[g][e2] = lq;
