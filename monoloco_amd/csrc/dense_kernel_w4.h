@@ -174,11 +174,24 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         goffq[q] = (unsigned)(((lane >> 2) + 16 * q) * (int)rowb + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
     // instruction q (0..3 = W rows, 4..7 = X rows) of this wave's share of ring slot `slot` (odd = lo halves) from the
     // request-stream pointers (rw, rx) = this wave's first row of the k32 step being requested
-    int dma_base = (w * 64) * 64;   // this wave's first row inside a slot's W part (made opaque per phase, see phase_wait)
+    // One asm statement per instruction: SGPR base + 32-bit lane offset + immediate (hipcc's own lowering of the builtin
+    // spends a 64-bit VALU add per instruction on a full 64-bit lane address); M0 is written in the same statement that
+    // uses it (it is compiler-reserved); s_mov + s_nop 3 = the 5 wait states an SALU-written SGPR (the base pointer, wherever
+    // hipcc schedules its update) needs before a VMEM instruction reads it; these loads are invisible to hipcc's vmcnt bookkeeping -- every wait for them is
+    // one of the counted ones below, and the stream is drained before any code hipcc counts for.
+    int dma_base = (int)(size_t)(__attribute__((address_space(3))) char*)smem + (w * 64) * 64;   // LDS byte address of this
+                                                                   // wave's first row in a slot's W part (opaque per phase)
     auto issue1 = [&](const char* rw, const char* rx, int slot, int q) {
         if (W4_DBG(4)) return;
-        char* sb = smem + dma_base + slot * W4_SLOT + (q < 4 ? 0 : W4_XOFF) + (q & 3) * 1024;
-        glds16((q < 4 ? rw : rx) + ((slot & 1) ? 64 : 0) + goffq[q & 3], sb);
+        // (the instruction's immediate offset is added to the global AND to the LDS address: the lo halves' + 64 is taken
+        //  out of M0 again)
+        const int ldsa = dma_base + slot * W4_SLOT + (q < 4 ? 0 : W4_XOFF) + (q & 3) * 1024 - ((slot & 1) ? 64 : 0);
+        if (slot & 1)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:64"
+                         :: "v"(goffq[q & 3]), "s"(q < 4 ? rw : rx), "s"(ldsa) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(goffq[q & 3]), "s"(q < 4 ? rw : rx), "s"(ldsa) : "memory");
     };
 
     // ---- fragment addressing: MFMA 32x32x16, lane l supplies row (l & 31), k = 8 * (l >> 5) .. + 7 of the k16 step,
@@ -247,6 +260,9 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             if (SPLIT) issue1(rq_w, rq_x, 2 * st + 1, q);
         }
         rq_advance();
+        // SALU write of an SGPR -> VMEM read of it needs 5 wait states, and hipcc pads nothing for an asm statement
+        // (in the loop a whole phase start lies between rq_advance and the next request)
+        asm volatile("s_nop 4" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
