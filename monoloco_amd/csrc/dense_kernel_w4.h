@@ -146,10 +146,14 @@ struct W4Frag {          // the fragments of one k32 step of one half (hi or lo)
     half8 x[4][2];       // activations: rows wm*128 + 32*jt + (lane & 31)
 };
 
+// HEAD > 0: the tile is not stored, its HEAD-wide output head is (partial sums);  HEAD == -1: the tile IS stored and, on
+// top, the one-output auxiliary head w_aux (reference architectures.py:60) is accumulated from the very values being
+// stored (hi + lo, what heads_kernel<1> would re-read from HBM: 268 MB and a launch saved); HEAD == 0: plain layer.
 template <int NSPLIT, bool RELU, bool RES, int HEAD>
 __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_kernel_w4(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[W4_LDS];
     constexpr bool SPLIT = NSPLIT == 3;
+    constexpr bool AUX = HEAD < 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -294,6 +298,10 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         f32x16 acc[4][4];
         {
             const float* bsc = p.bias_scaled + n0 + wn * 128;   // wave-uniform
+            // (lane half recomputed here and made opaque: a kernel-lifetime copy gets spilled around the main loop)
+            int il = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(il));
+            const bool upper = il >= 32;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 f32x8 b8[4];
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float b = hh ? b8[g][4 + e] : b8[g][e];
+                        const float b = upper ? b8[g][4 + e] : b8[g][e];
 #pragma unroll
                         for (int jt = 0; jt < 4; ++jt) acc[it][jt][g * 4 + e] = b;
                     }
@@ -490,10 +498,10 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) rq[RES ? pass : 0][qq] = *(const f32x4*)(src + (o + qq * row8));
             };
+            constexpr int RDEPTH = 3;   // residual tiles in flight
             if (RES) {
-                load_res(0);
-                load_res(1);
-                load_res(2);
+#pragma unroll
+                for (int q = 0; q < RDEPTH; ++q) load_res(q);
             }
             f32x4 d[4];
             auto flush = [&](int pass) {   // the transposed lines of `pass` (in d[]) -> global memory
@@ -506,15 +514,25 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     else *(f32x4*)(dst + (o + qq * row8)) = d[qq];
                 }
             };
+            float auxp[4] = {0.f, 0.f, 0.f, 0.f};   // AUX: this lane's part of w_aux . y for its person of row block jt
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
+                float auxw[16];
+                if (AUX) {   // the 16 head weights of this lane's weight rows of row block `it`
+                    f32x8 a8[4];
+                    w4_sload32(p.head_w + nbase, it * 128, a8[0], a8[1], a8[2], a8[3]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) auxw[g * 4 + e] = eh ? a8[g][4 + e] : a8[g][e];
+                }
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
                     const int pass = it * 4 + jt;
                     char* const buf = scr + (pass & 1) * 4096;
                     u32x2 rh[4], rl[4];
                     if (RES) {
-                        if (pass + 3 < 16) load_res(pass + 3);
+                        if (pass + RDEPTH < 16) load_res(pass + RDEPTH);
 #pragma unroll
                         for (int qq = 0; qq < 4; ++qq) *(f32x4*)(buf + rd_off + qq * 1024) = rq[pass][qq];
                         __builtin_amdgcn_wave_barrier();
@@ -550,6 +568,21 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                             }
                             oh[g][e2] = hq;
                             ol[g][e2] = lq;
+                            if (AUX) {   // the stored value itself, hi + lo (bf16 mode: the bf16 value), times its head weight;
+                                         // one statement, so that the two temporaries die at once
+                                if (NSPLIT == 0) {
+                                    auxp[jt] = __builtin_fmaf(__builtin_bit_cast(float, hq << 16), auxw[g * 4 + 2 * e2], auxp[jt]);
+                                    auxp[jt] = __builtin_fmaf(__builtin_bit_cast(float, hq & 0xffff0000u), auxw[g * 4 + 2 * e2 + 1], auxp[jt]);
+                                } else {
+                                    float y0, y1;
+                                    asm("v_fma_mix_f32 %1, %3, 1.0, %4 op_sel_hi:[1,0,1]\n\t"
+                                        "v_fma_mix_f32 %2, %3, 1.0, %4 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n\t"
+                                        "v_fmac_f32 %0, %1, %5\n\t"
+                                        "v_fmac_f32 %0, %2, %6"
+                                        : "+v"(auxp[jt]), "=&v"(y0), "=&v"(y1)
+                                        : "v"(hq), "v"(lq), "v"(auxw[g * 4 + 2 * e2]), "v"(auxw[g * 4 + 2 * e2 + 1]));
+                                }
+                            }
                         }
                     }
                     if (pass > 0) flush(pass - 1);
@@ -567,6 +600,14 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 }
             }
             flush(15);
+            if (AUX) {   // combine the two lane halves (weight rows 4h..4h+3 of every group of 8), one partial per person
+                const int slice = (n0 / BN) * 2 + wn;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const float sum = auxp[jt] + __shfl_xor(auxp[jt], 32, 64);
+                    if (eh == 0) p.head_part[(size_t)slice * p.M_pad + (mbase + jt * 32 + eml)] = sum;
+                }
+            }
         }
 
         stamp(11);

@@ -320,6 +320,18 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
     raw[row * raw_stride + col0 + o] = s;
 }
 
+// second half of the fused w_aux head (dense_kernel_w4<.., HEAD = -1>): raw[row][col0] = bias + sum over the nparts
+// 128-column slices of part[slice][row].  One thread per row.
+__global__ __launch_bounds__(256) void aux_reduce_kernel(const float* __restrict__ part, int nparts, int64_t m_pad, int64_t m,
+                                                        const float* __restrict__ bh, float* __restrict__ raw, int raw_stride,
+                                                        int col0) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= m) return;
+    float s = bh[0];
+    for (int sl = 0; sl < nparts; ++sl) s += part[(int64_t)sl * m_pad + row];
+    raw[row * raw_stride + col0] = s;
+}
+
 // ------------------------------------------------------------------------------------------
 // stereo: per left person the first right index whose aux logit (last column) is maximal, and a
 // global count of left persons with tied maxima (the reference keeps every tied row,

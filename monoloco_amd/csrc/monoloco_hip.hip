@@ -446,6 +446,11 @@ bool use_small_path(int precision, int64_t rows) {
     return dense_variant() != 1 && !dense_debug_bits() && precision != ML_PREC_BF16 && rows <= small_rows_env();
 }
 
+// does the tile path run dense_kernel_w4 for a layer with this K (and fused head width)?
+bool w4_runs(int K, int head_nh) {
+    return g_tile_kernel == 4 && K % 64 == 0 && (g_tile_kernel_all || (K > 128 && head_nh <= 0));
+}
+
 int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0, int64_t rows = -1) {
     mlk::DenseParams p = p_in;
     p.debug = dense_debug_bits();
@@ -482,6 +487,7 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, in
     }
 
     const int tiles = (p.M_pad / mlk::BM) * (p.N / mlk::BN);
+    if (head_nh == -1 && !w4_runs(p.K, 0)) return fail(ML_ERR_STATE, "fused aux head needs dense_kernel_w4");
 #ifdef ML_BRINGUP
     if (dense_variant() == 1) {
         if (precision == ML_PREC_F16X2)
@@ -507,12 +513,16 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, in
     // dense_kernel_w4 for the long-K layers; the short input layer (K <= 128: two or four k-steps per tile, all epilogue)
     // and the layer with the fused output head stay on dense_kernel_pp, whose two waves per SIMD overlap those
     // VALU-heavy epilogues (measured: 0.063 vs 0.077 ms and 0.351 vs 0.381 ms per layer at 65536 rows)
-    if (g_tile_kernel == 4 && p.K % 64 == 0 && (g_tile_kernel_all || (p.K > 128 && head_nh == 0))) {
+    if (w4_runs(p.K, head_nh)) {
 #define ML_W4(NS, RL, RS, HD) \
     hipLaunchKernelGGL((mlk::dense_kernel_w4<NS, RL, RS, HD>), dim3(grid), dim3(mlk::W4_THREADS), 0, st, p)
 #define ML_W4_NS(NS)                                              \
     do {                                                          \
-        if (head_nh == 8) ML_W4(NS, true, false, 8);              \
+        if (head_nh == -1) {                                      \
+            if (p.relu && p.res) ML_W4(NS, true, true, -1);       \
+            else if (!p.relu && !p.res) ML_W4(NS, false, false, -1); \
+            else return fail(ML_ERR_STATE, "fused aux head: unsupported layer form"); \
+        } else if (head_nh == 8) ML_W4(NS, true, false, 8);       \
         else if (head_nh == 9) ML_W4(NS, true, false, 9);         \
         else if (p.relu) {                                        \
             if (p.res) ML_W4(NS, true, true, 0);                  \
@@ -644,9 +654,21 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                 p.head_w = fused->d_w;
                 p.head_part = h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16;
             }
+            // the one-output w_aux head rides in the store epilogue of the layer that produces its input (w4 kernel:
+            // residual+relu layer when w3*w2 are merged, the plain w2 layer otherwise); its partials share d_part, which
+            // the w_fin head of a LATER launch overwrites only after aux_reduce_kernel has consumed them (stream order)
+            const Head* fused_aux = nullptr;
+            if (!fused && !small && mc.p <= 0.f && !dense_debug_bits() && dense_variant() != 1 && w4_runs(L.kpad, 0) &&
+                ((L.relu && L.res >= 0) || (!L.relu && L.res < 0)))
+                for (const Head& hd : h->heads)
+                    if (hd.after_layer == (int)li && hd.nh == 1 && hd.src == L.dst) fused_aux = &hd;
+            if (fused_aux) {
+                p.head_w = fused_aux->d_w;
+                p.head_part = h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16;
+            }
             const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
             if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
-            int rc = launch_dense(h->precision, p, st, fused ? fused->nh : 0, small ? rows_here : -1);
+            int rc = launch_dense(h->precision, p, st, fused ? fused->nh : (fused_aux ? -1 : 0), small ? rows_here : -1);
             if (rc) return rc;
             if (timed) {
                 HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));
@@ -658,6 +680,12 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                                    (const float*)(h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16), 2 * h->hidden / 256, m_pad,
                                    rows_here, fused->nh,
                                    (const float*)fused->d_b, raw_out + r0 * h->out_f, h->out_f, fused->col0);
+                HIP_TRY(hipGetLastError());
+            }
+            if (fused_aux && rows_here > 0) {
+                hipLaunchKernelGGL(mlk::aux_reduce_kernel, dim3((unsigned)((rows_here + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)(h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16), 2 * h->hidden / 256, m_pad,
+                                   rows_here, (const float*)fused_aux->d_b, raw_out + r0 * h->out_f, h->out_f, fused_aux->col0);
                 HIP_TRY(hipGetLastError());
             }
             if (mc.p > 0.f) {
@@ -694,7 +722,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                 }
             } else if (rows_here > 0) {
                 for (const Head& hd : h->heads)
-                    if (hd.after_layer == (int)li && &hd != fused) {
+                    if (hd.after_layer == (int)li && &hd != fused && &hd != fused_aux) {
                         rc = launch_heads(hd, at(hd.src), h->hidden, raw_out + r0 * h->out_f, h->out_f, rows_here, st,
                                           h->precision == ML_PREC_BF16);
                         if (rc) return rc;
