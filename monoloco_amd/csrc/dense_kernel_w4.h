@@ -498,7 +498,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) rq[RES ? pass : 0][qq] = *(const f32x4*)(src + (o + qq * row8));
             };
-            constexpr int RDEPTH = 3;   // residual tiles in flight
+            constexpr int RDEPTH = 3;   // residual tiles in flight (deeper does not help: 8 = same time; the tile-wide burst is HBM-bound)
             if (RES) {
 #pragma unroll
                 for (int q = 0; q < RDEPTH; ++q) load_res(q);
