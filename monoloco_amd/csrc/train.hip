@@ -190,14 +190,47 @@ int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* r
 
 // dout: gradient wrt the block output (m x H), overwritten with dz; xhat: scratch (m x H).  Produces the
 // parameter gradients of the block; the caller propagates dz through the Linear to the block input.
+// fresh pre-zeroed fp64 reduction slot (2 * H + 32 doubles): see col_stats
+int next_red_slot(ml_trainer* t, hipStream_t st) {
+    if (t->red_slot + 1 < RED_SLOTS) {
+        t->d_red = t->d_red_base + (size_t)(++t->red_slot) * (2 * t->H + 32);
+    } else {
+        T_TRY(hipMemsetAsync(t->d_red, 0, (size_t)(2 * t->H + 32) * sizeof(double), st));
+    }
+    return 0;
+}
+
 int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, float* xhat) {
     const int H = t->H;
     float* mean = t->bn_mean + (size_t)b.bn_idx * H;
     float* inv = t->bn_invstd + (size_t)b.bn_idx * H;
+    const uint32_t seed = t->seed + (uint32_t)t->step * 977u;
+    int rc;
+    if ((H & 3) == 0) {
+        // fused chain (train_kernels.h): pass 1 = sum(dy), sum(dy * xhat) with dy / xhat recomputed from (dout, z); pass 2 =
+        // dz over dout + column sums of dz.  4 reads + 1 write of an (m, H) matrix instead of 7 + 3; bit-identical results.
+        int gy = (int)((m + 255) / 256);
+        if (gy > 128) gy = 128;
+        if (gy < 1) gy = 1;
+        if ((rc = next_red_slot(t, st))) return rc;
+        double* s_dy = t->d_red;
+        hipLaunchKernelGGL(mlt::bwd_stats_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, (const float*)dout, (const float*)b.z, m, H,
+                           (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
+                           (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, s_dy, s_dy + H);
+        if ((rc = next_red_slot(t, st))) return rc;
+        double* s_dz = t->d_red;
+        hipLaunchKernelGGL(mlt::bn_bwd_fused_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, dout, (const float*)b.z, m, H,
+                           (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
+                           (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, (const double*)s_dy,
+                           (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz);
+        hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)s_dz, H,
+                           G(t, b.lin + ".bias"));
+        return linear_bwd_weight(t, st, dout, H, b.x, b.in_dim, G(t, b.lin + ".weight"), (int)m, H, b.in_dim);
+    }
     hipLaunchKernelGGL(mlt::relu_drop_bwd_kernel, dim3(nblk(m * H)), dim3(256), 0, st, dout, (const float*)b.z, m, H,
                        (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
-                       (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site, xhat);
-    int rc = col_stats(t, st, dout, xhat, m, H);  // sum(dy), sum(dy*xhat)
+                       (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, xhat);
+    rc = col_stats(t, st, dout, xhat, m, H);  // sum(dy), sum(dy*xhat)
     if (rc) return rc;
     hipLaunchKernelGGL(mlt::bn_bwd_kernel, dim3(nblk(m * H)), dim3(256), 0, st, dout, (const float*)xhat, m, H,
                        (const double*)t->d_red, (const double*)(t->d_red + H), (const float*)P(t, b.bn + ".weight"),

@@ -303,6 +303,123 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(float* __restrict__ dy, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The backward element-wise chain of a block, fused (round 2).  Before: relu_drop_bwd (dy, xhat written), col_stats(dy,
+// xhat), bn_bwd (dz written), col_stats(dz) = 7 reads + 3 writes of an (m, n) fp32 matrix.  Now two passes that recompute
+// dy and xhat from (dout, z) on the fly: 4 reads + 1 write.  Same per-element arithmetic and the same thread -> (column
+// group, row group) mapping and fp64 summation order as col_stats_kernel, so the results are bit-identical.
+//   dy   = dout * [gamma * xhat + beta > 0] * dropout_mask / (1 - p),   xhat = (z - mean) * invstd
+__device__ __forceinline__ void bwd_elem(float dout, float z, float mean, float invstd, float gamma, float beta, float p_drop,
+                                         uint32_t seed, uint32_t site, int64_t i, int j, float& dy, float& xh) {
+    xh = (z - mean) * invstd;
+    const float pre = gamma * xh + beta;
+    float g = pre > 0.f ? dout : 0.f;
+    if (p_drop > 0.f) g = (mlk::u01(seed, (uint32_t)i * 4099u + site, (uint32_t)j) >= p_drop) ? g / (1.f - p_drop) : 0.f;
+    dy = g;
+}
+
+// pass 1: s1[j] += sum_i dy[i][j], s2[j] += sum_i dy[i][j] * xhat[i][j]   (nothing written but the sums); n % 4 == 0
+__global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict__ dout, const float* __restrict__ z, int64_t m,
+                                                       int n, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float p_drop, uint32_t seed, uint32_t site, double* __restrict__ s1,
+                                                       double* __restrict__ s2) {
+    __shared__ double r1[16][64], r2[16][64];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j0 = blockIdx.x * 64 + cg * 4;
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t step = (int64_t)gridDim.y * 16;
+    if (j0 + 3 < n) {
+        const f32x4 mu = *(const f32x4*)(mean + j0), is = *(const f32x4*)(invstd + j0);
+        const f32x4 ga = *(const f32x4*)(gamma + j0), be = *(const f32x4*)(beta + j0);
+        for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += step) {
+            const f32x4 d = *(const f32x4*)(dout + i * n + j0);
+            const f32x4 zz = *(const f32x4*)(z + i * n + j0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float dy, xh;
+                bwd_elem(d[e], zz[e], mu[e], is[e], ga[e], be[e], p_drop, seed, site, i, j0 + e, dy, xh);
+                a[e] += (double)dy;
+                b[e] += (double)dy * (double)xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r1[rg][cg * 4 + e] = a[e];
+        r2[rg][cg * 4 + e] = b[e];
+    }
+    __syncthreads();
+    const int cj = threadIdx.x;
+    if (cj < 64 && blockIdx.x * 64 + cj < n) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            sa += r1[g][cj];
+            sb += r2[g][cj];
+        }
+        atomicAdd(&s1[blockIdx.x * 64 + cj], sa);
+        atomicAdd(&s2[blockIdx.x * 64 + cj], sb);
+    }
+}
+
+// pass 2: dz = gamma * invstd / m * (m * dy - sum(dy) - xhat * sum(dy * xhat)) written over dout, and the column sums of
+// dz (the Linear bias gradient) accumulated into sdz on the way; also publishes dgamma / dbeta.
+__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(float* __restrict__ dout, const float* __restrict__ z, int64_t m, int n,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float p_drop, uint32_t seed, uint32_t site,
+                                                          const double* __restrict__ sdy, const double* __restrict__ sdyx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          double* __restrict__ sdz) {
+    __shared__ double r1[16][64];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j0 = blockIdx.x * 64 + cg * 4;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t step = (int64_t)gridDim.y * 16;
+    if (j0 + 3 < n) {
+        const f32x4 mu = *(const f32x4*)(mean + j0), is = *(const f32x4*)(invstd + j0);
+        const f32x4 ga = *(const f32x4*)(gamma + j0), be = *(const f32x4*)(beta + j0);
+        float sa[4], sb[4], gg[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sa[e] = (float)sdy[j0 + e];
+            sb[e] = (float)sdyx[j0 + e];
+            gg[e] = ga[e] * is[e] / (float)m;
+        }
+        for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += step) {
+            const f32x4 d = *(const f32x4*)(dout + i * n + j0);
+            const f32x4 zz = *(const f32x4*)(z + i * n + j0);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float dy, xh;
+                bwd_elem(d[e], zz[e], mu[e], is[e], ga[e], be[e], p_drop, seed, site, i, j0 + e, dy, xh);
+                o[e] = gg[e] * ((float)m * dy - sa[e] - xh * sb[e]);
+                a[e] += (double)o[e];
+            }
+            *(f32x4*)(dout + i * n + j0) = o;
+        }
+        if (blockIdx.y == 0 && rg == 0) {  // one thread per column publishes the parameter gradients
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dgamma[j0 + e] = (float)sdyx[j0 + e];
+                dbeta[j0 + e] = (float)sdy[j0 + e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r1[rg][cg * 4 + e] = a[e];
+    __syncthreads();
+    const int cj = threadIdx.x;
+    if (cj < 64 && blockIdx.x * 64 + cj < n) {
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += r1[g][cj];
+        atomicAdd(&sdz[blockIdx.x * 64 + cj], s);
+    }
+}
+
 __global__ __launch_bounds__(256) void col_sum_to_float_kernel(const double* __restrict__ s, int n, float* __restrict__ out) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < n) out[j] = (float)s[j];
