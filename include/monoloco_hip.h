@@ -281,6 +281,10 @@ int ml_debug_set_tuning(int small_rows, int small32_rows, int chunk_rows);
  * input layer and the fused-head layer (default); 2 = dense_kernel_pp everywhere; 4 | 256 = dense_kernel_w4 wherever it
  * can run (tests). */
 int ml_debug_set_tile_kernel(int which);
+/* Training: batches of at least `rows` rows run the forward and data-gradient GEMMs of the hidden x hidden layers (hidden % 256 == 0) on the
+ * inference path's 3-product fp16 MFMA kernel with fp32 output, smaller ones on the exact-fp32 MFMA GEMM (default 4096;
+ * 0 = never).  Process-global test hook. */
+int ml_debug_set_train_fast_rows(int64_t rows);
 /* Packed fp16 hi|lo line image of a dense layer's weights (n * kpad * 2 uint16); only kept for
  * models finalized with ML_FLAG_HOST_ONLY. */
 int ml_debug_get_packed(const ml_loco* h, int layer, uint16_t* lines_host, int64_t capacity);

@@ -46,6 +46,7 @@ struct DenseParams {
     const char* res;    // [M_pad][N] line format or nullptr (may alias y: same tile, same threads)
     char* y;            // [M_pad][N] line format
     float descale;      // 2^-e
+    const float* descale_ptr;  // if not null: 2^-e lives on the device (weights packed on the device, training path)
     int M_pad, N, K;    // M_pad % 256 == 0, N % 256 == 0, K % 32 == 0
     int relu;
     int debug;          // bring-up/ablation bits (0 in production), see dense_kernel_pp.h

@@ -64,6 +64,7 @@ __device__ __forceinline__ void w4_split2(float v0, float v1, unsigned& h, unsig
 // 8 consecutive floats through the scalar cache (s_load_dwordx8): the bias of one (row block, register group) for both
 // lane halves.  An ordinary vector load here would make hipcc drain vmcnt(0) and break the epilogue's counted waits.
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x8 w4_sload8(const float* base_uniform, int byte_off_uniform) {
     f32x8 v;
     asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base_uniform), "s"(byte_off_uniform) : "memory");
@@ -148,12 +149,16 @@ struct W4Frag {          // the fragments of one k32 step of one half (hi or lo)
 
 // HEAD > 0: the tile is not stored, its HEAD-wide output head is (partial sums);  HEAD == -1: the tile IS stored and, on
 // top, the one-output auxiliary head w_aux (reference architectures.py:60) is accumulated from the very values being
-// stored (hi + lo, what heads_kernel<1> would re-read from HBM: 268 MB and a launch saved); HEAD == 0: plain layer.
+// stored (hi + lo, what heads_kernel<1> would re-read from HBM: 268 MB and a launch saved); HEAD == 0: plain layer;
+// HEAD == -2: the tile is stored as plain fp32 rows (y = [M_pad][N] floats: the pre-BatchNorm z of the TRAINING forward,
+// csrc/train.hip) -- 32 floats of a row are 128 bytes, so addressing and transposition are those of the line format;
+// with RES, res = an fp32 [M_pad][N] matrix that is ADDED (may alias y: the data-gradient GEMM accumulating into da).
 template <int NSPLIT, bool RELU, bool RES, int HEAD>
 __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_kernel_w4(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[W4_LDS];
     constexpr bool SPLIT = NSPLIT == 3;
-    constexpr bool AUX = HEAD < 0;
+    constexpr bool AUX = HEAD == -1;
+    constexpr bool F32OUT = HEAD == -2;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const size_t rowb = (size_t)p.K * 4;
     const size_t yrowb = (size_t)p.N * 4;
     const int nk = p.K / 32;   // even (K % 64 == 0, guaranteed by the host)
+    const float descale = p.descale_ptr ? *p.descale_ptr : p.descale;   // (before the first LDS-DMA: an ordinary load)
 
     // ---- LDS-DMA duty: per slot a wave fetches 64 W rows and 64 X rows, 4 instructions of 16 rows x 64 B each.
     // lane -> (row = lane / 4, position = lane % 4); the LDS image is lane-linear, the bank swizzle
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             asm volatile("" : "+s"(o));
             return o;
         };
-        const float lim = 65504.0f / p.descale;   // the fp16 range in the accumulator's scale (descale is a power of two)
+        const float lim = 65504.0f / descale;   // the fp16 range in the accumulator's scale (descale is a power of two)
 
         if (W4_DBG(1)) {   // ablation: keep the accumulators live, store (almost) nothing
             float sdbg = 0.f;
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = w4_acc(acc[it][jt][g * 4 + e]) * p.descale;
+                            v[e] = w4_acc(acc[it][jt][g * 4 + e]) * descale;
                             if (RELU) v[e] = __builtin_fmaxf(v[e], 0.0f);
                         }
 #pragma unroll
@@ -533,6 +539,8 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     u32x2 rh[4], rl[4];
                     if (RES) {
                         if (pass + RDEPTH < 16) load_res(pass + RDEPTH);
+                    }
+                    if (RES && !F32OUT) {
 #pragma unroll
                         for (int qq = 0; qq < 4; ++qq) *(f32x4*)(buf + rd_off + qq * 1024) = rq[pass][qq];
                         __builtin_amdgcn_wave_barrier();
@@ -549,8 +557,16 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                         for (int e2 = 0; e2 < 2; ++e2) {
                             const float a0 = acc[it][jt][g * 4 + 2 * e2], a1 = acc[it][jt][g * 4 + 2 * e2 + 1];
                             unsigned hq, lq;
-                            if (NSPLIT == 0) {   // bf16 lines: one bf16 in the hi slot
-                                float v0 = w4_acc(a0) * p.descale, v1 = w4_acc(a1) * p.descale;
+                            if (F32OUT) {   // plain fp32: hq / lq carry the two floats of the pair
+                                float v0 = w4_acc(a0) * descale, v1 = w4_acc(a1) * descale;
+                                if (RELU) {
+                                    v0 = __builtin_fmaxf(v0, 0.0f);
+                                    v1 = __builtin_fmaxf(v1, 0.0f);
+                                }
+                                hq = __builtin_bit_cast(unsigned, v0);
+                                lq = __builtin_bit_cast(unsigned, v1);
+                            } else if (NSPLIT == 0) {   // bf16 lines: one bf16 in the hi slot
+                                float v0 = w4_acc(a0) * descale, v1 = w4_acc(a1) * descale;
                                 if (RELU) {
                                     v0 = __builtin_fmaxf(v0, 0.0f);
                                     v1 = __builtin_fmaxf(v1, 0.0f);
@@ -562,9 +578,9 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                                 asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hq) : "v"(v0), "v"(v1));
                                 lq = 0u;
                             } else if (RES) {
-                                w4_pair_res<RELU>(a0, a1, p.descale, rh[g][e2], rl[g][e2], hq, lq);
+                                w4_pair_res<RELU>(a0, a1, descale, rh[g][e2], rl[g][e2], hq, lq);
                             } else {
-                                w4_pair_plain(a0, a1, p.descale, RELU ? 0.0f : -lim, lim, hq, lq);
+                                w4_pair_plain(a0, a1, descale, RELU ? 0.0f : -lim, lim, hq, lq);
                             }
                             oh[g][e2] = hq;
                             ol[g][e2] = lq;
@@ -590,12 +606,20 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     // execute in order)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        *(u32x2*)(buf + scr_row + ((g ^ (eml & 7)) * 16)) = oh[g];
-                        *(u32x2*)(buf + scr_row + (((g + 4) ^ (eml & 7)) * 16)) = ol[g];
+                        if (F32OUT) {   // 4 consecutive floats of this person = 16-byte chunk 2g + (lane half) of its 128-byte row
+                            u32x4 q4 = {oh[g][0], ol[g][0], oh[g][1], ol[g][1]};
+                            *(u32x4*)(buf + eml * LINE + (((2 * g + eh) ^ (eml & 7)) * 16)) = q4;
+                        } else {
+                            *(u32x2*)(buf + scr_row + ((g ^ (eml & 7)) * 16)) = oh[g];
+                            *(u32x2*)(buf + scr_row + (((g + 4) ^ (eml & 7)) * 16)) = ol[g];
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) d[qq] = *(const f32x4*)(buf + rd_off + qq * 1024);
+                    for (int qq = 0; qq < 4; ++qq) {
+                        d[qq] = *(const f32x4*)(buf + rd_off + qq * 1024);
+                        if (F32OUT && RES) d[qq] += rq[pass][qq];   // fp32 accumulate: the residual is fp32 in store layout already
+                    }
                     __builtin_amdgcn_sched_barrier(0);  // one region per pass: interleaving more of them costs registers
                 }
             }

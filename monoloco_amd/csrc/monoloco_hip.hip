@@ -636,6 +636,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             p.res = L.res >= 0 ? at(L.res) : nullptr;
             p.y = at(L.dst);
             p.descale = std::ldexp(1.0f, -L.scale_pow2);
+            p.descale_ptr = nullptr;
             p.M_pad = (int)m_pad;
             p.N = L.n;
             p.K = L.kpad;
@@ -1359,6 +1360,7 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
         p.res = rl;
         p.y = res_dev ? rl : yl;  // exercises the in-place residual form the model uses
         p.descale = std::ldexp(1.0f, -L.scale_pow2);
+        p.descale_ptr = nullptr;
         p.M_pad = (int)m_pad;
         p.N = n;
         p.K = L.kpad;

@@ -3,7 +3,9 @@
 //   model.train() forward (batch-stat BatchNorm + running-stat update, dropout)  architectures.py:48-102
 //   MultiTaskLoss                                                               losses.py:59-73, 112-131
 //   backward, clip_grad_norm_(3), Adam, per-batch StepLR                        trainer.py:157-161, 128-131
-// fp32 throughout (exact-fp32 MFMA), reductions in fp64.  Kernels: train_kernels.h.
+// fp32 throughout, reductions in fp64.  GEMMs: exact-fp32 MFMA (sgemm_kernel); from g_train_fast_rows rows on, the forward
+// and data-gradient GEMMs of the hidden x hidden layers run on the inference path's 3-product fp16 MFMA kernel
+// (dense_kernel_w4<3, false, *, -2>, fp32 in / fp32 out, fp32-class accuracy).  Kernels: train_kernels.h.
 #include "../../include/monoloco_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -17,6 +19,7 @@
 #include <vector>
 
 #include "train_kernels.h"
+#include "dense_kernel_w4.h"
 
 namespace {
 
@@ -66,7 +69,19 @@ struct ml_trainer {
     float* d_splitk = nullptr;                        // split-K partials of the weight-gradient GEMMs
     size_t splitk_cap = 0;                            // floats
     int nbn = 0;
+    // fast path (3-product fp16 MFMA GEMMs, see fast_linear_fwd / fast_linear_bwd_data): line-format copies of the
+    // activations that feed an H x H Linear (backward: of dz), and per such Linear the device-packed weights
+    std::vector<char*> lbufs;                         // 2S + 2 buffers of cap x H lines
+    std::vector<char*> wl;                            // 2S + 2 packed weight images (H x H lines)
+    std::vector<float*> wbs;                          // bias * 2^e
+    float* wsc_base = nullptr;                        // per image {2^e, 2^-e, bits of max|W|, -}
+    float* zero_bias = nullptr;                       // H zeros (the data-gradient GEMMs have no bias)
+    int n_cu = 256;
 };
+
+// rows from which the forward and data-gradient GEMMs of the H x H layers run on the 3-product fp16 MFMA kernel (0 = never); process-global,
+// ml_debug_set_train_fast_rows is the only writer
+int64_t g_train_fast_rows = 4096;
 
 namespace {
 
@@ -172,9 +187,71 @@ struct Block {  // Linear + BatchNorm + ReLU + Dropout
     uint32_t site;
 };
 
-int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* residual) {
+// one launch of the inference path's dense kernel with the fp32 epilogue: out (m x H fp32) [+]= x_lines . w_lines^T + bias
+int launch_fast_gemm(ml_trainer* t, hipStream_t st, const char* x_lines, const char* w_lines, const float* bias_scaled,
+                     const float* descale_ptr, float* out, int64_t m, bool accumulate) {
     const int H = t->H;
-    int rc = linear_fwd(t, st, b.x, b.in_dim, P(t, b.lin + ".weight"), P(t, b.lin + ".bias"), b.z, H, (int)m, H, b.in_dim);
+    mlk::DenseParams p;
+    p.x = x_lines;
+    p.w = w_lines;
+    p.bias = nullptr;
+    p.bias_scaled = bias_scaled;
+    p.res = accumulate ? (const char*)out : nullptr;
+    p.y = (char*)out;
+    p.descale = 1.0f;
+    p.descale_ptr = descale_ptr;
+    p.M_pad = (int)((m + 255) / 256 * 256);
+    p.N = H;
+    p.K = H;
+    p.relu = 0;
+    p.debug = 0;
+    p.trace = nullptr;
+    p.head_w = nullptr;
+    p.head_part = nullptr;
+    const int tiles = (p.M_pad / mlk::BM) * (p.N / mlk::BN);
+    const dim3 grid(tiles < t->n_cu ? tiles : t->n_cu), block(mlk::W4_THREADS);
+    if (accumulate) hipLaunchKernelGGL((mlk::dense_kernel_w4<3, false, true, -2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((mlk::dense_kernel_w4<3, false, false, -2>), grid, block, 0, st, p);
+    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "fast GEMM launch failed");
+    return 0;
+}
+
+// z (m x H, fp32) = x . W^T + b for an H x H Linear whose input exists as lines: the weights are scaled / split / packed on
+// the device (they change every step), then ONE launch of the inference path's dense kernel with the fp32 epilogue
+// (dense_kernel_w4<3, false, false, -2>): 3 fp16 MFMAs per product, fp32 accumulate -- fp32-class accuracy (~2^-22
+// relative per operand) at ~3x the rate of the exact-fp32 MFMA GEMM.  `slot` = which packed-weight image to use.
+int fast_linear_fwd(ml_trainer* t, hipStream_t st, const char* x_lines, const std::string& lin, float* z, int64_t m, int slot) {
+    const int H = t->H;
+    float* sc = t->wsc_base + 4 * slot;   // (zeroed at the start of the step)
+    hipLaunchKernelGGL(mlt::wmax_kernel, dim3(64), dim3(256), 0, st, (const float*)P(t, lin + ".weight"), (int64_t)H * H, sc);
+    hipLaunchKernelGGL(mlt::wpack_kernel<false>, dim3(nblk((int64_t)H * H / 8)), dim3(256), 0, st, (const float*)P(t, lin + ".weight"),
+                       (const float*)P(t, lin + ".bias"), H, H, H, sc, t->wl[slot], t->wbs[slot]);
+    return launch_fast_gemm(t, st, x_lines, t->wl[slot], t->wbs[slot], sc + 1, z, m, false);
+}
+
+// dx (m x H, fp32) [+]= dz . W for the same Linear, dz given as lines: the image of W^T replaces the forward image (which
+// the step no longer needs), its scale is the forward's.
+int fast_linear_bwd_data(ml_trainer* t, hipStream_t st, const char* dz_lines, const std::string& lin, float* dx, int64_t m, int slot,
+                         bool accumulate) {
+    const int H = t->H;
+    float* sc = t->wsc_base + 4 * slot;
+    hipLaunchKernelGGL(mlt::wpack_kernel<true>, dim3(nblk((int64_t)H * H / 8)), dim3(256), 0, st, (const float*)P(t, lin + ".weight"),
+                       (const float*)nullptr, H, H, H, sc, t->wl[slot], (float*)nullptr);
+    return launch_fast_gemm(t, st, dz_lines, t->wl[slot], t->zero_bias, sc + 1, dx, m, accumulate);
+}
+
+bool fast_rows(const ml_trainer* t, int64_t m) {
+    return g_train_fast_rows > 0 && m >= g_train_fast_rows && t->H % 256 == 0 && !t->lbufs.empty();
+}
+
+// x_lines: the block input as lines (or null: exact-fp32 MFMA GEMM on b.x); y_lines: where to put the block output as
+// lines as well (or null)
+int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* residual, const char* x_lines = nullptr,
+              char* y_lines = nullptr, int slot = -1) {
+    const int H = t->H;
+    int rc;
+    if (x_lines && slot >= 0) rc = fast_linear_fwd(t, st, x_lines, b.lin, b.z, m, slot);
+    else rc = linear_fwd(t, st, b.x, b.in_dim, P(t, b.lin + ".weight"), P(t, b.lin + ".bias"), b.z, H, (int)m, H, b.in_dim);
     if (rc) return rc;
     if ((rc = col_stats(t, st, b.z, nullptr, m, H))) return rc;
     float* mean = t->bn_mean + (size_t)b.bn_idx * H;
@@ -182,9 +259,15 @@ int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* r
     hipLaunchKernelGGL(mlt::bn_finalize_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red,
                        (const double*)(t->d_red + H), m, H, 1e-5f, 0.1f, mean, inv, ST(t, b.bn + ".running_mean"),
                        ST(t, b.bn + ".running_var"));
-    hipLaunchKernelGGL(mlt::bn_relu_drop_kernel, dim3(nblk(m * H)), dim3(256), 0, st, (const float*)b.z, m, H,
-                       (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
-                       (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site, residual, b.y);
+    if (y_lines)
+        hipLaunchKernelGGL(mlt::bn_relu_drop_lines_kernel, dim3(nblk(m * H / 4)), dim3(256), 0, st, (const float*)b.z, m, H,
+                           (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
+                           (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site, residual, b.y,
+                           y_lines);
+    else
+        hipLaunchKernelGGL(mlt::bn_relu_drop_kernel, dim3(nblk(m * H)), dim3(256), 0, st, (const float*)b.z, m, H,
+                           (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
+                           (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site, residual, b.y);
     return 0;
 }
 
@@ -200,7 +283,7 @@ int next_red_slot(ml_trainer* t, hipStream_t st) {
     return 0;
 }
 
-int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, float* xhat) {
+int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, float* xhat, char* dz_lines = nullptr) {
     const int H = t->H;
     float* mean = t->bn_mean + (size_t)b.bn_idx * H;
     float* inv = t->bn_invstd + (size_t)b.bn_idx * H;
@@ -222,7 +305,7 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
         hipLaunchKernelGGL(mlt::bn_bwd_fused_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, dout, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
                            (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, (const double*)s_dy,
-                           (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz);
+                           (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz, dz_lines);
         hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)s_dz, H,
                            G(t, b.lin + ".bias"));
         return linear_bwd_weight(t, st, dout, H, b.x, b.in_dim, G(t, b.lin + ".weight"), (int)m, H, b.in_dim);
@@ -244,9 +327,36 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
 
 int ensure_cap(ml_trainer* t, int64_t m) {
     if (m <= t->cap) return 0;
+    m = (m + 255) / 256 * 256;   // whole 256-row panels: the fast forward GEMM writes full tiles
     T_TRY(hipDeviceSynchronize());
     for (float* p : t->bufs) (void)hipFree(p);
     t->bufs.clear();
+    for (char* p : t->lbufs) (void)hipFree(p);
+    t->lbufs.clear();
+    if (t->H % 256 == 0) {
+        for (int i = 0; i < 2 * t->S + 2; ++i) {
+            char* p = nullptr;
+            T_TRY(hipMalloc((void**)&p, (size_t)m * t->H * 4));
+            t->lbufs.push_back(p);
+        }
+        if (t->wl.empty()) {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                t->n_cu = prop.multiProcessorCount;
+            T_TRY(hipMalloc((void**)&t->wsc_base, (size_t)(2 * t->S + 2) * 16));
+            T_TRY(hipMalloc((void**)&t->zero_bias, (size_t)t->H * 4));
+            T_TRY(hipMemset(t->zero_bias, 0, (size_t)t->H * 4));
+            for (int i = 0; i < 2 * t->S + 2; ++i) {
+                char* w = nullptr;
+                float* b = nullptr;
+                T_TRY(hipMalloc((void**)&w, (size_t)t->H * t->H * 4));
+                T_TRY(hipMalloc((void**)&b, (size_t)t->H * 4));
+                t->wl.push_back(w);
+                t->wbs.push_back(b);
+            }
+        }
+    }
     if (t->d_out) (void)hipFree(t->d_out);
     if (t->d_dout) (void)hipFree(t->d_dout);
     const int nb = 4 * t->S + 8;  // a_s (S+1), t_s (S), z (2S+2), y2, y3, xhat, 2 gradient buffers
@@ -314,7 +424,10 @@ int ml_trainer_destroy(ml_trainer* t) {
     if (!t) return ML_OK;
     (void)hipDeviceSynchronize();
     for (float* p : t->bufs) (void)hipFree(p);
-    void* ptrs[] = {t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    for (char* p : t->lbufs) (void)hipFree(p);
+    for (char* p : t->wl) (void)hipFree(p);
+    for (float* p : t->wbs) (void)hipFree(p);
+    void* ptrs[] = {t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -348,6 +461,11 @@ int ml_trainer_get_grad(ml_trainer* t, const char* key, float* host_data, int64_
 }
 int64_t ml_trainer_num_steps(const ml_trainer* t) { return t ? t->step : 0; }
 
+int ml_debug_set_train_fast_rows(int64_t rows) {
+    g_train_fast_rows = rows < 0 ? 0 : rows;
+    return ML_OK;
+}
+
 int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m,
                     int update, double* losses_host, float* raw_out_dev, void* stream) {
     if (!t || !x_dev || !labels_dev || m <= 1 || label_cols < 10) return tfail(ML_ERR_ARG, "bad argument");
@@ -377,22 +495,32 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     std::vector<Block> blocks;
     Block b0;
     b0.lin = "w1"; b0.bn = "batch_norm1"; b0.bn_idx = 0; b0.in_dim = t->in_f; b0.x = x_dev; b0.z = z0; b0.y = a[0]; b0.site = 0;
-    if ((rc = block_fwd(t, st, b0, m, nullptr))) return rc;
+    // fast forward path: the activations that feed an H x H Linear also exist as lines (la[s] = a_s, lt[s] = t_s, ly2 = y2);
+    // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
+    const bool fast = fast_rows(t, m);
+    if (fast) T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 2) * 16, st));
+    auto la = [&](int s) { return fast ? t->lbufs[s] : (char*)nullptr; };
+    auto lt = [&](int s) { return fast ? t->lbufs[S + 1 + s] : (char*)nullptr; };
+    char* ly2 = fast ? t->lbufs[2 * S + 1] : nullptr;
+    if ((rc = block_fwd(t, st, b0, m, nullptr, nullptr, la(0)))) return rc;
     std::vector<Block> sa(S), sb(S);
     for (int s = 0; s < S; ++s) {
         const std::string p = "linear_stages." + std::to_string(s) + ".";
         sa[s].lin = p + "w1"; sa[s].bn = p + "batch_norm1"; sa[s].bn_idx = 1 + 2 * s; sa[s].in_dim = H;
         sa[s].x = a[s]; sa[s].z = za[s]; sa[s].y = tt[s]; sa[s].site = 1 + 2 * s;
-        if ((rc = block_fwd(t, st, sa[s], m, nullptr))) return rc;
+        if ((rc = block_fwd(t, st, sa[s], m, nullptr, la(s), lt(s), fast ? 2 * s : -1))) return rc;
         sb[s].lin = p + "w2"; sb[s].bn = p + "batch_norm2"; sb[s].bn_idx = 2 + 2 * s; sb[s].in_dim = H;
         sb[s].x = tt[s]; sb[s].z = zb[s]; sb[s].y = a[s + 1]; sb[s].site = 2 + 2 * s;
-        if ((rc = block_fwd(t, st, sb[s], m, a[s]))) return rc;  // a_{s+1} = a_s + block(t_s)
+        if ((rc = block_fwd(t, st, sb[s], m, a[s], lt(s), la(s + 1), fast ? 2 * s + 1 : -1))) return rc;  // a_{s+1} = a_s + block(t_s)
     }
-    if ((rc = linear_fwd(t, st, a[S], H, P(t, "w2.weight"), P(t, "w2.bias"), y2, H, (int)m, H, H))) return rc;
+    if (fast) {
+        if ((rc = fast_linear_fwd(t, st, la(S), "w2", y2, m, 2 * S))) return rc;
+        hipLaunchKernelGGL(mlt::act_lines_kernel, dim3(nblk(m * H / 8)), dim3(256), 0, st, (const float*)y2, m, H, ly2);
+    } else if ((rc = linear_fwd(t, st, a[S], H, P(t, "w2.weight"), P(t, "w2.bias"), y2, H, (int)m, H, H))) return rc;
     if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
     Block b3;
     b3.lin = "w3"; b3.bn = "batch_norm3"; b3.bn_idx = 2 * S + 1; b3.in_dim = H; b3.x = y2; b3.z = z3; b3.y = y3; b3.site = 2 * S + 1;
-    if ((rc = block_fwd(t, st, b3, m, nullptr))) return rc;
+    if ((rc = block_fwd(t, st, b3, m, nullptr, ly2, nullptr, fast ? 2 * S + 1 : -1))) return rc;
     if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
     if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
     // ---------------- loss and its gradient
@@ -411,24 +539,39 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
                        G(t, "w_aux.bias"));
     if ((rc = linear_bwd_weight(t, st, t->d_dout, C, y3, H, G(t, "w_fin.weight"), (int)m, C - 1, H))) return rc;
     if ((rc = linear_bwd_data(t, st, t->d_dout, C, P(t, "w_fin.weight"), gA, H, (int)m, C - 1, H, 0))) return rc;  // dy3
-    if ((rc = block_bwd(t, st, b3, m, gA, xhat))) return rc;                                                     // gA = dz3
-    if ((rc = linear_bwd_data(t, st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0))) return rc;                 // gB = dy2
+    // fast path: the H x H data gradients run on the 3-product kernel as well, dz goes there as lines (one buffer: the
+    // forward's line buffers are free by now)
+    char* dzl = fast ? t->lbufs[0] : nullptr;
+    if ((rc = block_bwd(t, st, b3, m, gA, xhat, dzl))) return rc;                                                // gA = dz3
+    if (fast) rc = fast_linear_bwd_data(t, st, dzl, "w3", gB, m, 2 * S + 1, false);
+    else rc = linear_bwd_data(t, st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0);                          // gB = dy2
+    if (rc) return rc;
     if ((rc = linear_bwd_weight(t, st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H))) return rc;
     if ((rc = linear_bwd_data(t, st, t->d_dout + (C - 1), C, P(t, "w_aux.weight"), gB, H, (int)m, 1, H, 1))) return rc;  // += daux (x) w_aux
     // y2 = w2 a_S + b2
     if ((rc = col_stats(t, st, gB, nullptr, m, H))) return rc;
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red, H, G(t, "w2.bias"));
     if ((rc = linear_bwd_weight(t, st, gB, H, a[S], H, G(t, "w2.weight"), (int)m, H, H))) return rc;
-    if ((rc = linear_bwd_data(t, st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0))) return rc;                 // gA = da_S
+    if (fast) {
+        hipLaunchKernelGGL(mlt::act_lines_kernel, dim3(nblk(m * H / 8)), dim3(256), 0, st, (const float*)gB, m, H, dzl);
+        rc = fast_linear_bwd_data(t, st, dzl, "w2", gA, m, 2 * S, false);
+    } else rc = linear_bwd_data(t, st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0);                         // gA = da_S
+    if (rc) return rc;
     // residual stages, last to first:  a_{s+1} = a_s + B(A(a_s))
     for (int s = S - 1; s >= 0; --s) {
         T_TRY(hipMemcpyAsync(gB, gA, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));                          // gB = d r_s
-        if ((rc = block_bwd(t, st, sb[s], m, gB, xhat))) return rc;                                              // gB = dz_b
-        float* gT = xhat;  // xhat is free again: reuse it for d t_s
-        if ((rc = linear_bwd_data(t, st, gB, H, P(t, sb[s].lin + ".weight"), gT, H, (int)m, H, H, 0))) return rc;
-        T_TRY(hipMemcpyAsync(gB, gT, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));                          // gB = d t_s
-        if ((rc = block_bwd(t, st, sa[s], m, gB, xhat))) return rc;                                              // gB = dz_a
-        if ((rc = linear_bwd_data(t, st, gB, H, P(t, sa[s].lin + ".weight"), gA, H, (int)m, H, H, 1))) return rc;   // da_s += ...
+        if ((rc = block_bwd(t, st, sb[s], m, gB, xhat, dzl))) return rc;                                         // gB = dz_b
+        if (fast) {   // gB's fp32 dz_b has been consumed (dW) and its lines feed the GEMM: d t_s lands in gB directly
+            if ((rc = fast_linear_bwd_data(t, st, dzl, sb[s].lin, gB, m, 2 * s + 1, false))) return rc;
+        } else {
+            float* gT = xhat;  // xhat is free again: reuse it for d t_s
+            if ((rc = linear_bwd_data(t, st, gB, H, P(t, sb[s].lin + ".weight"), gT, H, (int)m, H, H, 0))) return rc;
+            T_TRY(hipMemcpyAsync(gB, gT, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));                      // gB = d t_s
+        }
+        if ((rc = block_bwd(t, st, sa[s], m, gB, xhat, dzl))) return rc;                                         // gB = dz_a
+        if (fast) rc = fast_linear_bwd_data(t, st, dzl, sa[s].lin, gA, m, 2 * s, true);
+        else rc = linear_bwd_data(t, st, gB, H, P(t, sa[s].lin + ".weight"), gA, H, (int)m, H, H, 1);            // da_s += ...
+        if (rc) return rc;
     }
     if ((rc = block_bwd(t, st, b0, m, gA, xhat))) return rc;
     // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(float* __restrict__ d
                                                           float p_drop, uint32_t seed, uint32_t site,
                                                           const double* __restrict__ sdy, const double* __restrict__ sdyx,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                          double* __restrict__ sdz) {
+                                                          double* __restrict__ sdz, char* __restrict__ lines) {
     __shared__ double r1[16][64];
     const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int j0 = blockIdx.x * 64 + cg * 4;
@@ -399,6 +399,19 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(float* __restrict__ d
                 a[e] += (double)o[e];
             }
             *(f32x4*)(dout + i * n + j0) = o;
+            if (lines) {   // dz as k32 hi|lo lines as well: the operand of the fast data-gradient GEMM (n % 32 == 0)
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = __builtin_fminf(__builtin_fmaxf(o[e], -65504.0f), 65504.0f);
+                    hi[e] = (_Float16)c;
+                    lo[e] = (_Float16)(c - (float)hi[e]);
+                }
+                char* dst = lines + i * (int64_t)n * 4 + (j0 >> 5) * 128 + (j0 & 31) * 2;
+                *(h4*)dst = hi;
+                *(h4*)(dst + 64) = lo;
+            }
         }
         if (blockIdx.y == 0 && rg == 0) {  // one thread per column publishes the parameter gradients
 #pragma unroll
@@ -418,6 +431,170 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(float* __restrict__ d
         for (int g = 0; g < 16; ++g) s += r1[g][cj];
         atomicAdd(&sdz[blockIdx.x * 64 + cj], s);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast forward GEMMs of a training step (round 2): z = y . W^T + b on the inference path's 3-product fp16 MFMA kernel
+// (fp32-class accuracy at ~3x the rate of the exact-fp32 MFMA).  Its operands are "k32 hi|lo lines"; the weights change
+// every step, so they are scaled / split / packed on the device:
+//   wmax_kernel:   max|W|;  e = floor(log2(2^14 / max|W|)) as the host packer, descale = 2^-e
+//   wpack_kernel:  lines of W * 2^e (fp16 hi | lo per k32 block), bias * 2^e; <true>: of W^T (data gradient)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_h(float v, _Float16& hi, _Float16& lo) {
+    const float c = __builtin_fminf(__builtin_fmaxf(v, -65504.0f), 65504.0f);
+    hi = (_Float16)c;
+    lo = (_Float16)(c - (float)hi);
+}
+
+// scale2 = {2^e, 2^-e, bits of max|W|, -}: wmax_kernel folds max|W| into scale2[2] (pre-zeroed; non-negative floats order like
+// their bit patterns), the pack kernels derive e from it and thread 0 publishes 2^e / 2^-e for the GEMM's epilogue
+__global__ __launch_bounds__(256) void wmax_kernel(const float* __restrict__ w, int64_t numel, float* __restrict__ scale2) {
+    __shared__ float red[256];
+    float mx = 0.f;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < numel; i += (int64_t)gridDim.x * 1024) {
+        const f32x4 v = *(const f32x4*)(w + i);
+        mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))),
+                             __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (numel & 3)) mx = __builtin_fmaxf(mx, __builtin_fabsf(w[numel - 1 - threadIdx.x]));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = __builtin_fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float r = red[0];
+        if (!(r < 3.0e38f)) r = 3.0e38f;   // inf / NaN weights: the step is lost anyway, keep the exponent finite
+        atomicMax((unsigned*)scale2 + 2, __builtin_bit_cast(unsigned, r));
+    }
+}
+
+__device__ __forceinline__ int wscale_exp(const float* scale2) {
+    const float m = scale2[2];
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) e = (int)floorf(log2f(16384.0f / m));   // max|W| * 2^e in [2^13, 2^15): far inside fp16
+    return e > 40 ? 40 : (e < -40 ? -40 : e);
+}
+
+// one thread per (row, group of 8 k) of W (n x k, k % 8 == 0), kpad = k rounded up to 64 (zero filled).
+// TRANS: the image of W^T (k rows of n values) for the data-gradient GEMM; its scale is the forward image's (same
+// weights, same step) and there is no bias.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void wpack_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int kpad,
+                                                    float* __restrict__ scale2, char* __restrict__ lines,
+                                                    float* __restrict__ bias_scaled) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int e2 = wscale_exp(scale2);
+    const float sc = ldexpf(1.0f, e2);
+    if (id == 0 && !TRANS) {
+        scale2[0] = sc;
+        scale2[1] = ldexpf(1.0f, -e2);
+    }
+    h8 hi, lo;
+    int row, g, width;
+    if (TRANS) {   // consecutive threads = consecutive rows of W^T (columns of W): coalesced reads
+        if (id >= (int64_t)k * (n / 8)) return;
+        g = (int)(id / k);
+        row = (int)(id - (int64_t)g * k);
+        width = n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 a, b;
+            split_h(w[(int64_t)(g * 8 + e) * k + row] * sc, a, b);
+            hi[e] = a;
+            lo[e] = b;
+        }
+    } else {
+        const int gpr = kpad / 8;
+        if (id >= (int64_t)n * gpr) return;
+        row = (int)(id / gpr);
+        g = (int)(id - (int64_t)row * gpr);
+        width = kpad;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = g * 8 + e;
+            _Float16 a, b;
+            split_h(kk < k ? w[(int64_t)row * k + kk] * sc : 0.f, a, b);
+            hi[e] = a;
+            lo[e] = b;
+        }
+        if (g == 0) bias_scaled[row] = bias[row] * sc;
+    }
+    char* dst = lines + (int64_t)row * width * 4 + (g >> 2) * 128 + (g & 3) * 16;
+    *(h8*)dst = hi;
+    *(h8*)(dst + 64) = lo;
+}
+
+// fp32 (m, n) -> lines (rows >= m of the padded buffer are left alone: a row of the GEMM only depends on its own input row)
+__global__ __launch_bounds__(256) void act_lines_kernel(const float* __restrict__ y, int64_t m, int n, char* __restrict__ lines) {
+    const int gpr = n / 8;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= m * gpr) return;
+    const int64_t row = id / gpr;
+    const int g = (int)(id - row * gpr);
+    const f32x4 a = *(const f32x4*)(y + row * n + g * 8), b = *(const f32x4*)(y + row * n + g * 8 + 4);
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        _Float16 p, q;
+        split_h(e < 4 ? a[e] : b[e - 4], p, q);
+        hi[e] = p;
+        lo[e] = q;
+    }
+    char* dst = lines + row * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16;
+    *(h8*)dst = hi;
+    *(h8*)(dst + 64) = lo;
+}
+
+// bn_relu_drop_kernel that ALSO writes its output as lines (the next layer's GEMM operand); identical per-element
+// arithmetic.  4 columns per lane (every fp32 access is a fully coalesced 16-byte one); an even / odd lane pair covers one
+// 8-column group of a line: the even lane stores the group's 8 hi halves, the odd lane its 8 lo halves.  n % 8 == 0.
+__global__ __launch_bounds__(256) void bn_relu_drop_lines_kernel(const float* __restrict__ z, int64_t m, int n,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float p_drop, uint32_t seed, uint32_t site,
+                                                                const float* __restrict__ residual, float* __restrict__ y,
+                                                                char* __restrict__ lines) {
+    const int qpr = n / 4;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = id < m * qpr;   // (m * n / 4 is even: a lane pair is live or dead together)
+    const int64_t i = live ? id / qpr : 0;
+    const int q = live ? (int)(id - i * qpr) : 0;
+    const int j0 = q * 4;
+    const int64_t base = i * n + j0;
+    f32x4 v = *(const f32x4*)(z + base);
+    const f32x4 mu = *(const f32x4*)(mean + j0), is = *(const f32x4*)(invstd + j0);
+    const f32x4 ga = *(const f32x4*)(gamma + j0), be = *(const f32x4*)(beta + j0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = ga[e] * ((v[e] - mu[e]) * is[e]) + be[e];
+        t = t > 0.f ? t : 0.f;
+        if (p_drop > 0.f) t = (mlk::u01(seed, (uint32_t)i * 4099u + site, (uint32_t)(j0 + e)) >= p_drop) ? t / (1.f - p_drop) : 0.f;
+        v[e] = t;
+    }
+    if (residual) {
+        const f32x4 r = *(const f32x4*)(residual + base);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+    }
+    if (live) *(f32x4*)(y + base) = v;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    unsigned hi2[2], lo2[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        _Float16 a0, b0, a1, b1;
+        split_h(v[2 * e], a0, b0);
+        split_h(v[2 * e + 1], a1, b1);
+        hi2[e] = __builtin_bit_cast(unsigned, h2{a0, a1});
+        lo2[e] = __builtin_bit_cast(unsigned, h2{b0, b1});
+    }
+    const bool odd = q & 1;
+    const unsigned s0 = __shfl_xor(odd ? hi2[0] : lo2[0], 1, 64), s1 = __shfl_xor(odd ? hi2[1] : lo2[1], 1, 64);
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 out = odd ? u4{s0, s1, lo2[0], lo2[1]} : u4{hi2[0], hi2[1], s0, s1};
+    const int g = q >> 1;   // 8-column group
+    if (live) *(u4*)(lines + i * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16 + (odd ? 64 : 0)) = out;
 }
 
 __global__ __launch_bounds__(256) void col_sum_to_float_kernel(const double* __restrict__ s, int n, float* __restrict__ out) {

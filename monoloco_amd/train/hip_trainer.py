@@ -11,6 +11,12 @@ from ..engine import _dev_f32, _ptr, _require_cuda, _stream
 TASKS = ('d', 'x', 'y', 'h', 'w', 'l', 'ori', 'aux')
 
 
+def set_fast_forward_rows(rows):
+    """Batches of at least `rows` rows run the hidden x hidden forward GEMMs on the 3-product fp16 MFMA kernel (default
+    4096, 0 = never; process-global test hook)."""
+    check(_lib.load().ml_debug_set_train_fast_rows(int(rows)), train=True)
+
+
 class HipTrainer:
     """Parameters, Adam state and the training step live in the library; tensors cross by state_dict key."""
 

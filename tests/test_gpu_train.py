@@ -145,3 +145,68 @@ def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path
         dic = net.forward(gp['stereo_kps_l'][:8].tolist(), synth.KITTI_K, keypoints_r=gp['stereo_kps_r'][:5].tolist())
         assert dic['aux'].shape == (8, 1)
     assert dic['d'].shape == (8, 1) and torch.isfinite(dic['d']).all()
+
+
+def _big_batch(mode, m, seed):
+    """The fixture batch tiled to m rows with a little keypoint jitter (labels repeated)."""
+    x, y = _batch(mode)
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, x.shape[0], size=m)
+    xb = x.numpy()[idx] + rng.normal(0, 0.01, size=(m, x.shape[1])).astype(np.float32)
+    return torch.tensor(xb), torch.tensor(y.numpy()[idx])
+
+
+@pytest.mark.parametrize("mode,hidden,m,p_drop", [('mono', 256, 4096, 0.0), ('stereo', 512, 5000, 0.0), ('mono', 1024, 4096, 0.2)])
+def test_fast_forward_gemms_match_exact_path(hip_lib, cuda_device, mode, hidden, m, p_drop):
+    """From 4096 rows the hidden x hidden forward GEMMs of a training step run on the inference path's 3-product fp16 MFMA
+    kernel (fp32 output): same losses, outputs and gradients as the exact-fp32 MFMA GEMM path to fp32 rounding class,
+    including a batch that is no multiple of the 256-row tile and dropout (same device RNG on both paths)."""
+    from monoloco_amd.train import HipTrainer
+    from monoloco_amd.train.hip_trainer import set_fast_forward_rows
+    in_f, out_f = (34, 9) if mode == 'mono' else (68, 10)
+    x, y = _big_batch(mode, m, 5)
+    sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(31, in_f, out_f, hidden).items()}
+    got = {}
+    try:
+        for name, rows in (('exact', 0), ('fast', 4096)):
+            set_fast_forward_rows(rows)
+            tr = HipTrainer(sd0, p_dropout=p_drop, lr=0.001, device=cuda_device, seed=3)
+            res, out = tr.step(x, y, update=False, want_outputs=True)
+            got[name] = (res, out.cpu().numpy(), {k: v.numpy() for k, v in tr.grads().items()})
+            res2 = tr.step(x, y)          # and a real update step runs
+            assert np.isfinite(res2['loss'])
+            tr.close()
+    finally:
+        set_fast_forward_rows(4096)
+    (r0, o0, g0), (r1, o1, g1) = got['exact'], got['fast']
+    assert not np.array_equal(o0, o1), "the fast path did not run"
+    assert np.abs(o0 - o1).max() <= 2e-5 * max(1.0, np.abs(o0).max()), np.abs(o0 - o1).max()
+    for k in r0:
+        assert abs(r0[k] - r1[k]) <= 1e-4 * max(1.0, abs(r0[k])), (k, r0[k], r1[k])
+    gmax = max(np.abs(v).max() for v in g0.values())
+    for k in g0:   # (a Linear bias that feeds a BatchNorm has a mathematically zero gradient: pure rounding noise)
+        scale = max(np.abs(g0[k]).max(), 1e-4 * gmax)
+        # (ReLU masks of pre-activations within rounding of 0 flip between the two paths: 1e-3 class, as between any two
+        # fp32 implementations; the fp64 comparison below is the accuracy bar)
+        assert np.abs(g0[k] - g1[k]).max() / scale <= 3e-3, (k, np.abs(g0[k] - g1[k]).max() / scale)
+
+
+def test_fast_forward_gemms_against_fp64_oracle(hip_lib, cuda_device):
+    """... and measured against the fp64 oracle the fast path is as close as fp32 torch is."""
+    from monoloco_amd.train import HipTrainer
+    from oracle.train_oracle import OracleTrainer
+    x, y = _big_batch('mono', 4096, 6)
+    sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(32, 34, 9, 256).items()}
+    tr = HipTrainer(sd0, p_dropout=0.0, lr=0.001, device=cuda_device)
+    tr.step(x, y, update=False)
+    o32 = OracleTrainer(sd0, lr=0.001)
+    o64 = OracleTrainer(sd0, lr=0.001, dtype=torch.float64)
+    o32.step(x, y, update=False)
+    o64.step(x.double(), y.double(), update=False)
+    g, g32, g64 = tr.grads(), o32.grads(), o64.grads()
+    for k in g:
+        scale = g64[k].abs().max().item() + 1e-12
+        e_hip = (g[k].double() - g64[k]).abs().max().item() / scale
+        e_t32 = (g32[k].double() - g64[k]).abs().max().item() / scale
+        assert e_hip <= max(8 * e_t32, 2e-5), (k, e_hip, e_t32)
+    tr.close()

@@ -34,7 +34,7 @@ for name, x, y in (('fixture-331', fx, fy), ('synthetic-65536', bx, by)):
     while tc < args.cpu_seconds and reps < 20:
         t0 = time.perf_counter(); o.step(x, y); tc += time.perf_counter() - t0; reps += 1
     flop = 3 * 16865280 * len(x)   # fwd + 2x bwd, algorithmic
-    print(json.dumps({"workload": "training step " + name + ", LocoModel 34->1024->9, dropout 0.2, fp32 (exact-fp32 MFMA)",
+    print(json.dumps({"workload": "training step " + name + ", LocoModel 34->1024->9, dropout 0.2, fp32 (rows >= 4096: forward and data-gradient GEMMs of the hidden layers on 3-product fp16 MFMA, the rest exact-fp32 MFMA)",
                       "rows": len(x), "ms_per_step": round(dt * 1e3, 3), "rows_per_s": round(len(x) / dt, 1),
                       "algorithmic_tflops": round(flop / dt / 1e12, 2),
                       "cpu_baseline": {"ms_per_step": round(tc / reps * 1e3, 1), "rows_per_s": round(len(x) * reps / tc, 1),

@@ -2,7 +2,7 @@
 dense kernel spills (spill stores are VMEM ops and would break the kernel's counted vmcnt waits)."""
 import re, subprocess, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, 'monoloco_amd', 'csrc', 'monoloco_hip.hip')
+src = os.path.join(root, 'monoloco_amd', 'csrc', sys.argv[1] if len(sys.argv) > 1 else 'monoloco_hip.hip')
 out = subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-c', src, '-o', '/dev/null',
                       '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True).stderr
 cur, rows = None, {}

@@ -1,0 +1,5 @@
+O=gpurun_out/r02_train2; mkdir -p $O
+( timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_w4.py -q -p no:cacheprovider 2>&1 ) > $O/pytest.log 2>&1
+tail -5 $O/pytest.log
+timeout 300 python tools/bench_train.py --steps 6 --cpu-seconds 0.1 2>&1 | cut -c1-400 | tee $O/bench_train.log
+bash tools/gpu_prof_train.sh
