@@ -153,12 +153,16 @@ struct W4Frag {          // the fragments of one k32 step of one half (hi or lo)
 // HEAD == -2: the tile is stored as plain fp32 rows (y = [M_pad][N] floats: the pre-BatchNorm z of the TRAINING forward,
 // csrc/train.hip) -- 32 floats of a row are 128 bytes, so addressing and transposition are those of the line format;
 // with RES, res = an fp32 [M_pad][N] matrix that is ADDED (may alias y: the data-gradient GEMM accumulating into da).
+// HEAD == -3: as -2, and the reduction is split: p.ksplit work items per output tile, each over p.K of the operands'
+// p.K * p.ksplit columns, partial s of the output at y + s * M_pad * N floats (the weight-gradient GEMM: 16 output tiles,
+// K = the batch; a fixed-order reduction kernel adds the partials).
 template <int NSPLIT, bool RELU, bool RES, int HEAD>
 __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_kernel_w4(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[W4_LDS];
     constexpr bool SPLIT = NSPLIT == 3;
     constexpr bool AUX = HEAD == -1;
-    constexpr bool F32OUT = HEAD == -2;
+    constexpr bool F32OUT = HEAD <= -2;
+    constexpr bool SPLITK = HEAD == -3;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -167,9 +171,10 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int wm = w >> 1;   // 2 waves along m (128 persons each)
 
     const int NT = p.N / BN;
-    const int ntiles = (p.M_pad / BM) * NT;
+    const int otiles = (p.M_pad / BM) * NT;                   // output tiles
+    const int ntiles = SPLITK ? otiles * p.ksplit : otiles;  // work items
     const int q8 = ntiles >> 3, r8 = ntiles & 7;
-    const size_t rowb = (size_t)p.K * 4;
+    const size_t rowb = SPLITK ? (size_t)p.K * p.ksplit * 4 : (size_t)p.K * 4;
     const size_t yrowb = (size_t)p.N * 4;
     const int nk = p.K / 32;   // even (K % 64 == 0, guaranteed by the host)
     const float descale = p.descale_ptr ? *p.descale_ptr : p.descale;   // (before the first LDS-DMA: an ordinary load)
@@ -226,9 +231,14 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     };
 
     // virtual block id -> tile: the XCD-aware bijective map of dense_kernel.h
-    auto tile_of = [&](int vb, int& m0, int& n0) {
+    auto tile_of = [&](int vb, int& m0, int& n0, int& ks) {
         const int xcd = vb & 7, idx = vb >> 3;
-        const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        ks = 0;
+        if (SPLITK) {
+            ks = tile / otiles;
+            tile -= ks * otiles;
+        }
         const int mt = tile / NT, nt = tile - mt * NT;
         m0 = mt * BM;
         n0 = nt * BN;
@@ -236,8 +246,8 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 
     int vb = blockIdx.x;
     if (vb >= ntiles) return;
-    int m0, n0;
-    tile_of(vb, m0, n0);
+    int m0, n0, ks0;
+    tile_of(vb, m0, n0, ks0);
 
     char* const scr = smem + W4_RING + w * 8192;   // two 4 KiB epilogue buffers of this wave
 
@@ -246,17 +256,17 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // request is conditional and every phase has the same vmcnt arithmetic.
     int rq_vb = vb, rq_left = nk;
     const size_t wave_rows = (size_t)(w * 64) * rowb;
-    const char* rq_w = p.w + (size_t)n0 * rowb + wave_rows;
-    const char* rq_x = p.x + (size_t)m0 * rowb + wave_rows;
+    const char* rq_w = p.w + (size_t)n0 * rowb + wave_rows + (size_t)ks0 * p.K * 4;   // (k offset in bytes: 128 per k32 block)
+    const char* rq_x = p.x + (size_t)m0 * rowb + wave_rows + (size_t)ks0 * p.K * 4;
     auto rq_advance = [&]() {   // after both slots of a k32 step have been requested
         rq_w += LINE;
         rq_x += LINE;
         if (--rq_left == 0) {
             if (rq_vb + (int)gridDim.x < ntiles) rq_vb += (int)gridDim.x;
-            int rm0, rn0;
-            tile_of(rq_vb, rm0, rn0);
-            rq_w = p.w + (size_t)rn0 * rowb + wave_rows;
-            rq_x = p.x + (size_t)rm0 * rowb + wave_rows;
+            int rm0, rn0, rks;
+            tile_of(rq_vb, rm0, rn0, rks);
+            rq_w = p.w + (size_t)rn0 * rowb + wave_rows + (size_t)rks * p.K * 4;
+            rq_x = p.x + (size_t)rm0 * rowb + wave_rows + (size_t)rks * p.K * 4;
             rq_left = nk;
         }
     };
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         const int rd_off = (elane >> 3) * LINE + (((elane & 7) ^ ((elane >> 3) & 7)) * 16);  // + qq * 1024
         // addresses of a pass = one wave-uniform 64-bit tile base + a 32-bit offset (kept as a running, opaque value so
         // that hipcc does not pre-compute 16 + 16 address pairs into SGPRs and spill them)
-        const size_t tile_off = (size_t)mbase * yrowb + (size_t)nbase * 4;
+        const size_t tile_off = (size_t)mbase * yrowb + (size_t)nbase * 4 + (SPLITK ? (size_t)ks0 * p.M_pad * yrowb : 0);
         const unsigned row8 = (unsigned)(8 * (int)yrowb);
         auto pass_off = [&](int pass) {   // pass = it * 4 + jt
             unsigned o = (unsigned)((pass & 3) * 32) * (unsigned)yrowb + (unsigned)((pass >> 2) * 128);
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #endif
         if (!more) break;
         vb = vb_next;
-        tile_of(vb, m0, n0);
+        tile_of(vb, m0, n0, ks0);
         // the next tile's first hi fragments again (the copy read in the last phase is not kept live across the
         // epilogue: 64 registers the epilogue needs; slot 0 is untouched until the next request behind the barrier)
 #pragma unroll

@@ -74,7 +74,10 @@ struct ml_trainer {
     std::vector<char*> lbufs;                         // 2S + 2 buffers of cap x H lines
     std::vector<char*> wl;                            // 2S + 2 packed weight images (H x H lines)
     std::vector<float*> wbs;                          // bias * 2^e
-    float* wsc_base = nullptr;                        // per image {2^e, 2^-e, bits of max|W|, -}
+    float* wsc_base = nullptr;                        // per image 8 scale words (train_kernels.h, wmax_kernel)
+    char *tl_dz = nullptr, *tl_x = nullptr;           // transposed lines [H][capT] of dz and of a layer input (dW = dz^T . x)
+    int64_t capT = 0;
+    int ks = 1;                                       // split of the batch reduction of the fast weight-gradient GEMM
     float* zero_bias = nullptr;                       // H zeros (the data-gradient GEMMs have no bias)
     int n_cu = 256;
 };
@@ -177,6 +180,46 @@ int col_stats(ml_trainer* t, hipStream_t st, const float* z, const float* w2, in
     return 0;
 }
 
+// ---- skinny products (input layer, output heads) on their own kernels (train_kernels.h); callers check skinny_ok
+bool skinny_ok(const ml_trainer* t, int nc) { return t->H % 256 == 0 && nc >= 1 && nc <= mlt::SK_NC; }
+
+int skinny_out(ml_trainer* t, hipStream_t st, const float* s, int lds, int nc, const float* w, int64_t wsc, int64_t wsj,
+               const float* bias, float* out, int64_t m, int accumulate) {
+    int64_t gy = (m + 63) / 64;
+    if (gy > 128) gy = 128;
+    hipLaunchKernelGGL(mlt::skinny_out_kernel, dim3(t->H / 64, (unsigned)gy), dim3(256), 0, st, s, lds, nc, w, wsc, wsj, bias, out, m,
+                       t->H, accumulate);
+    return 0;
+}
+
+// dst (nc x H, or H x nc when transpose) = s^T (nc x m) . x (m x H)
+int skinny_dw(ml_trainer* t, hipStream_t st, const float* s, int lds, int nc, const float* x, int64_t m, float* dst, int transpose) {
+    int64_t gy = (m + 15) / 16;
+    if (gy > 64) gy = 64;
+    while (gy > 1 && (size_t)gy * nc * t->H > t->splitk_cap) gy /= 2;
+    const dim3 block(256);
+    if (nc == 1) hipLaunchKernelGGL(mlt::skinny_dw_kernel<1>, dim3(t->H / 64, (unsigned)gy, 1), block, 0, st, s, lds, nc, x, m, t->H, t->d_splitk);
+    else if (nc <= 12) hipLaunchKernelGGL(mlt::skinny_dw_kernel<12>, dim3(t->H / 64, (unsigned)gy, 1), block, 0, st, s, lds, nc, x, m, t->H, t->d_splitk);
+    else hipLaunchKernelGGL(mlt::skinny_dw_kernel<36>, dim3(t->H / 64, (unsigned)gy, (nc + 35) / 36), block, 0, st, s, lds, nc, x, m, t->H, t->d_splitk);
+    hipLaunchKernelGGL(mlt::skinny_reduce_kernel, dim3(nblk((int64_t)nc * t->H)), block, 0, st, (const float*)t->d_splitk, (int)gy, nc,
+                       t->H, dst, transpose);
+    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "skinny weight-gradient launch failed");
+    return 0;
+}
+
+// out[i][c] = x[i] . w[c] + b[c], c < nc in {1, 8, 9}; false: no kernel for this shape (the caller takes the GEMM)
+bool skinny_heads(ml_trainer* t, hipStream_t st, const float* x, int64_t m, const float* w, const float* b, int nc, float* out, int ldo) {
+    if (t->H % 256 != 0 || (int64_t)nc * t->H > 15360) return false;
+    int64_t g = (m + 3) / 4;
+    if (g > 2048) g = 2048;
+    const dim3 grid((unsigned)g), block(256);
+    if (nc == 1) hipLaunchKernelGGL(mlt::skinny_heads_kernel<1>, grid, block, 0, st, x, m, t->H, w, b, out, ldo);
+    else if (nc == 8) hipLaunchKernelGGL(mlt::skinny_heads_kernel<8>, grid, block, 0, st, x, m, t->H, w, b, out, ldo);
+    else if (nc == 9) hipLaunchKernelGGL(mlt::skinny_heads_kernel<9>, grid, block, 0, st, x, m, t->H, w, b, out, ldo);
+    else return false;
+    return true;
+}
+
 struct Block {  // Linear + BatchNorm + ReLU + Dropout
     std::string lin, bn;
     int bn_idx;
@@ -222,8 +265,8 @@ int launch_fast_gemm(ml_trainer* t, hipStream_t st, const char* x_lines, const c
 // relative per operand) at ~3x the rate of the exact-fp32 MFMA GEMM.  `slot` = which packed-weight image to use.
 int fast_linear_fwd(ml_trainer* t, hipStream_t st, const char* x_lines, const std::string& lin, float* z, int64_t m, int slot) {
     const int H = t->H;
-    float* sc = t->wsc_base + 4 * slot;   // (zeroed at the start of the step)
-    hipLaunchKernelGGL(mlt::wmax_kernel, dim3(64), dim3(256), 0, st, (const float*)P(t, lin + ".weight"), (int64_t)H * H, sc);
+    float* sc = t->wsc_base + 8 * slot;   // (zeroed at the start of the step)
+    hipLaunchKernelGGL(mlt::wmax_kernel, dim3(64), dim3(256), 0, st, (const float*)P(t, lin + ".weight"), (int64_t)H * H, sc + 2);
     hipLaunchKernelGGL(mlt::wpack_kernel<false>, dim3(nblk((int64_t)H * H / 8)), dim3(256), 0, st, (const float*)P(t, lin + ".weight"),
                        (const float*)P(t, lin + ".bias"), H, H, H, sc, t->wl[slot], t->wbs[slot]);
     return launch_fast_gemm(t, st, x_lines, t->wl[slot], t->wbs[slot], sc + 1, z, m, false);
@@ -234,10 +277,52 @@ int fast_linear_fwd(ml_trainer* t, hipStream_t st, const char* x_lines, const st
 int fast_linear_bwd_data(ml_trainer* t, hipStream_t st, const char* dz_lines, const std::string& lin, float* dx, int64_t m, int slot,
                          bool accumulate) {
     const int H = t->H;
-    float* sc = t->wsc_base + 4 * slot;
+    float* sc = t->wsc_base + 8 * slot;
     hipLaunchKernelGGL(mlt::wpack_kernel<true>, dim3(nblk((int64_t)H * H / 8)), dim3(256), 0, st, (const float*)P(t, lin + ".weight"),
                        (const float*)nullptr, H, H, H, sc, t->wl[slot], (float*)nullptr);
-    return launch_fast_gemm(t, st, dz_lines, t->wl[slot], t->zero_bias, sc + 1, dx, m, accumulate);
+    return launch_fast_gemm(t, st, dz_lines, t->wl[slot], t->zero_bias, sc + 4, dx, m, accumulate);
+}
+
+// dz (m x H fp32; its max |.| already in the Linear's scale word 3) -> scaled lines (lbufs[0], for dx) and scaled
+// transposed lines (tl_dz, for dW); publishes both descales
+void fast_grad_lines(ml_trainer* t, hipStream_t st, const float* dz, int64_t m, int slot) {
+    const int64_t mT = (m + 64 * t->ks - 1) / (64 * t->ks) * (64 * t->ks);
+    hipLaunchKernelGGL(mlt::tlines_kernel<true>, dim3(t->H / 64, (unsigned)(mT / 64)), dim3(256), 0, st, dz, m, t->H, mT,
+                       t->wsc_base + 8 * slot, t->tl_dz, t->lbufs[0]);
+}
+
+// dW (H x H) = dz^T . x on the 3-product kernel: both operands as transposed lines (the reduction runs over the batch),
+// the batch split over t->ks work items per output tile, partials added in a fixed order.
+int fast_linear_bwd_weight(ml_trainer* t, hipStream_t st, const float* x, const std::string& lin, int64_t m, int slot) {
+    const int H = t->H;
+    const int64_t mT = (m + 64 * t->ks - 1) / (64 * t->ks) * (64 * t->ks);
+    hipLaunchKernelGGL(mlt::tlines_kernel<false>, dim3(H / 64, (unsigned)(mT / 64)), dim3(256), 0, st, x, m, H, mT, (float*)nullptr,
+                       t->tl_x, (char*)nullptr);
+    mlk::DenseParams p;
+    p.x = t->tl_dz;
+    p.w = t->tl_x;
+    p.bias = nullptr;
+    p.bias_scaled = t->zero_bias;
+    p.res = nullptr;
+    p.y = (char*)t->d_splitk;
+    p.descale = 1.0f;
+    p.descale_ptr = t->wsc_base + 8 * slot + 5;
+    p.M_pad = H;
+    p.N = H;
+    p.K = (int)(mT / t->ks);
+    p.ksplit = t->ks;
+    p.relu = 0;
+    p.debug = 0;
+    p.trace = nullptr;
+    p.head_w = nullptr;
+    p.head_part = nullptr;
+    const int items = (H / mlk::BM) * (H / mlk::BN) * t->ks;
+    hipLaunchKernelGGL((mlk::dense_kernel_w4<3, false, false, -3>), dim3(items < t->n_cu ? items : t->n_cu), dim3(mlk::W4_THREADS), 0,
+                       st, p);
+    hipLaunchKernelGGL(mlt::splitk_reduce_kernel, dim3(nblk((int64_t)H * H)), dim3(256), 0, st, (const float*)t->d_splitk, t->ks, H, H,
+                       H, (const float*)nullptr, 0, G(t, lin + ".weight"));
+    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "fast weight-gradient GEMM launch failed");
+    return 0;
 }
 
 bool fast_rows(const ml_trainer* t, int64_t m) {
@@ -251,6 +336,8 @@ int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* r
     const int H = t->H;
     int rc;
     if (x_lines && slot >= 0) rc = fast_linear_fwd(t, st, x_lines, b.lin, b.z, m, slot);
+    else if (y_lines && b.in_dim != H && skinny_ok(t, b.in_dim))   // the input layer of a fast-path step
+        rc = skinny_out(t, st, b.x, b.in_dim, b.in_dim, P(t, b.lin + ".weight"), 1, b.in_dim, P(t, b.lin + ".bias"), b.z, m, 0);
     else rc = linear_fwd(t, st, b.x, b.in_dim, P(t, b.lin + ".weight"), P(t, b.lin + ".bias"), b.z, H, (int)m, H, b.in_dim);
     if (rc) return rc;
     if ((rc = col_stats(t, st, b.z, nullptr, m, H))) return rc;
@@ -283,7 +370,9 @@ int next_red_slot(ml_trainer* t, hipStream_t st) {
     return 0;
 }
 
-int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, float* xhat, char* dz_lines = nullptr) {
+// slot >= 0: the Linear is an H x H one on the fast path: dz also goes to lbufs[0] / tl_dz as scaled lines, dW runs there;
+// slot == -2: the (narrow) input layer of a fast-path step
+int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, float* xhat, int slot = -1) {
     const int H = t->H;
     float* mean = t->bn_mean + (size_t)b.bn_idx * H;
     float* inv = t->bn_invstd + (size_t)b.bn_idx * H;
@@ -305,9 +394,16 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
         hipLaunchKernelGGL(mlt::bn_bwd_fused_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, dout, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
                            (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, (const double*)s_dy,
-                           (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz, dz_lines);
+                           (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz,
+                           slot >= 0 ? t->wsc_base + 8 * slot + 3 : (float*)nullptr);
         hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)s_dz, H,
                            G(t, b.lin + ".bias"));
+        if (slot >= 0) {
+            fast_grad_lines(t, st, dout, m, slot);
+            return fast_linear_bwd_weight(t, st, b.x, b.lin, m, slot);
+        }
+        if (slot == -2 && skinny_ok(t, b.in_dim))   // the input layer of a fast-path step: dW1 (H x in) = dz^T . x
+            return skinny_dw(t, st, b.x, b.in_dim, b.in_dim, dout, m, G(t, b.lin + ".weight"), 1);
         return linear_bwd_weight(t, st, dout, H, b.x, b.in_dim, G(t, b.lin + ".weight"), (int)m, H, b.in_dim);
     }
     hipLaunchKernelGGL(mlt::relu_drop_bwd_kernel, dim3(nblk(m * H)), dim3(256), 0, st, dout, (const float*)b.z, m, H,
@@ -339,12 +435,23 @@ int ensure_cap(ml_trainer* t, int64_t m) {
             T_TRY(hipMalloc((void**)&p, (size_t)m * t->H * 4));
             t->lbufs.push_back(p);
         }
+        // weight gradient: (H / 256)^2 output tiles, the batch reduction split so that the work items about fill the chip
+        // (at most 32: the partial buffer); the transposed operands are zero-padded to whole 64-row k-steps per split
+        const int otiles = (t->H / 256) * (t->H / 256);
+        t->ks = 1;
+        while (t->ks < 32 && otiles * t->ks * 2 <= 256) t->ks *= 2;
+        t->capT = (m + 64 * t->ks - 1) / (64 * t->ks) * (64 * t->ks);
+        if (t->tl_dz) (void)hipFree(t->tl_dz);
+        if (t->tl_x) (void)hipFree(t->tl_x);
+        t->tl_dz = t->tl_x = nullptr;
+        T_TRY(hipMalloc((void**)&t->tl_dz, (size_t)t->capT * t->H * 4));
+        T_TRY(hipMalloc((void**)&t->tl_x, (size_t)t->capT * t->H * 4));
         if (t->wl.empty()) {
             hipDeviceProp_t prop;
             int dev = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                 t->n_cu = prop.multiProcessorCount;
-            T_TRY(hipMalloc((void**)&t->wsc_base, (size_t)(2 * t->S + 2) * 16));
+            T_TRY(hipMalloc((void**)&t->wsc_base, (size_t)(2 * t->S + 2) * 32));
             T_TRY(hipMalloc((void**)&t->zero_bias, (size_t)t->H * 4));
             T_TRY(hipMemset(t->zero_bias, 0, (size_t)t->H * 4));
             for (int i = 0; i < 2 * t->S + 2; ++i) {
@@ -427,7 +534,7 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (char* p : t->lbufs) (void)hipFree(p);
     for (char* p : t->wl) (void)hipFree(p);
     for (float* p : t->wbs) (void)hipFree(p);
-    void* ptrs[] = {t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    void* ptrs[] = {t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -498,7 +605,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     // fast forward path: the activations that feed an H x H Linear also exist as lines (la[s] = a_s, lt[s] = t_s, ly2 = y2);
     // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
     const bool fast = fast_rows(t, m);
-    if (fast) T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 2) * 16, st));
+    if (fast) T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 2) * 32, st));
     auto la = [&](int s) { return fast ? t->lbufs[s] : (char*)nullptr; };
     auto lt = [&](int s) { return fast ? t->lbufs[S + 1 + s] : (char*)nullptr; };
     char* ly2 = fast ? t->lbufs[2 * S + 1] : nullptr;
@@ -517,11 +624,13 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         if ((rc = fast_linear_fwd(t, st, la(S), "w2", y2, m, 2 * S))) return rc;
         hipLaunchKernelGGL(mlt::act_lines_kernel, dim3(nblk(m * H / 8)), dim3(256), 0, st, (const float*)y2, m, H, ly2);
     } else if ((rc = linear_fwd(t, st, a[S], H, P(t, "w2.weight"), P(t, "w2.bias"), y2, H, (int)m, H, H))) return rc;
-    if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
+    if (!(fast && skinny_heads(t, st, y2, m, P(t, "w_aux.weight"), P(t, "w_aux.bias"), 1, t->d_out + (C - 1), C)))
+        if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
     Block b3;
     b3.lin = "w3"; b3.bn = "batch_norm3"; b3.bn_idx = 2 * S + 1; b3.in_dim = H; b3.x = y2; b3.z = z3; b3.y = y3; b3.site = 2 * S + 1;
     if ((rc = block_fwd(t, st, b3, m, nullptr, ly2, nullptr, fast ? 2 * S + 1 : -1))) return rc;
-    if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
+    if (!(fast && skinny_heads(t, st, y3, m, P(t, "w_fin.weight"), P(t, "w_fin.bias"), C - 1, t->d_out, C)))
+        if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
     if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
     // ---------------- loss and its gradient
     double* d_loss = t->d_red + 2 * H;  // the tail of the current (pre-zeroed) slot
@@ -537,30 +646,46 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)t->d_red, C - 1, G(t, "w_fin.bias"));
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)(t->d_red + (C - 1)), 1,
                        G(t, "w_aux.bias"));
-    if ((rc = linear_bwd_weight(t, st, t->d_dout, C, y3, H, G(t, "w_fin.weight"), (int)m, C - 1, H))) return rc;
-    if ((rc = linear_bwd_data(t, st, t->d_dout, C, P(t, "w_fin.weight"), gA, H, (int)m, C - 1, H, 0))) return rc;  // dy3
-    // fast path: the H x H data gradients run on the 3-product kernel as well, dz goes there as lines (one buffer: the
-    // forward's line buffers are free by now)
+    if (fast) {
+        if ((rc = skinny_dw(t, st, t->d_dout, C, C - 1, y3, m, G(t, "w_fin.weight"), 0))) return rc;
+        rc = skinny_out(t, st, t->d_dout, C, C - 1, P(t, "w_fin.weight"), H, 1, nullptr, gA, m, 0);
+    } else {
+        if ((rc = linear_bwd_weight(t, st, t->d_dout, C, y3, H, G(t, "w_fin.weight"), (int)m, C - 1, H))) return rc;
+        rc = linear_bwd_data(t, st, t->d_dout, C, P(t, "w_fin.weight"), gA, H, (int)m, C - 1, H, 0);  // dy3
+    }
+    if (rc) return rc;
+    // fast path: the H x H data and weight gradients run on the 3-product kernel as well; dz goes there as scaled lines
+    // (lbufs[0]: the forward's line buffers are free by now) and transposed lines (tl_dz), see block_bwd
     char* dzl = fast ? t->lbufs[0] : nullptr;
-    if ((rc = block_bwd(t, st, b3, m, gA, xhat, dzl))) return rc;                                                // gA = dz3
+    if ((rc = block_bwd(t, st, b3, m, gA, xhat, fast ? 2 * S + 1 : -1))) return rc;                              // gA = dz3
     if (fast) rc = fast_linear_bwd_data(t, st, dzl, "w3", gB, m, 2 * S + 1, false);
     else rc = linear_bwd_data(t, st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0);                          // gB = dy2
     if (rc) return rc;
-    if ((rc = linear_bwd_weight(t, st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H))) return rc;
-    if ((rc = linear_bwd_data(t, st, t->d_dout + (C - 1), C, P(t, "w_aux.weight"), gB, H, (int)m, 1, H, 1))) return rc;  // += daux (x) w_aux
+    if (fast) {
+        if ((rc = skinny_dw(t, st, t->d_dout + (C - 1), C, 1, y2, m, G(t, "w_aux.weight"), 0))) return rc;
+        rc = skinny_out(t, st, t->d_dout + (C - 1), C, 1, P(t, "w_aux.weight"), H, 1, nullptr, gB, m, 1);
+    } else {
+        if ((rc = linear_bwd_weight(t, st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H))) return rc;
+        rc = linear_bwd_data(t, st, t->d_dout + (C - 1), C, P(t, "w_aux.weight"), gB, H, (int)m, 1, H, 1);  // += daux (x) w_aux
+    }
+    if (rc) return rc;
     // y2 = w2 a_S + b2
     if ((rc = col_stats(t, st, gB, nullptr, m, H))) return rc;
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red, H, G(t, "w2.bias"));
-    if ((rc = linear_bwd_weight(t, st, gB, H, a[S], H, G(t, "w2.weight"), (int)m, H, H))) return rc;
     if (fast) {
-        hipLaunchKernelGGL(mlt::act_lines_kernel, dim3(nblk(m * H / 8)), dim3(256), 0, st, (const float*)gB, m, H, dzl);
+        hipLaunchKernelGGL(mlt::wmax_kernel, dim3(1024), dim3(256), 0, st, (const float*)gB, m * H, t->wsc_base + 8 * (2 * S) + 3);
+        fast_grad_lines(t, st, gB, m, 2 * S);
+        if ((rc = fast_linear_bwd_weight(t, st, a[S], "w2", m, 2 * S))) return rc;
         rc = fast_linear_bwd_data(t, st, dzl, "w2", gA, m, 2 * S, false);
-    } else rc = linear_bwd_data(t, st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0);                         // gA = da_S
+    } else {
+        if ((rc = linear_bwd_weight(t, st, gB, H, a[S], H, G(t, "w2.weight"), (int)m, H, H))) return rc;
+        rc = linear_bwd_data(t, st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0);                            // gA = da_S
+    }
     if (rc) return rc;
     // residual stages, last to first:  a_{s+1} = a_s + B(A(a_s))
     for (int s = S - 1; s >= 0; --s) {
         T_TRY(hipMemcpyAsync(gB, gA, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));                          // gB = d r_s
-        if ((rc = block_bwd(t, st, sb[s], m, gB, xhat, dzl))) return rc;                                         // gB = dz_b
+        if ((rc = block_bwd(t, st, sb[s], m, gB, xhat, fast ? 2 * s + 1 : -1))) return rc;                       // gB = dz_b
         if (fast) {   // gB's fp32 dz_b has been consumed (dW) and its lines feed the GEMM: d t_s lands in gB directly
             if ((rc = fast_linear_bwd_data(t, st, dzl, sb[s].lin, gB, m, 2 * s + 1, false))) return rc;
         } else {
@@ -568,12 +693,12 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
             if ((rc = linear_bwd_data(t, st, gB, H, P(t, sb[s].lin + ".weight"), gT, H, (int)m, H, H, 0))) return rc;
             T_TRY(hipMemcpyAsync(gB, gT, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));                      // gB = d t_s
         }
-        if ((rc = block_bwd(t, st, sa[s], m, gB, xhat, dzl))) return rc;                                         // gB = dz_a
+        if ((rc = block_bwd(t, st, sa[s], m, gB, xhat, fast ? 2 * s : -1))) return rc;                           // gB = dz_a
         if (fast) rc = fast_linear_bwd_data(t, st, dzl, sa[s].lin, gA, m, 2 * s, true);
         else rc = linear_bwd_data(t, st, gB, H, P(t, sa[s].lin + ".weight"), gA, H, (int)m, H, H, 1);            // da_s += ...
         if (rc) return rc;
     }
-    if ((rc = block_bwd(t, st, b0, m, gA, xhat))) return rc;
+    if ((rc = block_bwd(t, st, b0, m, gA, xhat, fast ? -2 : -1))) return rc;
     // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)
     {
         double* d_ss = t->d_red + 2 * H + 16;  // pre-zeroed, never shared with d_loss (other offset)

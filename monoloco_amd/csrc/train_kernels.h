@@ -371,8 +371,9 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(float* __restrict__ d
                                                           float p_drop, uint32_t seed, uint32_t site,
                                                           const double* __restrict__ sdy, const double* __restrict__ sdyx,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                          double* __restrict__ sdz, char* __restrict__ lines) {
+                                                          double* __restrict__ sdz, float* __restrict__ dzmax) {
     __shared__ double r1[16][64];
+    float mx = 0.f;   // max |dz| of this thread (dzmax: the scale of the fast gradient GEMMs' operand, may be null)
     const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int j0 = blockIdx.x * 64 + cg * 4;
     double a[4] = {0.0, 0.0, 0.0, 0.0};
@@ -399,19 +400,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(float* __restrict__ d
                 a[e] += (double)o[e];
             }
             *(f32x4*)(dout + i * n + j0) = o;
-            if (lines) {   // dz as k32 hi|lo lines as well: the operand of the fast data-gradient GEMM (n % 32 == 0)
-                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                h4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float c = __builtin_fminf(__builtin_fmaxf(o[e], -65504.0f), 65504.0f);
-                    hi[e] = (_Float16)c;
-                    lo[e] = (_Float16)(c - (float)hi[e]);
-                }
-                char* dst = lines + i * (int64_t)n * 4 + (j0 >> 5) * 128 + (j0 & 31) * 2;
-                *(h4*)dst = hi;
-                *(h4*)(dst + 64) = lo;
-            }
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(o[0]), __builtin_fabsf(o[1]))),
+                                 __builtin_fmaxf(__builtin_fabsf(o[2]), __builtin_fabsf(o[3])));
         }
         if (blockIdx.y == 0 && rg == 0) {  // one thread per column publishes the parameter gradients
 #pragma unroll
@@ -431,6 +421,14 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(float* __restrict__ d
         for (int g = 0; g < 16; ++g) s += r1[g][cj];
         atomicAdd(&sdz[blockIdx.x * 64 + cj], s);
     }
+    if (dzmax) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) {
+            if (!(mx < 3.0e38f)) mx = 3.0e38f;
+            atomicMax((unsigned*)dzmax, __builtin_bit_cast(unsigned, mx));
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -446,9 +444,11 @@ __device__ __forceinline__ void split_h(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(c - (float)hi);
 }
 
-// scale2 = {2^e, 2^-e, bits of max|W|, -}: wmax_kernel folds max|W| into scale2[2] (pre-zeroed; non-negative floats order like
-// their bit patterns), the pack kernels derive e from it and thread 0 publishes 2^e / 2^-e for the GEMM's epilogue
-__global__ __launch_bounds__(256) void wmax_kernel(const float* __restrict__ w, int64_t numel, float* __restrict__ scale2) {
+// Scale words of one Linear (8 floats, zeroed at the start of a step):
+//   [0] 2^e_w  [1] 2^-e_w  [2] max|W|  [3] max|dz|  [4] 2^-(e_w + e_dz) (descale of dx = dz . W)  [5] 2^-e_dz (of dW = dz^T . x)
+// wmax_kernel folds a max of absolute values into a word (non-negative floats order like their bit patterns); the pack /
+// line kernels derive the exponent from it and one thread publishes the powers of two the GEMM epilogues read.
+__global__ __launch_bounds__(256) void wmax_kernel(const float* __restrict__ w, int64_t numel, float* __restrict__ maxword) {
     __shared__ float red[256];
     float mx = 0.f;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < numel; i += (int64_t)gridDim.x * 1024) {
@@ -466,12 +466,11 @@ __global__ __launch_bounds__(256) void wmax_kernel(const float* __restrict__ w, 
     if (threadIdx.x == 0) {
         float r = red[0];
         if (!(r < 3.0e38f)) r = 3.0e38f;   // inf / NaN weights: the step is lost anyway, keep the exponent finite
-        atomicMax((unsigned*)scale2 + 2, __builtin_bit_cast(unsigned, r));
+        atomicMax((unsigned*)maxword, __builtin_bit_cast(unsigned, r));
     }
 }
 
-__device__ __forceinline__ int wscale_exp(const float* scale2) {
-    const float m = scale2[2];
+__device__ __forceinline__ int wscale_exp(float m) {
     int e = 0;
     if (m > 0.f && m < 3.0e38f) e = (int)floorf(log2f(16384.0f / m));   // max|W| * 2^e in [2^13, 2^15): far inside fp16
     return e > 40 ? 40 : (e < -40 ? -40 : e);
@@ -485,7 +484,7 @@ __global__ __launch_bounds__(256) void wpack_kernel(const float* __restrict__ w,
                                                     float* __restrict__ scale2, char* __restrict__ lines,
                                                     float* __restrict__ bias_scaled) {
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int e2 = wscale_exp(scale2);
+    const int e2 = wscale_exp(scale2[2]);
     const float sc = ldexpf(1.0f, e2);
     if (id == 0 && !TRANS) {
         scale2[0] = sc;
@@ -595,6 +594,221 @@ __global__ __launch_bounds__(256) void bn_relu_drop_lines_kernel(const float* __
     const u4 out = odd ? u4{s0, s1, lo2[0], lo2[1]} : u4{hi2[0], hi2[1], s0, s1};
     const int g = q >> 1;   // 8-column group
     if (live) *(u4*)(lines + i * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16 + (odd ? 64 : 0)) = out;
+}
+
+// fp32 (m, n) -> TRANSPOSED lines [n][m_pad] (row j = column j of src over the batch, k32 blocks of 32 consecutive rows:
+// the operands of the weight-gradient GEMM dW = dz^T . x, whose reduction runs over the batch), rows m..m_pad zero.
+// PLAIN: src is a gradient dz: it is scaled by 2^e_dz (sc[3] = max|dz| -> max * 2^e in [2^13, 2^15); gradients carry a
+// 1/m factor and would sit in fp16's subnormal range otherwise), ALSO written as ordinary lines (the operand of
+// dx = dz . W), and workgroup (0, 0) publishes the two descale words.  One workgroup per 64 x 64 tile.
+template <bool PLAIN>
+__global__ __launch_bounds__(256) void tlines_kernel(const float* __restrict__ src, int64_t m, int n, int64_t m_pad, float* __restrict__ sc,
+                                                    char* __restrict__ linesT, char* __restrict__ lines) {
+    __shared__ float tile[64][68];   // [column][row]
+    const int j0 = blockIdx.x * 64;
+    const int64_t i0 = (int64_t)blockIdx.y * 64;
+    float scale = 1.0f;
+    if (PLAIN) {
+        const int e = wscale_exp(sc[3]);
+        scale = ldexpf(1.0f, e);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            sc[4] = ldexpf(1.0f, -e) * sc[1];
+            sc[5] = ldexpf(1.0f, -e);
+        }
+    }
+    const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int r = r0 + 16 * ps;
+        const int64_t i = i0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (i < m) v = *(const f32x4*)(src + i * n + j0 + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] *= scale;
+            tile[c4 * 4 + e][r] = v[e];
+        }
+        if (PLAIN) {   // ordinary lines of the same (scaled) values: lane pairs exchange halves (see bn_relu_drop_lines_kernel)
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            unsigned hi2[2], lo2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                _Float16 a0, b0, a1, b1;
+                split_h(v[2 * e], a0, b0);
+                split_h(v[2 * e + 1], a1, b1);
+                hi2[e] = __builtin_bit_cast(unsigned, h2{a0, a1});
+                lo2[e] = __builtin_bit_cast(unsigned, h2{b0, b1});
+            }
+            const bool odd = c4 & 1;
+            const unsigned s0 = __shfl_xor(odd ? hi2[0] : lo2[0], 1, 64), s1 = __shfl_xor(odd ? hi2[1] : lo2[1], 1, 64);
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const u4 out = odd ? u4{s0, s1, lo2[0], lo2[1]} : u4{hi2[0], hi2[1], s0, s1};
+            const int g = (j0 >> 3) + (c4 >> 1);   // 8-column group of the row
+            if (i < m) *(u4*)(lines + i * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16 + (odd ? 64 : 0)) = out;
+        }
+    }
+    __syncthreads();
+    // 64 columns x 8 groups of 8 rows; a lane octet writes the two 128-byte lines of one column (256 contiguous bytes)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int col = (threadIdx.x >> 3) + 32 * ps, grp = threadIdx.x & 7;
+        const f32x4 a = *(const f32x4*)&tile[col][grp * 8], b = *(const f32x4*)&tile[col][grp * 8 + 4];
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 p, q;
+            split_h(e < 4 ? a[e] : b[e - 4], p, q);
+            hi[e] = p;
+            lo[e] = q;
+        }
+        char* dst = linesT + (int64_t)(j0 + col) * m_pad * 4 + (i0 >> 5) * 128 + (grp >> 2) * 128 + (grp & 3) * 16;
+        *(h8*)dst = hi;
+        *(h8*)(dst + 64) = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// "Skinny" products (one side at most 68 wide: the input layer, the two output heads).  On the 128 x 128 tiles of
+// sgemm_kernel they cost 0.2 - 0.9 ms each at 65536 rows (mostly padding); these are bound by the one (m x H) matrix they
+// read or write.  NCMAX = 68 = the stereo input width.
+constexpr int SK_NC = 68;
+
+// out (m x n) [+]= s (m x nc, row stride lds) . W + bias,  W(c, j) = w[c * wsc + j * wsj]      (n % 64 == 0)
+//   input layer forward (W = w1^T), data gradient of the heads (dy3 = dout . w_fin, dy2 += daux . w_aux).
+// One workgroup per 64 columns x (64 rows per pass); thread = 4 columns x 4 rows, operands through LDS.
+__global__ __launch_bounds__(256) void skinny_out_kernel(const float* __restrict__ s, int lds, int nc, const float* __restrict__ w,
+                                                        int64_t wsc, int64_t wsj, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int64_t m, int n, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float wl[SK_NC][64];
+    __shared__ __attribute__((aligned(16))) float sl[SK_NC][64];   // [c][row]
+    const int jb = blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < nc * 64; idx += 256) {
+        const int c = idx >> 6, jj = idx & 63;
+        wl[c][jj] = w[c * wsc + (int64_t)(jb + jj) * wsj];
+    }
+    const int cg = threadIdx.x & 15, rq = threadIdx.x >> 4;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b4 = *(const f32x4*)(bias + jb + cg * 4);
+    for (int64_t i0 = (int64_t)blockIdx.y * 64; i0 < m; i0 += (int64_t)gridDim.y * 64) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nc * 64; idx += 256) {
+            const int r = idx / nc, c = idx - r * nc;
+            sl[c][r] = (i0 + r < m) ? s[(i0 + r) * lds + c] : 0.f;
+        }
+        __syncthreads();
+        f32x4 acc[4] = {b4, b4, b4, b4};
+        for (int c = 0; c < nc; ++c) {
+            const f32x4 wv = *(const f32x4*)&wl[c][cg * 4];
+            const f32x4 sv = *(const f32x4*)&sl[c][rq * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[r][e] = __builtin_fmaf(sv[r], wv[e], acc[r][e]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t i = i0 + rq * 4 + r;
+            if (i < m) {
+                float* o = out + i * n + jb + cg * 4;
+                if (accumulate) acc[r] += *(const f32x4*)o;
+                *(f32x4*)o = acc[r];
+            }
+        }
+    }
+}
+
+// part[blockIdx.y][c][j] = sum over this workgroup's rows of s[i][c] * x[i][j]   (x: m x n, n % 64 == 0; c < nc <= 12 * NZ)
+//   weight gradients of the heads (s = dout) and of the input layer (s = the input, x = dz; result transposed by the
+//   reduction).  Thread = 4 columns x a row group, NCT accumulator rows; blockIdx.z selects a group of NCT skinny columns.
+template <int NCT>
+__global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ s, int lds, int nc, const float* __restrict__ x,
+                                                       int64_t m, int n, float* __restrict__ part) {
+    __shared__ float red[4][16][NCT * 4];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j0 = blockIdx.x * 64 + cg * 4;
+    const int c0 = blockIdx.z * NCT;
+    float acc[NCT][4];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[c][e] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += (int64_t)gridDim.y * 16) {
+        const f32x4 v = *(const f32x4*)(x + i * n + j0);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const float sv = (c0 + c < nc) ? s[i * lds + c0 + c] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(sv, v[e], acc[c][e]);
+        }
+    }
+    // the 16 row groups: 4 per wave (lane bits 4, 5), 4 waves
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = acc[c][e];
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            acc[c][e] = a;
+        }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 16) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wv][cg][c * 4 + e] = acc[c][e];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 16 * NCT * 4; idx += 256) {
+        const int g = idx / (NCT * 4), r = idx - g * (NCT * 4);
+        const int c = r >> 2, e = r & 3;
+        if (c0 + c < nc)
+            part[((int64_t)blockIdx.y * nc + c0 + c) * n + blockIdx.x * 64 + g * 4 + e] =
+                (red[0][g][r] + red[1][g][r]) + (red[2][g][r] + red[3][g][r]);
+    }
+}
+
+// dst[c][j] (or dst[j][c] when transpose) = sum over the partial planes, in order
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restrict__ part, int planes, int nc, int n,
+                                                           float* __restrict__ dst, int transpose) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= nc * n) return;
+    float a = 0.f;
+    for (int z = 0; z < planes; ++z) a += part[(int64_t)z * nc * n + id];
+    const int c = id / n, j = id - c * n;
+    dst[transpose ? (int64_t)j * nc + c : id] = a;
+}
+
+// out[i][c] = x[i] . w[c] + b[c] for c < NC (the output heads, x: m x n, n % 256 == 0, out row stride ldo): a wave per
+// row, the head weights in LDS (NC * n <= 15360 floats), butterfly reduction.
+template <int NC>
+__global__ __launch_bounds__(256) void skinny_heads_kernel(const float* __restrict__ x, int64_t m, int n, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) float wl[15360];
+    for (int idx = threadIdx.x; idx < NC * n; idx += 256) wl[idx] = w[idx];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wv; i < m; i += (int64_t)gridDim.x * 4) {
+        float acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+        for (int j = lane * 4; j < n; j += 256) {
+            const f32x4 v = *(const f32x4*)(x + i * n + j);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 ww = *(const f32x4*)&wl[c * n + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c] = __builtin_fmaf(v[e], ww[e], acc[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float a = acc[c];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+            if (lane == c) out[i * ldo + c] = a + bias[c];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void col_sum_to_float_kernel(const double* __restrict__ s, int n, float* __restrict__ out) {

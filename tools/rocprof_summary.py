@@ -21,6 +21,15 @@ def main(db_path, out_path=None):
             "select name, grid_x, count(*), avg(duration), min(duration), max(duration) from kernels "
             "where name like '%dense_kernel%' group by name, grid_x").fetchall():
         lines.append("%-60s grid_x=%-8d calls=%-5d avg_ns=%-10.0f min=%-9d max=%d" % (name[:60], gx, n, avg, mn, mx))
+    lines.append("")
+    lines.append("# exact-fp32 GEMM (training) by grid")
+    try:
+        for name, gx, gy, gz, n, avg, mn, mx in cur.execute(
+                "select name, grid_x, grid_y, grid_z, count(*), avg(duration), min(duration), max(duration) from kernels "
+                "where name like '%sgemm_kernel%' group by grid_x, grid_y, grid_z").fetchall():
+            lines.append("%-40s grid=(%d,%d,%d) calls=%-5d avg_ns=%-10.0f min=%-9d max=%d" % (name[:40], gx, gy, gz, n, avg, mn, mx))
+    except sqlite3.Error as e:
+        lines.append("(n/a: %s)" % e)
     txt = "\n".join(lines) + "\n"
     if out_path:
         open(out_path, 'w').write(txt)
