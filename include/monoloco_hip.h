@@ -141,6 +141,10 @@ int ml_get_keypoints(const float* kps_dev, int64_t m, int mode, float* out_dev, 
 #define ML_POSTGEO_STRIDE 12
 int ml_post_geometry(const float* kps_dev, int64_t m, const float* kinv_host, const float* d_dev, float* out_dev,
                      void* stream);
+/* ... with the distances read at d_dev[i * d_stride] (a column of the packed (m, ML_OUT_STRIDE) result: Loco.forward
+ * computes this block right behind the network, from the keypoints it already has on the device). */
+int ml_post_geometry_strided(const float* kps_dev, int64_t m, const float* kinv_host, const float* d_dev, int64_t d_stride,
+                             float* out_dev, void* stream);
 /* Dataset-preparation rows in one launch (prep/preprocess_kitti.py:190-253 calls preprocess_monoloco once per
  * matched annotation, each with the K of its image): kps_dev (m,3,17); kinv_table_host (nk,9) = inverses of the
  * distinct intrinsic matrices; k_index_dev (m) int32 = table entry of each row (not range-checked).  kps_r_dev

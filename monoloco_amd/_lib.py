@@ -50,6 +50,7 @@ SIGNATURES = {
     'ml_stereo_pairs': (c_int, [_P, c_int64, _P, c_int64, _P, _P]),
     'ml_extract_outputs': (c_int, [_P, c_int, _P, c_int64, _P, POINTER(c_float), _P, _P, _P, _P]),
     'ml_post_geometry': (c_int, [_P, c_int64, POINTER(c_float), _P, _P, _P]),
+    'ml_post_geometry_strided': (c_int, [_P, c_int64, POINTER(c_float), _P, c_int64, _P, _P]),
     'ml_preprocess_rows': (c_int, [_P, _P, c_int64, POINTER(c_float), c_int, _P, c_float, _P, _P]),
     'ml_extract_outputs_mono': (c_int, [_P, c_int64, _P, _P]),
     'ml_laplace_sampling': (c_int, [_P, c_int64, c_int, c_uint32, _P, _P]),

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void back_correct_kernel(const float* __restri
 // Same arithmetic, in the same order, as keypoints_kernel / pix2cam_kernel / xyz_from_distance_kernel.
 constexpr int POSTGEO_STRIDE = 12;
 __global__ __launch_bounds__(256) void post_geometry_kernel(const float* __restrict__ kps, int64_t m, Kinv ki,
-                                                            const float* __restrict__ d, float* __restrict__ out) {
+                                                            const float* __restrict__ d, int64_t d_stride,
+                                                            float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
     const float* u = kps + i * KPS_ROW;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void post_geometry_kernel(const float* __restr
     o[6] = cx;
     o[7] = cy;
     o[8] = cz;
-    const float dd = d ? d[i] : 0.0f;
+    const float dd = d ? d[i * d_stride] : 0.0f;
     const float nrm = sqrtf(__fadd_rn(__fadd_rn(1.0f, __fmul_rn(cx, cx)), __fmul_rn(cy, cy)));
     o[9] = __fmul_rn(cx, dd) / nrm;
     o[10] = __fmul_rn(cy, dd) / nrm;

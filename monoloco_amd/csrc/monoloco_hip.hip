@@ -1036,13 +1036,18 @@ int ml_preprocess_rows(const float* kps_dev, const float* kps_r_dev, int64_t m, 
     return ML_OK;
 }
 
-int ml_post_geometry(const float* kps_dev, int64_t m, const float* kinv_host, const float* d_dev, float* out_dev,
-                     void* stream) {
-    if (m < 0 || !kinv_host || (m > 0 && (!kps_dev || !out_dev))) return fail(ML_ERR_ARG, "bad argument");
+int ml_post_geometry_strided(const float* kps_dev, int64_t m, const float* kinv_host, const float* d_dev, int64_t d_stride,
+                             float* out_dev, void* stream) {
+    if (m < 0 || !kinv_host || (m > 0 && (!kps_dev || !out_dev)) || d_stride < 1) return fail(ML_ERR_ARG, "bad argument");
     if (m == 0) return ML_OK;
-    hipLaunchKernelGGL(mlk::post_geometry_kernel, ML_GRID(m), kps_dev, m, make_kinv(kinv_host), d_dev, out_dev);
+    hipLaunchKernelGGL(mlk::post_geometry_kernel, ML_GRID(m), kps_dev, m, make_kinv(kinv_host), d_dev, d_stride, out_dev);
     HIP_TRY(hipGetLastError());
     return ML_OK;
+}
+
+int ml_post_geometry(const float* kps_dev, int64_t m, const float* kinv_host, const float* d_dev, float* out_dev,
+                     void* stream) {
+    return ml_post_geometry_strided(kps_dev, m, kinv_host, d_dev, 1, out_dev, stream);
 }
 
 int ml_extract_outputs_mono(const float* raw_dev, int64_t m, float* out_dev, void* stream) {

@@ -134,19 +134,28 @@ def extract_outputs_device(raw, centre=None, kk=None, box_conf=None, row_index=N
     return out, xyzds
 
 
-def post_geometry(kps, kk, d=None, device=None):
+def post_geometry(kps, kk, d=None, device=None, out=None):
     """(m,3,17) keypoints, K, predicted distances (m) -> (m,12) device tensor: uv_shoulder, uv_head, uv_center,
-    xy_center (3), xyz_pred (3) -- the geometry of Loco.post_process in one launch (ml_post_geometry)."""
+    xy_center (3), xyz_pred (3) -- the geometry of Loco.post_process in one launch (ml_post_geometry).  `d` may be a
+    strided 1-D device view (a column of the packed result); `out`: a preallocated contiguous (m,12) device tensor."""
     lib = _lib.load()
     dev = _require_cuda(device)
     kps = _dev_f32(kps, dev)
     assert kps.dim() == 3 and kps.shape[1] == 3 and kps.shape[2] == 17, "keypoints must be (m, 3, 17)"
     m = kps.shape[0]
-    d = _dev_f32(d, dev).reshape(-1) if d is not None else None
-    assert d is None or d.shape[0] == m
-    out = torch.empty((m, 12), dtype=torch.float32, device=dev)
+    stride = 1
+    if d is not None:
+        if isinstance(d, torch.Tensor) and d.dim() == 1 and d.is_cuda and d.dtype == torch.float32 and d.device == dev \
+                and d.shape[0] == m and m > 0 and d.stride(0) >= 1:
+            stride = int(d.stride(0))
+        else:
+            d = _dev_f32(d, dev).reshape(-1)
+        assert d.shape[0] == m
+    if out is None:
+        out = torch.empty((m, 12), dtype=torch.float32, device=dev)
+    assert out.is_contiguous() and tuple(out.shape) == (m, 12) and out.device == dev
     with torch.cuda.device(dev):
-        check(lib.ml_post_geometry(_ptr(kps), m, fptr(inverse_intrinsics(kk)), _ptr(d), _ptr(out), _stream(dev)))
+        check(lib.ml_post_geometry_strided(_ptr(kps), m, fptr(inverse_intrinsics(kk)), _ptr(d), stride, _ptr(out), _stream(dev)))
     return out
 
 
@@ -291,13 +300,14 @@ class LocoEngine:
                                                    _ptr(out), _ptr(xyzds), _stream(dev)))
         return out, xyzds, raw
 
-    def forward_stereo(self, kps_l, kps_r, kinv, box_conf=None, want_raw_all=False):
+    def forward_stereo(self, kps_l, kps_r, kinv, box_conf=None, want_raw_all=False, out=None):
         """All-vs-all stereo.  Returns dict(out, xyzds, best, ties, raw_all)."""
         dev = self.device
         kps_l = _dev_f32(kps_l, dev)
         kps_r = _dev_f32(kps_r, dev)
         ml, mr = kps_l.shape[0], kps_r.shape[0]
-        out = torch.empty((ml, _lib.ML_OUT_STRIDE), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((ml, _lib.ML_OUT_STRIDE), dtype=torch.float32, device=dev)
         xyzds = torch.empty((ml, _lib.ML_XYZDS_STRIDE), dtype=torch.float32, device=dev)
         best = torch.empty((ml,), dtype=torch.int32, device=dev)
         ties = torch.zeros((1,), dtype=torch.int32, device=dev)

@@ -6,6 +6,7 @@ visible through the reference's own call sites: inputs may also be tensors (no l
 ``device`` must be a HIP device (default: the current one) and ``post_process`` is vectorised (the
 reference's per-person Python loop is quadratic in the number of persons).
 """
+import ctypes
 import logging
 from collections import defaultdict
 
@@ -16,6 +17,12 @@ from .. import engine
 from ..utils import get_iou_matches, reorder_matches, xyz_from_distance
 from .architectures import LocoModel, MonolocoModel
 from .process import extract_outputs_mono, packed_to_dict, unnormalize_bi
+
+
+class _LocoOut(dict):
+    """The dictionary Loco.forward returns: a plain dict of the reference's keys, plus (as an attribute, not a key) the
+    geometry block of the same keypoints that post_process would otherwise recompute."""
+    __slots__ = ('_geo',)
 
 
 class Loco:
@@ -70,7 +77,9 @@ class Loco:
             return None
         dev = self.device
         kps = engine._dev_f32(keypoints, dev)
-        kinv = engine.inverse_intrinsics(kk.tolist() if isinstance(kk, torch.Tensor) else kk)
+        kk_list = kk.tolist() if hasattr(kk, 'tolist') else kk
+        kinv = engine.inverse_intrinsics(kk_list)
+        geo_host = None
         if self.net == 'monoloco':
             # legacy MonoLoco (net.py:95-100): zero-centred inputs, outputs (d, log(b/d))
             x = engine.preprocess_mono(kps, kk.tolist() if isinstance(kk, torch.Tensor) else kk, device=dev,
@@ -84,17 +93,19 @@ class Loco:
             dic_out = extract_outputs_mono(self.engine.forward_raw(x))
             n_out = kps.shape[0]
         elif self.net == 'monoloco_pp':
-            out, _, _ = self.engine.forward_mono(kps, kinv)
-            dic_out = packed_to_dict(out, 9)
+            buf, out, geo = self._packed_buffers(kps.shape[0])
+            self.engine.forward_mono(kps, kinv, out=out)
+            dic_out, geo_host = self._fetch_with_geometry(buf, out, geo, kps, kinv, 9)
             n_out = kps.shape[0]
         else:
             if keypoints_r is not None and len(keypoints_r) > 0:
                 kps_r = engine._dev_f32(keypoints_r, dev)
             else:
                 kps_r = kps[0:1].clone()  # reference net.py:115-116
-            res = self.engine.forward_stereo(kps, kps_r, kinv, want_raw_all=True)
+            buf, out, geo = self._packed_buffers(kps.shape[0])
+            res = self.engine.forward_stereo(kps, kps_r, kinv, want_raw_all=True, out=out)
             if int(res['ties'].item()) == 0:
-                dic_out = packed_to_dict(res['out'], 10)
+                dic_out, geo_host = self._fetch_with_geometry(buf, out, geo, kps, kinv, 10)
             else:
                 # exact ties of the aux logit: the reference keeps every tied pair row (process.py:325)
                 raw = res['raw_all'].view(kps.shape[0], kps_r.shape[0], 10)
@@ -110,7 +121,30 @@ class Loco:
                                                         n_samples=self.N_SAMPLES).cpu()
         else:
             dic_out['epi'] = [0.] * n_out
+        if geo_host is not None:
+            # the geometry block post_process needs, computed behind the network from the keypoints that were on the device
+            # anyway and fetched in the same copy; post_process uses it when it is handed these very objects again
+            dic_out = _LocoOut(dic_out)
+            dic_out._geo = (keypoints, kk_list, dic_out['d'], geo_host)
         return dic_out
+
+    def _packed_buffers(self, m):
+        """One device allocation for the packed (m,16) network result and the (m,12) post-process geometry."""
+        buf = torch.empty((m * (engine._lib.ML_OUT_STRIDE + 12),), dtype=torch.float32, device=self.device)
+        n = m * engine._lib.ML_OUT_STRIDE
+        return buf, buf[:n].view(m, engine._lib.ML_OUT_STRIDE), buf[n:].view(m, 12)
+
+    def _fetch_with_geometry(self, buf, out, geo, kps, kinv, n_cols):
+        """post_geometry on the device from the packed distances (column 3), then ONE copy of both blocks off the device."""
+        m = out.shape[0]
+        # (engine.post_geometry without its argument checks: everything here was just produced by this class)
+        with torch.cuda.device(self.device):
+            engine.check(engine._lib.load().ml_post_geometry_strided(
+                engine._ptr(kps), m, engine.fptr(kinv), ctypes.c_void_p(out.data_ptr() + 3 * 4), engine._lib.ML_OUT_STRIDE,
+                engine._ptr(geo), engine._stream(self.device)))
+        n = m * engine._lib.ML_OUT_STRIDE
+        host = buf.cpu()
+        return packed_to_dict(host[:n].view(m, engine._lib.ML_OUT_STRIDE), n_cols), host[n:].view(m, 12)
 
     @staticmethod
     def post_process(dic_in, boxes, keypoints, kk, dic_gt=None, iou_min=0.3, reorder=True, verbose=False):
@@ -137,21 +171,27 @@ class Loco:
 
         # device geometry, whole image in ONE launch and one copy back (ml_post_geometry): representative pixels,
         # normalised centre, back-projected xyz
-        kps_t = keypoints if isinstance(keypoints, torch.Tensor) else torch.tensor(keypoints, dtype=torch.float32)
-        m_kp = kps_t.shape[0]
         d_all = torch.as_tensor(dic_in['d'], dtype=torch.float32).reshape(-1)
-        n_pred = min(d_all.shape[0], m_kp)
-        d_fit = torch.zeros(m_kp, dtype=torch.float32)
-        d_fit[:n_pred] = d_all[:n_pred]
-        geo = engine.post_geometry(kps_t, kk.tolist() if isinstance(kk, torch.Tensor) else kk, d_fit).cpu()
-        uv_shoulders, uv_heads, uv_centers = geo[:, 0:2], geo[:, 2:4], geo[:, 4:6]
+        kk_list = kk.tolist() if hasattr(kk, 'tolist') else kk
+        cached = getattr(dic_in, '_geo', None)
+        if cached is not None and cached[0] is keypoints and cached[2] is dic_in['d'] and cached[1] == kk_list \
+                and cached[3].shape[0] == len(keypoints) == d_all.shape[0]:
+            geo = cached[3]   # computed by forward() on these keypoints / intrinsics / distances
+            n_pred = d_all.shape[0]
+        else:
+            kps_t = keypoints if isinstance(keypoints, torch.Tensor) else torch.tensor(keypoints, dtype=torch.float32)
+            m_kp = kps_t.shape[0]
+            n_pred = min(d_all.shape[0], m_kp)
+            d_fit = torch.zeros(m_kp, dtype=torch.float32)
+            d_fit[:n_pred] = d_all[:n_pred]
+            geo = engine.post_geometry(kps_t, kk_list, d_fit).cpu()
         xy_centers = geo[:, 6:9]
-        xyz_all = geo[:n_pred, 9:12].double().numpy()
+        g64 = geo.numpy().astype(np.float64)
+        xyz_all = g64[:n_pred, 9:12]
         dist_all = np.sqrt(xyz_all[:, 0] ** 2 + xyz_all[:, 1] ** 2 + xyz_all[:, 2] ** 2)
-        bi_all = torch.as_tensor(dic_in['bi'], dtype=torch.float32).reshape(-1).double().numpy()
-        uv_s = np.rint(uv_shoulders.double().numpy()).astype(int)
-        uv_c = np.rint(uv_centers.double().numpy()).astype(int)
-        uv_h = np.rint(uv_heads.double().numpy()).astype(int)
+        bi_all = torch.as_tensor(dic_in['bi'], dtype=torch.float32).reshape(-1).numpy().astype(np.float64)
+        uv = np.rint(g64[:, 0:6]).astype(int)
+        uv_s, uv_h, uv_c = uv[:, 0:2], uv[:, 2:4], uv[:, 4:6]
         has_yaw = 'yaw' in dic_in
         has_aux = 'aux' in dic_in
         if not has_yaw and all_idxs:

@@ -289,6 +289,53 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train':
     golden_train()
 
 
+def golden_train_big():
+    """Two iterations of the reference's training loop body on LARGE batches (4096 / 5000 rows drawn from its fixtures,
+    synth.big_train_batch), hidden 256, dropout 0: the regime in which the HIP step runs its hidden-layer GEMMs on the
+    3-product fp16 MFMA kernel.  First-step outputs, losses of both steps, first-step (clipped) gradients: all of them for
+    mono, the large matrices of one stage + the narrow layers for stereo."""
+    import itertools
+    from monoloco.train.losses import CompositeLoss, MultiTaskLoss
+    g = {}
+    for mode, in_f, out_f, seed, m in (('mono', 34, 9, 41, 4096), ('stereo', 68, 10, 42, 5000)):
+        hidden = 256
+        dj = json.load(open(os.path.join(REF, 'tests', 'sample_joints-kitti-%s.json' % mode)))
+        xb, yb = synth.big_train_batch(np.asarray(dj['train']['X'], dtype=np.float32), np.asarray(dj['train']['Y'], dtype=np.float32),
+                                       m, seed)
+        x, y = torch.tensor(xb), torch.tensor(yb)
+        tasks = ('d', 'x', 'y', 'h', 'w', 'l', 'ori') + (('aux',) if mode == 'stereo' else ())
+        losses_tr, losses_val = CompositeLoss(tasks)()
+        mt = MultiTaskLoss(losses_tr, losses_val, (1,) * len(tasks), tasks)
+        model = LocoModel(in_f, out_f, hidden, p_dropout=0.0, device='cpu')
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(seed, in_f, out_f, hidden).items()},
+                              strict=False)
+        model.train()
+        opt = torch.optim.Adam(params=itertools.chain(model.parameters(), mt.parameters()), lr=0.001)
+        keep = None if mode == 'mono' else ('w1.weight', 'linear_stages.1.w1.weight', 'linear_stages.1.w2.weight',
+                                            'linear_stages.1.batch_norm2.weight', 'w2.weight', 'w3.weight', 'w_fin.weight',
+                                            'w_aux.weight', 'w2.bias')
+        for step in range(2):
+            opt.zero_grad()
+            out = model(x)
+            loss, vals = mt(out, y, phase='train')
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 3)
+            if step == 0:
+                g[mode + '_out0'] = out.detach().numpy()
+                for k, p in model.named_parameters():
+                    if keep is None or k in keep:
+                        g[mode + '_grad0/' + k] = p.grad.numpy().copy()
+            opt.step()
+            g[mode + '_loss%d' % step] = np.array([float(loss)] + [float(v) for v in vals])
+        g[mode + '_rows_seed'] = np.array([m, seed])
+    np.savez_compressed(os.path.join(OUT, 'golden_train_big.npz'), **g)
+    print('golden_train_big.npz %.1f KiB' % (os.path.getsize(os.path.join(OUT, 'golden_train_big.npz')) / 1024))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train_big':
+    golden_train_big()
+
+
 def golden_formats():
     """On-disk formats: the reference's preprocess_pifpaf on JSON texts (fixture + a synthetic x,y,w,h/'score'
     list) and the reference's save_txts (eval/generate_kitti.py:202-253) for every `net` branch on seeded

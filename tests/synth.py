@@ -88,3 +88,12 @@ def make_poses(m, seed=0, width=1238, height=374):
     kps[:, 1] = cy + hgt * (sk_y[None] + 0.02 * rng.standard_normal((m, 17)))
     kps[:, 2] = rng.uniform(0.2, 1, (m, 17))
     return kps
+
+
+def big_train_batch(x, y, m, seed):
+    """A training batch of m rows drawn (with replacement) from the fixture batch (x, y numpy fp32), keypoints jittered by
+    N(0, 0.01) -- the same rows for oracle/make_golden.py (reference run) and the GPU tests."""
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, x.shape[0], size=m)
+    xb = x[idx] + rng.normal(0, 0.01, size=(m, x.shape[1])).astype(np.float32)
+    return xb.astype(np.float32), y[idx].astype(np.float32)

@@ -154,6 +154,12 @@ def test_loco_dropin_on_pifpaf_fixture(hip_lib, cuda_device, c1, tag):
         assert np.abs(np.array(pp[key]) - np.array(ref[key])).max() <= TOL, key
     assert np.abs(np.array(pp['confs']) / np.array(ref['confs']) - 1).max() <= 1e-4
     assert pp['stds_epi'] == ref['stds_epi']
+    # forward() hands post_process the geometry block of these keypoints (one device round trip less per frame); a plain
+    # dict with the same entries, or other keypoint objects, take the stand-alone route: identical results
+    assert getattr(dic, '_geo', None) is not None and isinstance(dic, dict)
+    assert dict(net.post_process(dict(dic), boxes, kps, kk)) == dict(pp)
+    assert dict(net.post_process(dic, boxes, copy.deepcopy(kps), kk)) == dict(pp)
+    assert json.loads(json.dumps({k: v for k, v in dic.items() if k == 'epi'})) == {'epi': [0.] * 16}
     # with ground truth (IoU matching, re-ordering, xyz_real)
     ppg = net.post_process(dic, boxes, kps, kk, dic_gt=cj['dic_gt'])
     refg = cj['post_gt_%s' % tag]

@@ -148,12 +148,10 @@ def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path
 
 
 def _big_batch(mode, m, seed):
-    """The fixture batch tiled to m rows with a little keypoint jitter (labels repeated)."""
+    """The fixture batch drawn to m rows with a little keypoint jitter (synth.big_train_batch, shared with make_golden)."""
     x, y = _batch(mode)
-    rng = np.random.default_rng(seed)
-    idx = rng.integers(0, x.shape[0], size=m)
-    xb = x.numpy()[idx] + rng.normal(0, 0.01, size=(m, x.shape[1])).astype(np.float32)
-    return torch.tensor(xb), torch.tensor(y.numpy()[idx])
+    xb, yb = synth.big_train_batch(x.numpy(), y.numpy(), m, seed)
+    return torch.tensor(xb), torch.tensor(yb)
 
 
 @pytest.mark.parametrize("mode,hidden,m,p_drop", [('mono', 256, 4096, 0.0), ('stereo', 512, 5000, 0.0), ('mono', 1024, 4096, 0.2)])
@@ -209,4 +207,44 @@ def test_fast_forward_gemms_against_fp64_oracle(hip_lib, cuda_device):
         e_hip = (g[k].double() - g64[k]).abs().max().item() / scale
         e_t32 = (g32[k].double() - g64[k]).abs().max().item() / scale
         assert e_hip <= max(8 * e_t32, 2e-5), (k, e_hip, e_t32)
+    tr.close()
+
+
+@pytest.mark.parametrize("mode,in_f,out_f", [('mono', 34, 9), ('stereo', 68, 10)])
+def test_fast_path_training_steps_match_reference(hip_lib, cuda_device, mode, in_f, out_f):
+    """The reference's own loop body (oracle/make_golden.py train_big: torch CPU fp32) on 4096 / 5000-row batches, hidden
+    256: first-step outputs, both steps' losses and the first step's clipped gradients of the HIP step whose hidden-layer
+    GEMMs (forward, data and weight gradients) run on the 3-product fp16 MFMA kernel."""
+    from monoloco_amd.train import HipTrainer
+    g = dict(np.load(os.path.join(G, 'golden_train_big.npz')))
+    m, seed = [int(v) for v in g[mode + '_rows_seed']]
+    x, y = _big_batch(mode, m, seed)
+    sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(seed, in_f, out_f, 256).items()}
+    tr = HipTrainer(sd0, p_dropout=0.0, lr=0.001, device=cuda_device)
+    names = ['loss', 'd', 'x', 'y', 'h', 'w', 'l', 'ori'] + (['aux'] if mode == 'stereo' else [])
+    gmax = max(np.abs(v).max() for k, v in g.items() if k.startswith(mode + '_grad0/'))
+    for step in range(2):
+        if step == 0:
+            res, out = tr.step(x, y, want_outputs=True)
+            ref_out = g[mode + '_out0']
+            assert np.abs(out.cpu().numpy() - ref_out).max() <= 2e-5 * max(1.0, np.abs(ref_out).max())
+            grads = tr.grads()
+            checked = 0
+            for k, v in grads.items():
+                if mode + '_grad0/' + k not in g:
+                    continue
+                ref_g = g[mode + '_grad0/' + k]
+                err = np.abs(v.numpy() - ref_g).max()
+                # 2e-3 of the tensor's largest entry (+ a floor: the biases in front of a BatchNorm have a mathematically zero
+                # gradient).  Measured (tools/exp_train_big.py): <= 1.2e-4 for every tensor except the first layer's, where
+                # the whole backward chain has accumulated (w1.weight 3.9e-4, batch_norm1.bias 6.3e-4); the exact-fp32 route
+                # sits at <= 2.5e-4 against the same reference run, torch fp32 itself at ~1e-4 of fp64.
+                assert err <= 2e-3 * max(np.abs(ref_g).max(), 1e-4 * gmax) + 2e-7 * gmax, (k, err, np.abs(ref_g).max())
+                checked += 1
+            assert checked >= 9
+        else:
+            res = tr.step(x, y)
+        ref = g['%s_loss%d' % (mode, step)]
+        got = np.array([res[n] for n in names])
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (step, got, ref)
     tr.close()

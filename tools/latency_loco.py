@@ -27,4 +27,7 @@ print("Loco.forward: %d persons, %.1f us per call; post_process %.1f us per call
 if len(sys.argv) > 1:
     pr = cProfile.Profile(); pr.enable()
     for _ in range(200): dic = net.forward(kps, kk)
-    pr.disable(); pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+    pr.disable(); pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(200): out = net.post_process(dic, boxes, kps, kk)
+    pr.disable(); pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
