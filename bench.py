@@ -236,7 +236,9 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         from monoloco_amd.train import HipTrainer
         g = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_train_inputs.npz'))
         res = {"config": "BASELINE configs[4]: LocoModel 34->1024->9 train-mode fwd + MultiTaskLoss + bwd + clip + Adam, "
-                         "dropout 0.2, fp32 MFMA"}
+                         "dropout 0.2; fp32 tensors; GEMMs: exact-fp32 MFMA below 4096 rows, from 4096 rows the hidden-layer "
+                         "forward / data-gradient / weight-gradient GEMMs on the 3-product fp16 MFMA kernel (fp32-class accuracy), "
+                         "so frac_of_f32_mfma_peak (157 TF basis) can exceed 1"}
         sd_t = {k: torch.tensor(v) for k, v in synth.make_state_dict(31, 34, 9, 1024).items()}
         for tag, rows in (("fixture_331", 331), ("batch_65536", 65536)):
             tr = HipTrainer(sd_t, p_dropout=0.2, lr=0.001, device=dev)
