@@ -375,50 +375,14 @@ struct SmallHeads {
     int col0[2];          // first raw column of each head
 };
 
-__global__ __launch_bounds__(256) void heads_small_kernel(SmallHeads hp, int H, float* __restrict__ raw, int raw_stride,
-                                                          int64_t m) {
-    const int64_t row = blockIdx.x;
-    if (row >= m) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int total = hp.nh[0] + hp.nh[1];
-    const int npairs = H / 8;
-    for (int o = wave; o < total; o += 4) {
-        const int hsel = o < hp.nh[0] ? 0 : 1;
-        const int oo = o - (hsel ? hp.nh[0] : 0);
-        const char* arow = hp.act[hsel] + row * (int64_t)H * 4;
-        const float* wrow = hp.w[hsel] + (size_t)oo * H;
-        float a = 0.0f;
-        for (int pr = lane; pr < npairs; pr += 64) {
-            const int bb = pr >> 2, sub = pr & 3;
-            const char* q = arow + bb * LINE + sub * 16;
-            const half8 hi = *(const half8*)q;
-            const half8 lo = *(const half8*)(q + 64);
-            const f32x4 wa = *(const f32x4*)(wrow + bb * 32 + sub * 8);
-            const f32x4 wb = *(const f32x4*)(wrow + bb * 32 + sub * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a = __builtin_fmaf((float)hi[e] + (float)lo[e], wa[e], a);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a = __builtin_fmaf((float)hi[4 + e] + (float)lo[4 + e], wb[e], a);
-        }
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) a += __shfl_xor(a, sft, 64);
-        if (lane == 0) raw[row * raw_stride + hp.col0[hsel] + oo] = a + hp.b[hsel][oo];
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // post: one thread per person.  Column meaning of raw: theta, psi, d, s=log(b/d), h, w, l,
 // sin, cos [, aux logit].  All arithmetic fp32 in the reference's association order.
-__global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ raw, int out_f,
-                                                   const int32_t* __restrict__ row_index, int64_t m,
-                                                   const float* __restrict__ centre, Kinv ki,
-                                                   const float* __restrict__ box_conf, float* __restrict__ out,
-                                                   float* __restrict__ xyzds) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    const int64_t src = row_index ? (int64_t)row_index[i] : i;
-    const float* r = raw + src * out_f;
+// One person of the post-process; r = its out_f raw network outputs (a global row, or registers of the fused tail).
+template <typename R>
+__device__ __forceinline__ void post_person(const R& r, int out_f, int64_t i, const float* __restrict__ centre, const Kinv& ki,
+                                            const float* __restrict__ box_conf, float* __restrict__ out,
+                                            float* __restrict__ xyzds) {
     const float theta = r[0], psi = r[1], d = r[2], s = r[3];
     const float bi = __fmul_rn(expf(s), d);                       // process.py:131
     const float x = __fmul_rn(__fmul_rn(d, sinf(psi)), cosf(theta));  // camera.py:232
@@ -456,6 +420,98 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ raw
         float* q = xyzds + i * 5;
         q[0] = px; q[1] = py; q[2] = pz; q[3] = d; q[4] = bi;
     }
+}
+
+__global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ raw, int out_f,
+                                                   const int32_t* __restrict__ row_index, int64_t m,
+                                                   const float* __restrict__ centre, Kinv ki,
+                                                   const float* __restrict__ box_conf, float* __restrict__ out,
+                                                   float* __restrict__ xyzds) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int64_t src = row_index ? (int64_t)row_index[i] : i;
+    const float* r = raw + src * out_f;
+    post_person(r, out_f, i, centre, ki, box_conf, out, xyzds);
+}
+
+// post_out != null: the row is post-processed here as well (post_person by thread 0: a single image's forward ends in this
+// launch); raw may then be null.
+__global__ __launch_bounds__(256) void heads_small_kernel(SmallHeads hp, int H, float* __restrict__ raw, int raw_stride,
+                                                          int64_t m, const float* __restrict__ centre, Kinv ki,
+                                                          const float* __restrict__ box_conf, float* __restrict__ post_out,
+                                                          float* __restrict__ xyzds) {
+    __shared__ float srow[16];
+    const int64_t row = blockIdx.x;
+    if (row >= m) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total = hp.nh[0] + hp.nh[1];
+    const int npairs = H / 8;
+    for (int o = wave; o < total; o += 4) {
+        const int hsel = o < hp.nh[0] ? 0 : 1;
+        const int oo = o - (hsel ? hp.nh[0] : 0);
+        const char* arow = hp.act[hsel] + row * (int64_t)H * 4;
+        const float* wrow = hp.w[hsel] + (size_t)oo * H;
+        float a = 0.0f;
+        for (int pr = lane; pr < npairs; pr += 64) {
+            const int bb = pr >> 2, sub = pr & 3;
+            const char* q = arow + bb * LINE + sub * 16;
+            const half8 hi = *(const half8*)q;
+            const half8 lo = *(const half8*)(q + 64);
+            const f32x4 wa = *(const f32x4*)(wrow + bb * 32 + sub * 8);
+            const f32x4 wb = *(const f32x4*)(wrow + bb * 32 + sub * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a = __builtin_fmaf((float)hi[e] + (float)lo[e], wa[e], a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a = __builtin_fmaf((float)hi[4 + e] + (float)lo[4 + e], wb[e], a);
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) a += __shfl_xor(a, sft, 64);
+        if (lane == 0) {
+            const float v = a + hp.b[hsel][oo];
+            if (raw) raw[row * raw_stride + hp.col0[hsel] + oo] = v;
+            srow[hp.col0[hsel] + oo] = v;
+        }
+    }
+    if (post_out) {
+        __syncthreads();
+        if (threadIdx.x == 0) post_person((const float*)srow, raw_stride, row, centre, ki, box_conf, post_out, xyzds);
+    }
+}
+
+
+// The tail of the mono tile path in ONE launch instead of three: both fused heads' partial sums are added exactly as
+// head_reduce_kernel / aux_reduce_kernel add them (bias first, slices in order), the raw row lives in registers (and is
+// written out only on request), then post_person.  OUT_F = NH + 1: w_fin's NH outputs, then the aux logit.
+template <int NH>
+__global__ __launch_bounds__(256) void tail_mono_kernel(const float* __restrict__ part_fin, const float* __restrict__ part_aux,
+                                                       int nparts, int64_t m_pad, int64_t m, const float* __restrict__ b_fin,
+                                                       const float* __restrict__ b_aux, float* __restrict__ raw,
+                                                       const float* __restrict__ centre, Kinv ki,
+                                                       const float* __restrict__ box_conf, float* __restrict__ out,
+                                                       float* __restrict__ xyzds) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    float r[NH + 1];
+#pragma unroll
+    for (int o = 0; o < NH; ++o) r[o] = b_fin[o];
+    r[NH] = b_aux[0];
+    for (int sl = 0; sl < nparts; ++sl) {
+        const float* pf = part_fin + ((int64_t)sl * m_pad + i) * 16;
+        const f32x4 a = *(const f32x4*)pf, b = *(const f32x4*)(pf + 4);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            r[o] += a[o];
+            r[4 + o] += b[o];
+        }
+        if (NH == 9) r[8] += pf[8];
+        r[NH] += part_aux[(int64_t)sl * m_pad + i];
+    }
+    if (raw) {
+#pragma unroll
+        for (int o = 0; o <= NH; ++o) raw[i * (NH + 1) + o] = r[o];
+    }
+    post_person(r, NH + 1, i, centre, ki, box_conf, out, xyzds);
 }
 
 // ------------------------------------------------------------------------------------------

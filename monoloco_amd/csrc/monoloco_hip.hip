@@ -167,7 +167,8 @@ struct ml_loco {
     float* d_xr = nullptr;
     float* d_cl = nullptr;      // stereo: left centres
     int32_t* d_rowidx = nullptr;
-    float* d_part = nullptr;    // fused-head partial sums [2*hidden/256][cap_rows][16]
+    float* d_part = nullptr;    // fused-head partial sums [2*hidden/256][cap_rows][16] ...
+    float* d_part_aux = nullptr;  // ... and, behind them, the fused w_aux head's [2*hidden/256][cap_rows] (same allocation)
     int64_t cap_side = 0;
     int64_t dev_bytes = 0;
     // optional per-launch timing of the dense kernel (ml_loco_profile_*): HIP events recorded on
@@ -330,7 +331,7 @@ int free_workspace(ml_loco* h) {
     dev_free(h->d_raw);
     dev_free(h->d_rowidx);
     dev_free(h->d_part);
-    h->d_xf32 = h->d_centre = h->d_raw = h->d_part = nullptr;
+    h->d_xf32 = h->d_centre = h->d_raw = h->d_part = h->d_part_aux = nullptr;
     h->d_rowidx = nullptr;
     h->cap_rows = 0;
     return ML_OK;
@@ -349,7 +350,8 @@ int ensure_rows(ml_loco* h, int64_t rows) {
     if ((rc = dev_alloc(h, &h->d_centre, need * 2 * 4))) return rc;
     if ((rc = dev_alloc(h, &h->d_raw, need * (int64_t)h->out_f * 4))) return rc;
     if ((rc = dev_alloc(h, &h->d_rowidx, need * 4))) return rc;
-    if ((rc = dev_alloc(h, &h->d_part, (int64_t)(2 * h->hidden / 256) * need * 16 * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_part, (int64_t)(2 * h->hidden / 256) * need * 17 * 4))) return rc;
+    h->d_part_aux = h->d_part + (int64_t)(2 * h->hidden / 256) * need * 16;
     h->cap_rows = need;
     return ML_OK;
 }
@@ -609,11 +611,26 @@ struct McPass {
     int64_t m_per = 0;   // persons per pass (rows = passes * m_per)
 };
 
-int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass mc = McPass()) {
+// The caller's post-process, handed to run_network so that the mono tile path can end in ONE launch (tail_mono_kernel:
+// both head reductions + post_person) instead of head_reduce + aux_reduce + post; done says whether that happened.
+struct TailMono {
+    const float* centre;
+    mlk::Kinv ki;
+    const float* box_conf;
+    float* out;
+    float* xyzds;
+    float* raw;   // the caller's raw buffer, or null (then the raw rows never leave the registers)
+    bool done = false;
+};
+
+int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass mc = McPass(), TailMono* tail = nullptr) {
     const int64_t m_pad_all = round_up64(rows, 256);
     // (row chunking is an inference experiment knob; the batched MC-dropout passes index their masks by global row)
     const int64_t chunk = (chunk_rows_env() > 0 && mc.p <= 0.f) ? chunk_rows_env() : m_pad_all;
     const bool small = use_small_path(h->precision, rows);  // decided on the whole call, not per chunk
+    const bool defer = tail && chunk == m_pad_all;   // head reductions wait for the end of the (single) chunk
+    const Head *def_fin = nullptr, *def_aux = nullptr;
+    const int nparts = 2 * h->hidden / 256;
     if (h->precision == ML_PREC_BF16) {
         // the pre-process kernels write fp16 hi|lo lines; the bf16 comparison mode re-rounds them once (hi + lo -> one
         // bf16 in the hi slot, 16 B per row chunk; 17 MB at 65536 rows -- < 0.5 % of a step, counted in its time)
@@ -656,8 +673,8 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                 p.head_part = h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16;
             }
             // the one-output w_aux head rides in the store epilogue of the layer that produces its input (w4 kernel:
-            // residual+relu layer when w3*w2 are merged, the plain w2 layer otherwise); its partials share d_part, which
-            // the w_fin head of a LATER launch overwrites only after aux_reduce_kernel has consumed them (stream order)
+            // residual+relu layer when w3*w2 are merged, the plain w2 layer otherwise); its partials have their own region
+            // behind the w_fin head's
             const Head* fused_aux = nullptr;
             if (!fused && !small && mc.p <= 0.f && !dense_debug_bits() && dense_variant() != 1 && w4_runs(L.kpad, 0) &&
                 ((L.relu && L.res >= 0) || (!L.relu && L.res < 0)))
@@ -665,7 +682,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                     if (hd.after_layer == (int)li && hd.nh == 1 && hd.src == L.dst) fused_aux = &hd;
             if (fused_aux) {
                 p.head_w = fused_aux->d_w;
-                p.head_part = h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16;
+                p.head_part = h->d_part_aux + r0 * (int64_t)nparts;
             }
             const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
             if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
@@ -676,16 +693,18 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                 h->ev_layer[h->ev_used] = (int)li;
                 h->ev_used++;
             }
-            if (fused && rows_here > 0) {
+            if (fused && rows_here > 0 && defer) def_fin = fused;
+            else if (fused && rows_here > 0) {
                 hipLaunchKernelGGL(mlk::head_reduce_kernel, dim3((unsigned)((rows_here * 16 + 255) / 256)), dim3(256), 0, st,
                                    (const float*)(h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16), 2 * h->hidden / 256, m_pad,
                                    rows_here, fused->nh,
                                    (const float*)fused->d_b, raw_out + r0 * h->out_f, h->out_f, fused->col0);
                 HIP_TRY(hipGetLastError());
             }
-            if (fused_aux && rows_here > 0) {
+            if (fused_aux && rows_here > 0 && defer) def_aux = fused_aux;
+            else if (fused_aux && rows_here > 0) {
                 hipLaunchKernelGGL(mlk::aux_reduce_kernel, dim3((unsigned)((rows_here + 255) / 256)), dim3(256), 0, st,
-                                   (const float*)(h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16), 2 * h->hidden / 256, m_pad,
+                                   (const float*)(h->d_part_aux + r0 * (int64_t)nparts), nparts, m_pad,
                                    rows_here, (const float*)fused_aux->d_b, raw_out + r0 * h->out_f, h->out_f, fused_aux->col0);
                 HIP_TRY(hipGetLastError());
             }
@@ -717,8 +736,17 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                         hp.col0[k] = hd.col0;
                         ++k;
                     }
-                    hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden,
-                                       raw_out + r0 * h->out_f, h->out_f, rows_here);
+                    // (a mono forward of a single image ends here: the post-process rides in the same launch)
+                    const bool with_post = defer && h->out_f <= 16 && hp.col0[0] + hp.nh[0] <= 16 && hp.col0[1] + hp.nh[1] <= 16;
+                    if (with_post) {
+                        hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden, tail->raw,
+                                           h->out_f, rows_here, tail->centre, tail->ki, tail->box_conf, tail->out, tail->xyzds);
+                        tail->done = true;
+                    } else {
+                        hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden,
+                                           raw_out + r0 * h->out_f, h->out_f, rows_here, (const float*)nullptr, mlk::Kinv{},
+                                           (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                    }
                     HIP_TRY(hipGetLastError());
                 }
             } else if (rows_here > 0) {
@@ -730,6 +758,30 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                     }
             }
         }
+    }
+    if (defer && rows > 0) {
+        const bool fuse_tail = def_fin && def_aux && def_fin->col0 == 0 && def_aux->col0 == def_fin->nh && h->out_f == def_fin->nh + 1 &&
+                               (def_fin->nh == 8 || def_fin->nh == 9);
+        const dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+        if (fuse_tail) {
+            if (def_fin->nh == 8)
+                hipLaunchKernelGGL(mlk::tail_mono_kernel<8>, grid, block, 0, st, (const float*)h->d_part, (const float*)h->d_part_aux, nparts,
+                                   m_pad_all, rows, (const float*)def_fin->d_b, (const float*)def_aux->d_b, tail->raw, tail->centre, tail->ki,
+                                   tail->box_conf, tail->out, tail->xyzds);
+            else
+                hipLaunchKernelGGL(mlk::tail_mono_kernel<9>, grid, block, 0, st, (const float*)h->d_part, (const float*)h->d_part_aux, nparts,
+                                   m_pad_all, rows, (const float*)def_fin->d_b, (const float*)def_aux->d_b, tail->raw, tail->centre, tail->ki,
+                                   tail->box_conf, tail->out, tail->xyzds);
+            tail->done = true;
+        } else {   // only one of the heads was fused into a dense epilogue: the ordinary reductions, the caller post-processes
+            if (def_fin)
+                hipLaunchKernelGGL(mlk::head_reduce_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), block, 0, st, (const float*)h->d_part,
+                                   nparts, m_pad_all, rows, def_fin->nh, (const float*)def_fin->d_b, raw_out, h->out_f, def_fin->col0);
+            if (def_aux)
+                hipLaunchKernelGGL(mlk::aux_reduce_kernel, grid, block, 0, st, (const float*)h->d_part_aux, nparts, m_pad_all, rows,
+                                   (const float*)def_aux->d_b, raw_out, h->out_f, def_aux->col0);
+        }
+        HIP_TRY(hipGetLastError());
     }
     return ML_OK;
 }
@@ -1146,9 +1198,11 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
                        (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, use_small_path(h->precision, m) ? round_up64(m, 32) : m_pad, 0);
     HIP_TRY(hipGetLastError());
     float* raw = raw_dev ? raw_dev : h->d_raw;
-    if ((rc = run_network(h, m, raw, st))) return rc;
-    hipLaunchKernelGGL(mlk::post_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, raw, h->out_f,
-                       (const int32_t*)nullptr, m, h->d_centre, ki, box_conf_dev, out_dev, xyzds_dev);
+    TailMono tail{h->d_centre, ki, box_conf_dev, out_dev, xyzds_dev, raw_dev};
+    if ((rc = run_network(h, m, raw, st, McPass(), &tail))) return rc;
+    if (!tail.done)
+        hipLaunchKernelGGL(mlk::post_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, raw, h->out_f,
+                           (const int32_t*)nullptr, m, h->d_centre, ki, box_conf_dev, out_dev, xyzds_dev);
     HIP_TRY(hipGetLastError());
     return ML_OK;
 }
