@@ -1,6 +1,8 @@
 // train_kernels.h -- device kernels of the training step (reference monoloco/train/trainer.py:150-161,
-// losses.py:46-142, network/architectures.py:48-102 in train mode).  Everything is fp32 with exact-fp32
-// MFMA (v_mfma_f32_32x32x2_f32 == an fmaf chain), reductions accumulate in fp64.
+// losses.py:46-142, network/architectures.py:48-102 in train mode).  All tensors are fp32, reductions accumulate in
+// fp64.  GEMMs: sgemm_kernel (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32 == an fmaf chain) for every shape; for large batches
+// the hidden x hidden products run on the inference path's 3-product fp16 MFMA kernel instead (dense_kernel_w4.h) and this
+// file supplies what feeds it: device-side weight packing, line / transposed-line writers, and the narrow-layer kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
