@@ -79,6 +79,14 @@ __global__ __launch_bounds__(SMALL_THREADS) void dense_small_kernel(DenseParams 
             }
         }
     };
+    // the residual of the finishing wave is requested first: its latency hides behind the operand stream instead of
+    // standing alone behind the reduction (res may alias y: same thread, read long before the write)
+    const size_t yoff = (size_t)(m0 + r) * ((size_t)p.N * 4) + (size_t)(n0 >> 5) * LINE + (size_t)((n0 & 16) + 4 * q) * 2;
+    half4 rh, rl;
+    if (RES && w == 0) {
+        rh = *(const half4*)(p.res + yoff);
+        rl = *(const half4*)(p.res + yoff + 64);
+    }
     const int nw = nl > w ? (nl - w + 3) / 4 : 0;  // lines of this wave
     const int ng = (nw + 3) / 4;
     if (ng > 0) fetch4(fa, 0);
@@ -102,12 +110,6 @@ __global__ __launch_bounds__(SMALL_THREADS) void dense_small_kernel(DenseParams 
 
     // lane holds person m0 + r, outputs n0 + 4q + e (e = 0..3): 4 consecutive fp16 of the hi half and of the
     // lo half of line n0/32 of the output row
-    const size_t yoff = (size_t)(m0 + r) * ((size_t)p.N * 4) + (size_t)(n0 >> 5) * LINE + (size_t)((n0 & 16) + 4 * q) * 2;
-    half4 rh, rl;
-    if (RES) {
-        rh = *(const half4*)(p.res + yoff);
-        rl = *(const half4*)(p.res + yoff + 64);
-    }
     half4 oh, ol;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -195,6 +197,15 @@ __global__ __launch_bounds__(SMALL_THREADS) void dense_small32_kernel(DenseParam
             }
         }
     };
+    const size_t ybase = (size_t)(m0 + r) * ((size_t)p.N * 4) + (size_t)(n0 >> 5) * LINE + (size_t)(4 * q) * 2;
+    half4 rh[4], rl[4];   // residual of the finishing wave, requested ahead of the operand stream (see dense_small_kernel)
+    if (RES && w == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            rh[g] = *(const half4*)(p.res + ybase + (size_t)(8 * g) * 2);
+            rl[g] = *(const half4*)(p.res + ybase + (size_t)(8 * g) * 2 + 64);
+        }
+    }
     const int nw = nl > w ? (nl - w + 3) / 4 : 0;  // lines of this wave
     const int ng = (nw + 1) / 2;
     if (ng > 0) fetch2(fa, 0);
@@ -216,21 +227,15 @@ __global__ __launch_bounds__(SMALL_THREADS) void dense_small32_kernel(DenseParam
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] += red[ww][e][lane];
 
-    const size_t ybase = (size_t)(m0 + r) * ((size_t)p.N * 4) + (size_t)(n0 >> 5) * LINE + (size_t)(4 * q) * 2;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const size_t yoff = ybase + (size_t)(8 * g) * 2;
-        half4 rh, rl;
-        if (RES) {
-            rh = *(const half4*)(p.res + yoff);
-            rl = *(const half4*)(p.res + yoff + 64);
-        }
         half4 oh, ol;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = acc[g * 4 + e] * p.descale;
             if (RELU) v = __builtin_fmaxf(v, 0.0f);
-            if (RES) v += (float)rh[e] + (float)rl[e];
+            if (RES) v += (float)rh[g][e] + (float)rl[g][e];
             _Float16 a, b;
             split_f16(v, a, b);
             oh[e] = a;
