@@ -291,3 +291,27 @@ def test_handles_do_not_leak_device_memory(hip_lib, cuda_device):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info(cuda_device)[0]
     assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
+
+
+def test_post_geometry_block_matches_oracle_and_strided_distances(hip_lib, cuda_device):
+    """ml_post_geometry(_strided): the per-person geometry of Loco.post_process (reference net.py:195-215) against the
+    oracle's get_keypoints / pixel_to_camera / xyz_from_distance; distances read from a column of a packed (m, 16) block
+    (what Loco.forward does) give the same bits as a contiguous vector."""
+    from monoloco_amd import engine
+    m = 300
+    kps = torch.tensor(synth.make_keypoints(m, seed=9))
+    d = torch.rand(m) * 40 + 0.5
+    geo = engine.post_geometry(kps.to(cuda_device), synth.KITTI_K, d.to(cuda_device), device=cuda_device).cpu()
+    packed = torch.zeros((m, 16), device=cuda_device)
+    packed[:, 3] = d.to(cuda_device)
+    out = torch.empty((m, 12), device=cuda_device)
+    geo2 = engine.post_geometry(kps.to(cuda_device), synth.KITTI_K, packed[:, 3], device=cuda_device, out=out)
+    assert geo2 is out and torch.equal(geo2.cpu(), geo)
+    for col, mode in ((0, 'shoulder'), (2, 'head'), (4, 'center')):
+        ref = O.get_keypoints(kps, mode)
+        assert (geo[:, col:col + 2] - ref).abs().max() <= 1e-4, mode      # pixels (values up to ~1200)
+    xy = O.pixel_to_camera(O.get_keypoints(kps, 'center'), synth.KITTI_K, 1)
+    assert (geo[:, 6:9] - xy).abs().max() <= 1e-6
+    xyz = O.xyz_from_distance(d.view(-1, 1), xy)
+    assert (geo[:, 9:12] - xyz).abs().max() <= 1e-4 * 40
+    assert engine.post_geometry(kps[:0].to(cuda_device), synth.KITTI_K, None, device=cuda_device).shape == (0, 12)
