@@ -309,7 +309,7 @@ def test_post_geometry_block_matches_oracle_and_strided_distances(hip_lib, cuda_
     assert geo2 is out and torch.equal(geo2.cpu(), geo)
     for col, mode in ((0, 'shoulder'), (2, 'head'), (4, 'center')):
         ref = O.get_keypoints(kps, mode)
-        assert (geo[:, col:col + 2] - ref).abs().max() <= 1e-4, mode      # pixels (values up to ~1200)
+        assert (geo[:, col:col + 2] - ref).abs().max() <= 3e-4, mode      # pixels up to ~1200: 1-2 ulp of a 5-joint mean
     xy = O.pixel_to_camera(O.get_keypoints(kps, 'center'), synth.KITTI_K, 1)
     assert (geo[:, 6:9] - xy).abs().max() <= 1e-6
     xyz = O.xyz_from_distance(d.view(-1, 1), xy)
