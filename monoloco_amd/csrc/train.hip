@@ -180,8 +180,9 @@ int col_stats(ml_trainer* t, hipStream_t st, const float* z, const float* w2, in
     return 0;
 }
 
-// ---- skinny products (input layer, output heads) on their own kernels (train_kernels.h); callers check skinny_ok
-bool skinny_ok(const ml_trainer* t, int nc) { return t->H % 256 == 0 && nc >= 1 && nc <= mlt::SK_NC; }
+// ---- skinny products (input layer, output heads) on their own kernels (train_kernels.h) at every batch size; callers
+// check skinny_ok (64-column workgroups)
+bool skinny_ok(const ml_trainer* t, int nc) { return t->H % 64 == 0 && nc >= 1 && nc <= mlt::SK_NC; }
 
 int skinny_out(ml_trainer* t, hipStream_t st, const float* s, int lds, int nc, const float* w, int64_t wsc, int64_t wsj,
                const float* bias, float* out, int64_t m, int accumulate) {
@@ -209,7 +210,7 @@ int skinny_dw(ml_trainer* t, hipStream_t st, const float* s, int lds, int nc, co
 
 // out[i][c] = x[i] . w[c] + b[c], c < nc in {1, 8, 9}; false: no kernel for this shape (the caller takes the GEMM)
 bool skinny_heads(ml_trainer* t, hipStream_t st, const float* x, int64_t m, const float* w, const float* b, int nc, float* out, int ldo) {
-    if (t->H % 256 != 0 || (int64_t)nc * t->H > 15360) return false;
+    if (t->H % 4 != 0 || (int64_t)nc * t->H > 15360) return false;
     int64_t g = (m + 3) / 4;
     if (g > 2048) g = 2048;
     const dim3 grid((unsigned)g), block(256);
@@ -336,7 +337,7 @@ int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* r
     const int H = t->H;
     int rc;
     if (x_lines && slot >= 0) rc = fast_linear_fwd(t, st, x_lines, b.lin, b.z, m, slot);
-    else if (y_lines && b.in_dim != H && skinny_ok(t, b.in_dim))   // the input layer of a fast-path step
+    else if (b.in_dim != H && skinny_ok(t, b.in_dim))   // the (narrow) input layer
         rc = skinny_out(t, st, b.x, b.in_dim, b.in_dim, P(t, b.lin + ".weight"), 1, b.in_dim, P(t, b.lin + ".bias"), b.z, m, 0);
     else rc = linear_fwd(t, st, b.x, b.in_dim, P(t, b.lin + ".weight"), P(t, b.lin + ".bias"), b.z, H, (int)m, H, b.in_dim);
     if (rc) return rc;
@@ -371,7 +372,7 @@ int next_red_slot(ml_trainer* t, hipStream_t st) {
 }
 
 // slot >= 0: the Linear is an H x H one on the fast path: dz also goes to lbufs[0] / tl_dz as scaled lines, dW runs there;
-// slot == -2: the (narrow) input layer of a fast-path step
+// slot == -2: the (narrow) input layer
 int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, float* xhat, int slot = -1) {
     const int H = t->H;
     float* mean = t->bn_mean + (size_t)b.bn_idx * H;
@@ -402,7 +403,7 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
             fast_grad_lines(t, st, dout, m, slot);
             return fast_linear_bwd_weight(t, st, b.x, b.lin, m, slot);
         }
-        if (slot == -2 && skinny_ok(t, b.in_dim))   // the input layer of a fast-path step: dW1 (H x in) = dz^T . x
+        if (slot == -2 && skinny_ok(t, b.in_dim))   // the input layer: dW1 (H x in) = dz^T . x
             return skinny_dw(t, st, b.x, b.in_dim, b.in_dim, dout, m, G(t, b.lin + ".weight"), 1);
         return linear_bwd_weight(t, st, dout, H, b.x, b.in_dim, G(t, b.lin + ".weight"), (int)m, H, b.in_dim);
     }
@@ -624,12 +625,13 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         if ((rc = fast_linear_fwd(t, st, la(S), "w2", y2, m, 2 * S))) return rc;
         hipLaunchKernelGGL(mlt::act_lines_kernel, dim3(nblk(m * H / 8)), dim3(256), 0, st, (const float*)y2, m, H, ly2);
     } else if ((rc = linear_fwd(t, st, a[S], H, P(t, "w2.weight"), P(t, "w2.bias"), y2, H, (int)m, H, H))) return rc;
-    if (!(fast && skinny_heads(t, st, y2, m, P(t, "w_aux.weight"), P(t, "w_aux.bias"), 1, t->d_out + (C - 1), C)))
+    const bool skinny = skinny_ok(t, C - 1);
+    if (!(skinny && skinny_heads(t, st, y2, m, P(t, "w_aux.weight"), P(t, "w_aux.bias"), 1, t->d_out + (C - 1), C)))
         if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
     Block b3;
     b3.lin = "w3"; b3.bn = "batch_norm3"; b3.bn_idx = 2 * S + 1; b3.in_dim = H; b3.x = y2; b3.z = z3; b3.y = y3; b3.site = 2 * S + 1;
     if ((rc = block_fwd(t, st, b3, m, nullptr, ly2, nullptr, fast ? 2 * S + 1 : -1))) return rc;
-    if (!(fast && skinny_heads(t, st, y3, m, P(t, "w_fin.weight"), P(t, "w_fin.bias"), C - 1, t->d_out, C)))
+    if (!(skinny && skinny_heads(t, st, y3, m, P(t, "w_fin.weight"), P(t, "w_fin.bias"), C - 1, t->d_out, C)))
         if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
     if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
     // ---------------- loss and its gradient
@@ -646,7 +648,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)t->d_red, C - 1, G(t, "w_fin.bias"));
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)(t->d_red + (C - 1)), 1,
                        G(t, "w_aux.bias"));
-    if (fast) {
+    if (skinny) {
         if ((rc = skinny_dw(t, st, t->d_dout, C, C - 1, y3, m, G(t, "w_fin.weight"), 0))) return rc;
         rc = skinny_out(t, st, t->d_dout, C, C - 1, P(t, "w_fin.weight"), H, 1, nullptr, gA, m, 0);
     } else {
@@ -661,7 +663,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     if (fast) rc = fast_linear_bwd_data(t, st, dzl, "w3", gB, m, 2 * S + 1, false);
     else rc = linear_bwd_data(t, st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0);                          // gB = dy2
     if (rc) return rc;
-    if (fast) {
+    if (skinny) {
         if ((rc = skinny_dw(t, st, t->d_dout + (C - 1), C, 1, y2, m, G(t, "w_aux.weight"), 0))) return rc;
         rc = skinny_out(t, st, t->d_dout + (C - 1), C, 1, P(t, "w_aux.weight"), H, 1, nullptr, gB, m, 1);
     } else {
@@ -698,7 +700,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         else rc = linear_bwd_data(t, st, gB, H, P(t, sa[s].lin + ".weight"), gA, H, (int)m, H, H, 1);            // da_s += ...
         if (rc) return rc;
     }
-    if ((rc = block_bwd(t, st, b0, m, gA, xhat, fast ? -2 : -1))) return rc;
+    if ((rc = block_bwd(t, st, b0, m, gA, xhat, -2))) return rc;
     // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)
     {
         double* d_ss = t->d_red + 2 * H + 16;  // pre-zeroed, never shared with d_loss (other offset)
