@@ -151,6 +151,74 @@ def timed_steps(step, steps, warmup, world, device, begin=None, end=None):
     return dt, extra
 
 
+def power_probe(step, dev, seconds=1.5):
+    """Board power and shader clock while the timed workload keeps running (after the timed region; librocm_smi64 through
+    ctypes, one sample every ~20 ms from a side thread).  Returns a dict for roofline.power, or None when the SMI library is
+    not usable.  Evidence for what bounds the dense kernels: see profiles/r02_ablation.md section 2."""
+    import ctypes
+    import threading
+    import torch
+    try:
+        smi = ctypes.CDLL('librocm_smi64.so')
+    except OSError:
+        try:
+            smi = ctypes.CDLL('/opt/rocm/lib/librocm_smi64.so')
+        except OSError:
+            return None
+
+    class Freqs(ctypes.Structure):
+        _fields_ = [('has_deep_sleep', ctypes.c_bool), ('num_supported', ctypes.c_uint32), ('current', ctypes.c_uint32),
+                    ('frequency', ctypes.c_uint64 * 33)]
+    try:
+        if smi.rsmi_init(ctypes.c_uint64(0)) != 0:
+            return None
+        idx = ctypes.c_uint32(dev.index or 0)
+        cap = ctypes.c_uint64(0)
+        if smi.rsmi_dev_power_cap_get(idx, ctypes.c_uint32(0), ctypes.byref(cap)) != 0:
+            cap = ctypes.c_uint64(0)
+        watts, mhz = [], []
+        stop = threading.Event()
+
+        def sample():
+            pw = ctypes.c_uint64(0)
+            fr = Freqs()
+            while not stop.is_set():
+                if smi.rsmi_dev_current_socket_power_get(idx, ctypes.byref(pw)) == 0:
+                    watts.append(pw.value / 1e6)
+                if smi.rsmi_dev_gpu_clk_freq_get(idx, ctypes.c_int(0), ctypes.byref(fr)) == 0 and fr.current < 33:
+                    f = fr.frequency[fr.current] / 1e6
+                    if 50.0 < f < 4000.0:
+                        mhz.append(f)
+                time.sleep(0.02)
+        th = threading.Thread(target=sample, daemon=True)
+        t_end = time.perf_counter() + seconds
+        for _ in range(20):     # get the chip to its steady operating point before sampling
+            step()
+        torch.cuda.synchronize(dev)
+        th.start()
+        n = 0
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(dev)
+            n += 10
+        stop.set()
+        th.join(timeout=2.0)
+        smi.rsmi_shut_down()
+        if not watts:
+            return None
+        watts.sort()
+        out = {"socket_power_w_median": round(watts[len(watts) // 2], 1), "socket_power_w_max": round(watts[-1], 1),
+               "power_cap_w": round(cap.value / 1e6, 1) if cap.value else None, "samples": len(watts), "steps_while_sampling": n,
+               "note": "rocm_smi while the same steps keep running right after the timed region"}
+        if mhz:
+            mhz.sort()
+            out["sclk_mhz_median"] = round(mhz[len(mhz) // 2], 0)
+        return out
+    except Exception as e:  # measurement garnish: never fail the bench line over it
+        return {"error": repr(e)[:200]}
+
+
 def _ms(fn, iters, warmup, dev):
     """Wall-clock ms per call of an asynchronous device call: warm-up, sync, `iters` calls, sync."""
     import torch
@@ -457,6 +525,10 @@ def main():
                         "time on rank 0 (HIP events on the launch stream); executed MFMA FLOP are %sx higher"
                         % (FLOP_PER_ROW[args.workload], "~2.6" if args.precision == 'f16x2' else "~0.88"),
             }
+        if world == 1 and "roofline" in line:
+            pw = power_probe(step, dev)
+            if pw is not None:
+                line["roofline"]["power"] = pw
         if args.workload == 'mono':
             line["parity"] = parity_of_timed_run(sd, kps, conf, xyzds, raw, kk)
         if world == 1 and args.workload == 'mono' and not args.no_extra:
