@@ -112,7 +112,7 @@ def test_extract_outputs_matches_oracle(hip_lib, cuda_device):
     assert ((out[:, 2] - zref)[both].abs() / amp).max() <= 5e-5
     assert (out[:, C['yaw']] - ref['yaw'][0][:, 0]).abs().max() <= 2e-6
     assert (out[:, C['aux']] - ref['aux'][:, 0]).abs().max() <= 2e-6
-    assert (out[:, 8:11] - raw[:, 4:7]).abs().max() == 0
+    assert (out[:, 8:11] - torch.as_tensor(raw[:, 4:7])).abs().max() == 0
     assert (xyzds[:, 0:3] - xyz).abs().max() <= 1e-5
     assert ((out[:, C['conf']] - cf).abs() / cf.abs().clamp_min(1e-6)).max() <= 1e-5
     ego = out[:, C['yaw_ego']][both]
