@@ -223,6 +223,13 @@ int ml_trainer_get_grad(ml_trainer* t, const char* key, float* host_data, int64_
  * Synchronises the stream before returning (the reference syncs with .item() too). */
 int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m,
                     int update, double* losses_host, float* raw_out_dev, void* stream);
+/* AutoTuneMultiTaskLoss (train/losses.py:17-43, selected by `--auto_tune_mtl`, trainer.py:95-96): every task loss is divided by
+ * 2 exp(log_sigma)^2 and the log_sigmas are added to the total; the eight log_sigmas (d, x, y, h, w, l, ori, aux; zero at
+ * creation) are optimised by the same Adam and schedule, unclipped, and are not part of the state_dict.  With it on,
+ * ml_trainer_step reports the weighted task values and the total including the log_sigmas. */
+int ml_trainer_set_auto_tune(ml_trainer* t, int enable);
+int ml_trainer_get_log_sigmas(ml_trainer* t, float* host8);
+int ml_trainer_set_log_sigmas(ml_trainer* t, const float* host8);
 int64_t ml_trainer_num_steps(const ml_trainer* t);
 int ml_trainer_destroy(ml_trainer* t);
 const char* ml_train_last_error(void);

@@ -80,6 +80,13 @@ struct ml_trainer {
     int ks = 1;                                       // split of the batch reduction of the fast weight-gradient GEMM
     float* zero_bias = nullptr;                       // H zeros (the data-gradient GEMMs have no bias)
     int n_cu = 256;
+    // AutoTuneMultiTaskLoss (reference losses.py:17-43, trainer.py:95-96): one learnable log_sigma per task, optimised by
+    // the same Adam (same lr schedule, NOT clipped: clip_grad_norm_ sees model.parameters() only), not part of the
+    // state_dict.  Eight scalars: kept and updated on the host, their task weights uploaded per step.
+    bool auto_tune = false;
+    float log_sigma[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ls_m1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ls_m2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float h_tw[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    float* d_tw = nullptr;
 };
 
 // rows from which the forward and data-gradient GEMMs of the H x H layers run on the 3-product fp16 MFMA kernel (0 = never); process-global,
@@ -535,7 +542,7 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (char* p : t->lbufs) (void)hipFree(p);
     for (char* p : t->wl) (void)hipFree(p);
     for (float* p : t->wbs) (void)hipFree(p);
-    void* ptrs[] = {t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    void* ptrs[] = {t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -568,6 +575,24 @@ int ml_trainer_get_grad(ml_trainer* t, const char* key, float* host_data, int64_
     return xfer(t, key, host_data, nullptr, numel, 2);
 }
 int64_t ml_trainer_num_steps(const ml_trainer* t) { return t ? t->step : 0; }
+
+int ml_trainer_set_auto_tune(ml_trainer* t, int enable) {
+    if (!t) return tfail(ML_ERR_ARG, "null trainer");
+    t->auto_tune = enable != 0;
+    return ML_OK;
+}
+
+int ml_trainer_get_log_sigmas(ml_trainer* t, float* host8) {
+    if (!t || !host8) return tfail(ML_ERR_ARG, "null argument");
+    for (int i = 0; i < 8; ++i) host8[i] = t->log_sigma[i];
+    return ML_OK;
+}
+
+int ml_trainer_set_log_sigmas(ml_trainer* t, const float* host8) {
+    if (!t || !host8) return tfail(ML_ERR_ARG, "null argument");
+    for (int i = 0; i < 8; ++i) t->log_sigma[i] = host8[i];
+    return ML_OK;
+}
 
 int ml_debug_set_train_fast_rows(int64_t rows) {
     g_train_fast_rows = rows < 0 ? 0 : rows;
@@ -637,8 +662,16 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     // ---------------- loss and its gradient
     double* d_loss = t->d_red + 2 * H;  // the tail of the current (pre-zeroed) slot
     T_TRY(hipMemsetAsync(t->d_dout, 0, (size_t)m * C * 4, st));
+    if (t->auto_tune) {
+        for (int i = 0; i < 8; ++i) {
+            const float e = std::exp(t->log_sigma[i]);
+            t->h_tw[i] = 1.0f / (2.0f * (e * e));   // lam * l / (2.0 * (log_sigma.exp() ** 2)), losses.py:34
+        }
+        if (!t->d_tw) T_TRY(hipMalloc((void**)&t->d_tw, 8 * sizeof(float)));
+        T_TRY(hipMemcpyAsync(t->d_tw, t->h_tw, 8 * sizeof(float), hipMemcpyHostToDevice, st));
+    }
     hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
-                       t->d_dout, d_loss);
+                       t->d_dout, d_loss, (const float*)(t->auto_tune ? t->d_tw : nullptr));
     double lv[16];
     T_TRY(hipMemcpyAsync(lv, d_loss, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     // ---------------- backward
@@ -702,23 +735,36 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     }
     if ((rc = block_bwd(t, st, b0, m, gA, xhat, -2))) return rc;
     // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)
+    const int64_t k = t->step + 1;
+    const float lr = t->lr0 * std::pow(t->gamma, (float)(t->step / t->sched_step));
+    const float bc1 = 1.f - std::pow(0.9f, (float)k), bc2 = 1.f - std::pow(0.999f, (float)k);
     {
         double* d_ss = t->d_red + 2 * H + 16;  // pre-zeroed, never shared with d_loss (other offset)
         hipLaunchKernelGGL(mlt::sumsq_kernel, dim3(512), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
-        const int64_t k = t->step + 1;
-        const float lr = t->lr0 * std::pow(t->gamma, (float)(t->step / t->sched_step));
-        const float bc1 = 1.f - std::pow(0.9f, (float)k), bc2 = 1.f - std::pow(0.999f, (float)k);
         hipLaunchKernelGGL(mlt::clip_adam_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
                            (const double*)d_ss, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);
         if (update) t->step++;
     }
     T_TRY(hipStreamSynchronize(st));
+    const int nt = (C == 10) ? 8 : 7;
     if (losses_host) {
         double tot = 0;
-        const int nt = (C == 10) ? 8 : 7;
-        for (int i = 0; i < nt; ++i) tot += lv[i];
+        for (int i = 0; i < 8; ++i) {
+            // auto-tune: the training-phase values are the weighted ones, the total adds the log_sigmas (losses.py:34-39)
+            const double v = (t->auto_tune && i < nt) ? (double)((float)lv[i] * t->h_tw[i]) : lv[i];
+            losses_host[1 + i] = v;
+            if (i < nt) tot += v + (t->auto_tune ? (double)t->log_sigma[i] : 0.0);
+        }
         losses_host[0] = tot;
-        for (int i = 0; i < 8; ++i) losses_host[1 + i] = lv[i];
+    }
+    if (t->auto_tune && update) {   // Adam on the log_sigmas with this step's task losses (fp32 like torch, no clipping)
+        for (int i = 0; i < nt; ++i) {
+            const float g = 1.0f - 2.0f * t->h_tw[i] * (float)lv[i];   // d/ds [ l / (2 exp(2 s)) + s ]
+            t->ls_m1[i] = 0.9f * t->ls_m1[i] + 0.1f * g;
+            t->ls_m2[i] = 0.999f * t->ls_m2[i] + 0.001f * g * g;
+            const float denom = std::sqrt(t->ls_m2[i]) / std::sqrt(bc2) + 1e-8f;
+            t->log_sigma[i] -= (lr / bc1) * (t->ls_m1[i] / denom);
+        }
     }
     return ML_OK;
 }

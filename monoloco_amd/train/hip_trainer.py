@@ -20,7 +20,8 @@ def set_fast_forward_rows(rows):
 class HipTrainer:
     """Parameters, Adam state and the training step live in the library; tensors cross by state_dict key."""
 
-    def __init__(self, state_dict, p_dropout=0.2, lr=0.002, sched_gamma=0.98, sched_step=30, seed=1, device=None):
+    def __init__(self, state_dict, p_dropout=0.2, lr=0.002, sched_gamma=0.98, sched_step=30, seed=1, device=None,
+                 auto_tune_mtl=False):
         self._h = None
         lib = _lib.load()
         self.device = _require_cuda(device)
@@ -35,6 +36,21 @@ class HipTrainer:
                                         float(lr), float(sched_gamma), int(sched_step), int(seed), ctypes.byref(h)), train=True)
             self._h = h
             self.load_state_dict(state_dict)
+        self.auto_tune_mtl = bool(auto_tune_mtl)
+        if self.auto_tune_mtl:   # AutoTuneMultiTaskLoss (reference train/losses.py:17-43)
+            check(lib.ml_trainer_set_auto_tune(self._h, 1), train=True)
+
+    @property
+    def log_sigmas(self):
+        """The learnable log_sigma per task (d, x, y, h, w, l, ori[, aux]) of the auto-tuned loss; zeros when it is off."""
+        buf = (ctypes.c_float * 8)()
+        check(_lib.load().ml_trainer_get_log_sigmas(self._h, buf), train=True)
+        return torch.tensor(list(buf)[:self.out_features - 2])
+
+    def set_log_sigmas(self, values):
+        vals = [float(v) for v in values] + [0.0] * 8
+        buf = (ctypes.c_float * 8)(*vals[:8])
+        check(_lib.load().ml_trainer_set_log_sigmas(self._h, buf), train=True)
 
     def close(self):
         if self._h is not None:

@@ -10,6 +10,7 @@ reference does, so with ``--dropout 0`` the trajectory is comparable batch by ba
 import copy
 import datetime
 import json
+import math
 import os
 import time
 from collections import defaultdict
@@ -81,8 +82,11 @@ class Trainer:
         # same construction order as the reference (trainer.py:115-123), hence the same default initialisation
         self.model = LocoModel(input_size=self.input_size[self.mode], output_size=self.output_size[self.mode],
                                linear_size=args.hidden_size, p_dropout=args.dropout, num_stage=args.n_stage)
+        # AutoTuneMultiTaskLoss instead of MultiTaskLoss (reference trainer.py:95-98)
+        self.auto_tune_mtl = bool(getattr(args, 'auto_tune_mtl', False))
         self.hip = HipTrainer(self.model.state_dict(), p_dropout=args.dropout, lr=args.lr, sched_gamma=args.sched_gamma,
-                              sched_step=int(args.sched_step), seed=args.r_seed, device=self.device)
+                              sched_step=int(args.sched_step), seed=args.r_seed, device=self.device,
+                              auto_tune_mtl=self.auto_tune_mtl)
         self.epoch_losses = defaultdict(lambda: defaultdict(list))
         self._eval_eng, self._eval_version = None, -1
 
@@ -118,11 +122,15 @@ class Trainer:
         vals['ori'] = ang.abs().mean().item() * 180 / 3.14
         norm = 1 - out[:, 2:3] / lab[:, 3:4]
         laplace = (norm.abs() * torch.exp(-out[:, 3:4]) + 0.01 + out[:, 3:4] + 2).mean().item()   # losses.py:112-131
-        total = laplace + sum(vals[t] for t in ('x', 'y', 'h', 'w', 'l')) + (out[:, 7:9] - lab[:, 7:9]).abs().mean().item()
+        train_type = [laplace] + [vals[t] for t in ('x', 'y', 'h', 'w', 'l')] + [(out[:, 7:9] - lab[:, 7:9]).abs().mean().item()]
         if 'aux' in self.tasks:
             vals['aux'] = torch.nn.functional.binary_cross_entropy_with_logits(out[:, 9:10], lab[:, 10:11]).item()
-            total += vals['aux']
-        vals['all'] = total
+            train_type.append(vals['aux'])
+        if self.auto_tune_mtl:   # losses.py:34-39: every task / (2 sigma^2), plus the log_sigmas
+            ls = self.hip.log_sigmas.tolist()
+            vals['all'] = sum(v / (2.0 * math.exp(s) ** 2) + s for v, s in zip(train_type, ls))
+        else:
+            vals['all'] = sum(train_type)
         return vals
 
     def train(self):
@@ -162,7 +170,10 @@ class Trainer:
         self.model.eval()
         dataset = KeypointsDataset(self.joints, phase='val')
         dic_err = {'val': defaultdict(lambda: defaultdict(float))}
-        dic_err['val']['sigmas'] = [0.] * len(self.tasks)
+        # the sigmas = exp(log_sigma) of the auto-tuned loss, zeros otherwise (reference trainer.py:208, 281-284, printed at
+        # :297-300; its index arithmetic there only works for stereo -- for mono it runs past the list -- so the values are
+        # taken from the loss itself here)
+        dic_err['val']['sigmas'] = [math.exp(v) for v in self.hip.log_sigmas.tolist()] if self.auto_tune_mtl else [0.] * len(self.tasks)
 
         def stats(inputs, labels, clst):
             out = self._forward_eval(inputs)

@@ -336,6 +336,51 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train_big':
     golden_train_big()
 
 
+def golden_train_autotune():
+    """Three iterations of the reference's loop body with its AutoTuneMultiTaskLoss (`--auto_tune_mtl`, losses.py:17-43,
+    trainer.py:95-96) on the mono and stereo fixtures, hidden 128, dropout 0: per step the total and the (weighted) task
+    values, the log_sigmas after every step, the first step's outputs and log_sigma gradient."""
+    import itertools
+    from monoloco.train.losses import AutoTuneMultiTaskLoss, CompositeLoss
+    g = {}
+    for mode, in_f, out_f, seed in (('mono', 34, 9, 7), ('stereo', 68, 10, 8)):
+        hidden = 128
+        dj = json.load(open(os.path.join(REF, 'tests', 'sample_joints-kitti-%s.json' % mode)))
+        x = torch.tensor(dj['train']['X'])
+        y = torch.tensor(dj['train']['Y'])
+        tasks = ('d', 'x', 'y', 'h', 'w', 'l', 'ori') + (('aux',) if mode == 'stereo' else ())
+        losses_tr, losses_val = CompositeLoss(tasks)()
+        mt = AutoTuneMultiTaskLoss(losses_tr, losses_val, (1,) * len(tasks), tasks)
+        model = LocoModel(in_f, out_f, hidden, p_dropout=0.0, device='cpu')
+        model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(seed, in_f, out_f, hidden).items()},
+                              strict=False)
+        model.train()
+        opt = torch.optim.Adam(params=itertools.chain(model.parameters(), mt.parameters()), lr=0.001)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.5)
+        for step in range(3):
+            opt.zero_grad()
+            out = model(x)
+            loss, vals = mt(out, y, phase='train')
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 3)
+            if step == 0:
+                g[mode + '_out0'] = out.detach().numpy()
+                g[mode + '_grad0_log_sigmas'] = mt.log_sigmas.grad.numpy().copy()
+                g[mode + '_grad0_w1'] = model.w1.weight.grad.numpy().copy()
+            opt.step()
+            sched.step()
+            g[mode + '_loss%d' % step] = np.array([float(loss)] + [float(v) for v in vals])
+            g[mode + '_log_sigmas%d' % step] = mt.log_sigmas.detach().numpy().copy()
+        _, vals_val = mt(model(x), y, phase='val')
+        g[mode + '_val_tail'] = np.array([float(v) for v in vals_val[len(tasks):]])     # the sigmas appended in 'val' phase
+    np.savez_compressed(os.path.join(OUT, 'golden_train_autotune.npz'), **g)
+    print('golden_train_autotune.npz %.1f KiB' % (os.path.getsize(os.path.join(OUT, 'golden_train_autotune.npz')) / 1024))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train_autotune':
+    golden_train_autotune()
+
+
 def golden_formats():
     """On-disk formats: the reference's preprocess_pifpaf on JSON texts (fixture + a synthetic x,y,w,h/'score'
     list) and the reference's save_txts (eval/generate_kitti.py:202-253) for every `net` branch on seeded

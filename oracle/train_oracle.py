@@ -42,19 +42,26 @@ def multitask_loss(out, lab):
 
 
 class OracleTrainer:
-    def __init__(self, state_dict, lr, p_dropout=0.0, sched_step=30, sched_gamma=0.98, dtype=torch.float32):
+    def __init__(self, state_dict, lr, p_dropout=0.0, sched_step=30, sched_gamma=0.98, dtype=torch.float32, auto_tune_mtl=False):
         self.params = {k: torch.as_tensor(v).to(dtype).clone().requires_grad_(True) for k, v in state_dict.items()
                        if 'running_' not in k and not k.endswith('num_batches_tracked')}
         self.run = {k: torch.as_tensor(v).to(dtype).clone() for k, v in state_dict.items() if 'running_' in k}
         self.p = p_dropout
         self.num_stage = len({k.split('.')[1] for k in state_dict if k.startswith('linear_stages.')})
-        self.opt = torch.optim.Adam(list(self.params.values()), lr=lr)
+        # AutoTuneMultiTaskLoss (reference train/losses.py:17-43): one learnable log_sigma per task, in the same optimiser
+        # (trainer.py:127-129 chains mt_loss.parameters()), outside clip_grad_norm_ (trainer.py:159: model.parameters())
+        n_tasks = 8 if self.params['w_fin.weight'].shape[0] == 9 else 7
+        self.log_sigmas = torch.zeros(n_tasks, dtype=dtype, requires_grad=True) if auto_tune_mtl else None
+        self.opt = torch.optim.Adam(list(self.params.values()) + ([self.log_sigmas] if auto_tune_mtl else []), lr=lr)
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=sched_step, gamma=sched_gamma)
 
     def step(self, x, lab, update=True):
         self.opt.zero_grad()
         out = forward_train(self.params, self.run, x, self.p, self.num_stage)
         loss, vals = multitask_loss(out, lab)
+        if self.log_sigmas is not None:
+            vals = {k: v / (2.0 * (s.exp() ** 2)) for (k, v), s in zip(vals.items(), self.log_sigmas)}
+            loss = sum(vals.values()) + self.log_sigmas.sum()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(list(self.params.values()), 3)
         if update:

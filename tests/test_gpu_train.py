@@ -93,8 +93,9 @@ def test_dropout_training_runs_and_learns(hip_lib, cuda_device):
     tr.close()
 
 
-@pytest.mark.parametrize("mode,hidden", [("mono", 256), ("stereo", 256), ("mono", 200)])
-def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path, mode, hidden):
+@pytest.mark.parametrize("mode,hidden,auto_tune", [("mono", 256, False), ("stereo", 256, False), ("mono", 200, False),
+                                                   ("stereo", 256, True)])
+def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path, mode, hidden, auto_tune):
     """The reference's test flow (tests/test_train_mono.py:42-50, test_train_stereo.py): train on the sample joints,
     save a checkpoint, load it into Loco and predict."""
     import json
@@ -120,10 +121,16 @@ def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path
     path.write_text(json.dumps(joints))
     out = str(tmp_path / 'model.pkl')
     args = argparse.Namespace(mode=mode, joints=str(path), epochs=4, no_save=False, lr=0.001, sched_step=30, sched_gamma=0.98,
-                              hidden_size=hidden, n_stage=3, r_seed=1, out=out, bs=512, dropout=0.2)
+                              hidden_size=hidden, n_stage=3, r_seed=1, out=out, bs=512, dropout=0.2, auto_tune_mtl=auto_tune)
     tr = Trainer(args)
     tr.train()
     dic_err, model = tr.evaluate()
+    sig = dic_err['val']['sigmas']
+    assert len(sig) == (7 if mode == 'mono' else 8)
+    if auto_tune:    # `--auto_tune_mtl`: the sigmas moved away from 1 (4 Adam steps of lr 1e-3 on the log_sigmas)
+        assert all(abs(v - 1.0) > 1e-3 and abs(v - 1.0) < 0.02 for v in sig), sig
+    else:
+        assert sig == [0.] * len(sig)
     assert os.path.exists(out)
     # reference trainer.py:197-246: per-task errors, bi statistics, per-cluster entries, model returned in eval mode
     all_ = dic_err['val']['all']
@@ -249,4 +256,36 @@ def test_fast_path_training_steps_match_reference(hip_lib, cuda_device, mode, in
         # the second step runs on weights after one Adam update, which is +-lr * sign(g) for every parameter at step 1:
         # gradients within rounding noise of zero flip sign between any two fp32 implementations (measured 3e-5)
         assert np.abs(got - ref).max() <= (2e-5 if step == 0 else 2e-4) * max(1.0, np.abs(ref).max()), (step, got, ref)
+    tr.close()
+
+
+@pytest.mark.parametrize("mode,in_f,out_f,seed", [('mono', 34, 9, 7), ('stereo', 68, 10, 8)])
+def test_autotune_loss_training_matches_reference(hip_lib, cuda_device, mode, in_f, out_f, seed):
+    """`--auto_tune_mtl` (reference train/losses.py:17-43, trainer.py:95-96): three iterations of the reference's loop with
+    AutoTuneMultiTaskLoss -- per step the total (incl. the log_sigmas) and the weighted task values, the log_sigmas after
+    every step (same Adam and StepLR as the weights, unclipped), first-step outputs and the w1 gradient (which carries the
+    task weights through the whole backward pass)."""
+    from monoloco_amd.train import HipTrainer
+    g = dict(np.load(os.path.join(G, 'golden_train_autotune.npz')))
+    x, y = _batch(mode)
+    sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(seed, in_f, out_f, 128).items()}
+    tr = HipTrainer(sd0, p_dropout=0.0, lr=0.001, sched_gamma=0.5, sched_step=2, device=cuda_device, auto_tune_mtl=True)
+    names = ['loss', 'd', 'x', 'y', 'h', 'w', 'l', 'ori'] + (['aux'] if mode == 'stereo' else [])
+    assert tr.log_sigmas.tolist() == [0.0] * (len(names) - 1)
+    for step in range(3):
+        if step == 0:
+            res, out = tr.step(x, y, want_outputs=True)
+            assert np.abs(out.cpu().numpy() - g[mode + '_out0']).max() <= 1e-5 * max(1.0, np.abs(g[mode + '_out0']).max())
+            ref_g = g[mode + '_grad0_w1']
+            assert np.abs(tr.grads()['w1.weight'].numpy() - ref_g).max() <= 2e-6 + 2e-4 * np.abs(ref_g).max()
+        else:
+            res = tr.step(x, y)
+        ref = g['%s_loss%d' % (mode, step)]
+        got = np.array([res[n] for n in names])
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (step, got, ref)
+        assert np.abs(tr.log_sigmas.numpy() - g['%s_log_sigmas%d' % (mode, step)]).max() <= 2e-6, step
+    # the sigmas the reference appends to the validation values (losses.py:42)
+    assert np.abs(np.exp(tr.log_sigmas.numpy()) - g[mode + '_val_tail']).max() <= 1e-5
+    tr.set_log_sigmas([0.5] * 8)
+    assert np.allclose(tr.log_sigmas.numpy(), 0.5)
     tr.close()
