@@ -140,8 +140,12 @@ class Trainer:
         for epoch in range(self.num_epochs):
             running = defaultdict(lambda: defaultdict(float))
             for inputs, labels, _, _ in self.dataloaders['train']:
-                losses = self.hip.step(inputs, labels, update=True)
-                for k, v in losses.items():
+                # the reference logs, for the training phase as well, the validation-type values of the train-mode outputs
+                # it has just back-propagated (trainer.py:163-165, epoch_logs :193-197); 'loss' (the optimised total of the
+                # step) is kept beside them
+                losses, raw = self.hip.step(inputs, labels, update=True, want_outputs=True)
+                running['train']['loss'] += losses['loss'] * inputs.size(0)
+                for k, v in self._val_losses(raw.cpu(), labels).items():
                     running['train'][k] += v * inputs.size(0)
             for inputs, labels, _, _ in self.dataloaders['val']:
                 vals = self._val_losses(self._forward_eval(inputs), labels)

@@ -145,6 +145,8 @@ def test_trainer_surface_and_checkpoint_roundtrip(hip_lib, cuda_device, tmp_path
     assert len(tr.epoch_losses['val']['all']) == 4
     losses = tr.epoch_losses['train']['loss']
     assert len(losses) == 4 and losses[-1] < losses[0]
+    # the reference's training-phase log: validation-type values of the train-mode outputs, same keys as the val phase
+    assert set(tr.epoch_losses['val']) <= set(tr.epoch_losses['train']) and len(tr.epoch_losses['train']['d']) == 4
     net = Loco(model=out, mode=mode, device=cuda_device, linear_size=hidden)
     if mode == 'mono':
         dic = net.forward(gp['mono_kps'][:8].tolist(), synth.KITTI_K)
