@@ -228,6 +228,9 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
  * creation) are optimised by the same Adam and schedule, unclipped, and are not part of the state_dict.  With it on,
  * ml_trainer_step reports the weighted task values and the total including the log_sigmas. */
 int ml_trainer_set_auto_tune(ml_trainer* t, int enable);
+/* Task weights of the multi-task loss (the reference's `Trainer.lambdas`, train/trainer.py:42, all 1 by default; order d, x, y,
+ * h, w, l, ori, aux): loss = sum lambda_i * l_i (losses.py:66); reported task values are the weighted ones. */
+int ml_trainer_set_lambdas(ml_trainer* t, const float* host8);
 int ml_trainer_get_log_sigmas(ml_trainer* t, float* host8);
 int ml_trainer_set_log_sigmas(ml_trainer* t, const float* host8);
 int64_t ml_trainer_num_steps(const ml_trainer* t);

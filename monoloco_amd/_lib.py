@@ -69,6 +69,7 @@ SIGNATURES = {
     'ml_trainer_get_tensor': (c_int, [_P, c_char_p, POINTER(c_float), c_int64]),
     'ml_trainer_get_grad': (c_int, [_P, c_char_p, POINTER(c_float), c_int64]),
     'ml_trainer_set_auto_tune': (c_int, [_P, c_int]),
+    'ml_trainer_set_lambdas': (c_int, [_P, POINTER(c_float)]),
     'ml_trainer_get_log_sigmas': (c_int, [_P, POINTER(c_float)]),
     'ml_trainer_set_log_sigmas': (c_int, [_P, POINTER(c_float)]),
     'ml_trainer_step': (c_int, [_P, _P, _P, c_int, c_int64, c_int, POINTER(c_double), _P, _P]),

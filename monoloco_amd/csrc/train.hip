@@ -84,6 +84,8 @@ struct ml_trainer {
     // the same Adam (same lr schedule, NOT clipped: clip_grad_norm_ sees model.parameters() only), not part of the
     // state_dict.  Eight scalars: kept and updated on the host, their task weights uploaded per step.
     bool auto_tune = false;
+    bool weighted = false;   // lambdas other than all 1 (the reference's Trainer.lambdas, trainer.py:42)
+    float lambdas[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     float log_sigma[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ls_m1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ls_m2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float h_tw[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     float* d_tw = nullptr;
@@ -582,6 +584,16 @@ int ml_trainer_set_auto_tune(ml_trainer* t, int enable) {
     return ML_OK;
 }
 
+int ml_trainer_set_lambdas(ml_trainer* t, const float* host8) {
+    if (!t || !host8) return tfail(ML_ERR_ARG, "null argument");
+    t->weighted = false;
+    for (int i = 0; i < 8; ++i) {
+        t->lambdas[i] = host8[i];
+        if (host8[i] != 1.0f) t->weighted = true;
+    }
+    return ML_OK;
+}
+
 int ml_trainer_get_log_sigmas(ml_trainer* t, float* host8) {
     if (!t || !host8) return tfail(ML_ERR_ARG, "null argument");
     for (int i = 0; i < 8; ++i) host8[i] = t->log_sigma[i];
@@ -662,16 +674,18 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     // ---------------- loss and its gradient
     double* d_loss = t->d_red + 2 * H;  // the tail of the current (pre-zeroed) slot
     T_TRY(hipMemsetAsync(t->d_dout, 0, (size_t)m * C * 4, st));
-    if (t->auto_tune) {
+    const bool task_weights = t->auto_tune || t->weighted;
+    if (task_weights) {
         for (int i = 0; i < 8; ++i) {
             const float e = std::exp(t->log_sigma[i]);
-            t->h_tw[i] = 1.0f / (2.0f * (e * e));   // lam * l / (2.0 * (log_sigma.exp() ** 2)), losses.py:34
+            // lam * l (losses.py:66), or lam * l / (2.0 * (log_sigma.exp() ** 2)) (losses.py:34)
+            t->h_tw[i] = t->auto_tune ? t->lambdas[i] / (2.0f * (e * e)) : t->lambdas[i];
         }
         if (!t->d_tw) T_TRY(hipMalloc((void**)&t->d_tw, 8 * sizeof(float)));
         T_TRY(hipMemcpyAsync(t->d_tw, t->h_tw, 8 * sizeof(float), hipMemcpyHostToDevice, st));
     }
     hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
-                       t->d_dout, d_loss, (const float*)(t->auto_tune ? t->d_tw : nullptr));
+                       t->d_dout, d_loss, (const float*)(task_weights ? t->d_tw : nullptr));
     double lv[16];
     T_TRY(hipMemcpyAsync(lv, d_loss, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     // ---------------- backward
@@ -751,7 +765,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         double tot = 0;
         for (int i = 0; i < 8; ++i) {
             // auto-tune: the training-phase values are the weighted ones, the total adds the log_sigmas (losses.py:34-39)
-            const double v = (t->auto_tune && i < nt) ? (double)((float)lv[i] * t->h_tw[i]) : lv[i];
+            const double v = (task_weights && i < nt) ? (double)((float)lv[i] * t->h_tw[i]) : lv[i];
             losses_host[1 + i] = v;
             if (i < nt) tot += v + (t->auto_tune ? (double)t->log_sigma[i] : 0.0);
         }

@@ -21,7 +21,7 @@ class HipTrainer:
     """Parameters, Adam state and the training step live in the library; tensors cross by state_dict key."""
 
     def __init__(self, state_dict, p_dropout=0.2, lr=0.002, sched_gamma=0.98, sched_step=30, seed=1, device=None,
-                 auto_tune_mtl=False):
+                 auto_tune_mtl=False, lambdas=None):
         self._h = None
         lib = _lib.load()
         self.device = _require_cuda(device)
@@ -39,6 +39,10 @@ class HipTrainer:
         self.auto_tune_mtl = bool(auto_tune_mtl)
         if self.auto_tune_mtl:   # AutoTuneMultiTaskLoss (reference train/losses.py:17-43)
             check(lib.ml_trainer_set_auto_tune(self._h, 1), train=True)
+        if lambdas is not None:  # task weights (reference Trainer.lambdas, trainer.py:42), order d, x, y, h, w, l, ori[, aux]
+            vals = [float(v) for v in lambdas] + [1.0] * 8
+            assert not self.auto_tune_mtl or all(v in (0.0, 1.0) for v in vals[:8]), "auto-tune needs lambdas in {0, 1} (losses.py:21)"
+            check(lib.ml_trainer_set_lambdas(self._h, (ctypes.c_float * 8)(*vals[:8])), train=True)
 
     @property
     def log_sigmas(self):

@@ -55,6 +55,7 @@ class Trainer:
     VAL_BS = 10000
     tasks = ('d', 'x', 'y', 'h', 'w', 'l', 'ori', 'aux')
     val_task = 'd'
+    lambdas = (1, 1, 1, 1, 1, 1, 1, 1)
     clusters = ['10', '20', '30', '40']
     input_size = dict(mono=34, stereo=68)
     output_size = dict(mono=9, stereo=10)
@@ -86,7 +87,7 @@ class Trainer:
         self.auto_tune_mtl = bool(getattr(args, 'auto_tune_mtl', False))
         self.hip = HipTrainer(self.model.state_dict(), p_dropout=args.dropout, lr=args.lr, sched_gamma=args.sched_gamma,
                               sched_step=int(args.sched_step), seed=args.r_seed, device=self.device,
-                              auto_tune_mtl=self.auto_tune_mtl)
+                              auto_tune_mtl=self.auto_tune_mtl, lambdas=self.lambdas[:len(self.tasks)])
         self.epoch_losses = defaultdict(lambda: defaultdict(list))
         self._eval_eng, self._eval_version = None, -1
 
@@ -126,11 +127,12 @@ class Trainer:
         if 'aux' in self.tasks:
             vals['aux'] = torch.nn.functional.binary_cross_entropy_with_logits(out[:, 9:10], lab[:, 10:11]).item()
             train_type.append(vals['aux'])
-        if self.auto_tune_mtl:   # losses.py:34-39: every task / (2 sigma^2), plus the log_sigmas
+        lam = self.lambdas[:len(train_type)]
+        if self.auto_tune_mtl:   # losses.py:34-39: every task * lambda / (2 sigma^2), plus the log_sigmas
             ls = self.hip.log_sigmas.tolist()
-            vals['all'] = sum(v / (2.0 * math.exp(s) ** 2) + s for v, s in zip(train_type, ls))
+            vals['all'] = sum(la * v / (2.0 * math.exp(s) ** 2) + s for la, v, s in zip(lam, train_type, ls))
         else:
-            vals['all'] = sum(train_type)
+            vals['all'] = sum(la * v for la, v in zip(lam, train_type))
         return vals
 
     def train(self):

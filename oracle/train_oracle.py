@@ -42,7 +42,8 @@ def multitask_loss(out, lab):
 
 
 class OracleTrainer:
-    def __init__(self, state_dict, lr, p_dropout=0.0, sched_step=30, sched_gamma=0.98, dtype=torch.float32, auto_tune_mtl=False):
+    def __init__(self, state_dict, lr, p_dropout=0.0, sched_step=30, sched_gamma=0.98, dtype=torch.float32, auto_tune_mtl=False,
+                 lambdas=None):
         self.params = {k: torch.as_tensor(v).to(dtype).clone().requires_grad_(True) for k, v in state_dict.items()
                        if 'running_' not in k and not k.endswith('num_batches_tracked')}
         self.run = {k: torch.as_tensor(v).to(dtype).clone() for k, v in state_dict.items() if 'running_' in k}
@@ -51,6 +52,7 @@ class OracleTrainer:
         # AutoTuneMultiTaskLoss (reference train/losses.py:17-43): one learnable log_sigma per task, in the same optimiser
         # (trainer.py:127-129 chains mt_loss.parameters()), outside clip_grad_norm_ (trainer.py:159: model.parameters())
         n_tasks = 8 if self.params['w_fin.weight'].shape[0] == 9 else 7
+        self.lambdas = [float(v) for v in (lambdas if lambdas is not None else [1.0] * 8)][:n_tasks]   # trainer.py:42
         self.log_sigmas = torch.zeros(n_tasks, dtype=dtype, requires_grad=True) if auto_tune_mtl else None
         self.opt = torch.optim.Adam(list(self.params.values()) + ([self.log_sigmas] if auto_tune_mtl else []), lr=lr)
         self.sched = torch.optim.lr_scheduler.StepLR(self.opt, step_size=sched_step, gamma=sched_gamma)
@@ -59,6 +61,8 @@ class OracleTrainer:
         self.opt.zero_grad()
         out = forward_train(self.params, self.run, x, self.p, self.num_stage)
         loss, vals = multitask_loss(out, lab)
+        vals = {k: lam * v for (k, v), lam in zip(vals.items(), self.lambdas)}      # losses.py:66 / :34
+        loss = sum(vals.values())
         if self.log_sigmas is not None:
             vals = {k: v / (2.0 * (s.exp() ** 2)) for (k, v), s in zip(vals.items(), self.log_sigmas)}
             loss = sum(vals.values()) + self.log_sigmas.sum()

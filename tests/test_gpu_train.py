@@ -291,3 +291,28 @@ def test_autotune_loss_training_matches_reference(hip_lib, cuda_device, mode, in
     tr.set_log_sigmas([0.5] * 8)
     assert np.allclose(tr.log_sigmas.numpy(), 0.5)
     tr.close()
+
+
+def test_task_lambdas_against_oracle(hip_lib, cuda_device):
+    """Trainer.lambdas (reference trainer.py:42, losses.py:66: loss = sum lambda_i * l_i): weighted task values, total and
+    gradients against the oracle, with and without the auto-tuned loss (lambdas in {0, 1} there, losses.py:21)."""
+    from monoloco_amd.train import HipTrainer
+    from oracle.train_oracle import OracleTrainer
+    x, y = _batch('stereo')
+    sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(13, 68, 10, 128).items()}
+    names = ['loss', 'd', 'x', 'y', 'h', 'w', 'l', 'ori', 'aux']
+    for lambdas, auto in (((1, 0.5, 2, 1, 0, 1, 3, 0.25), False), ((1, 1, 0, 1, 1, 0, 1, 1), True)):
+        tr = HipTrainer(sd0, p_dropout=0.0, lr=0.001, device=cuda_device, lambdas=lambdas, auto_tune_mtl=auto)
+        orc = OracleTrainer(sd0, lr=0.001, lambdas=lambdas, auto_tune_mtl=auto)
+        for step in range(2):
+            res = tr.step(x, y)
+            ref, _ = orc.step(x, y)
+            got = np.array([res[n] for n in names]); want = np.array([ref[n] for n in names])
+            assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (lambdas, step, got, want)
+            if step == 0:
+                g, go = tr.grads(), orc.grads()
+                for k in ('w1.weight', 'w_fin.weight', 'w_aux.weight', 'linear_stages.1.w2.weight'):
+                    assert (g[k] - go[k]).abs().max() <= 2e-6 + 2e-4 * go[k].abs().max(), (lambdas, k)
+        if auto:
+            assert np.abs(tr.log_sigmas.numpy() - orc.log_sigmas.detach().numpy()).max() <= 2e-6
+        tr.close()
