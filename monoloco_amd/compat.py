@@ -30,6 +30,7 @@ _PROCESS = ('preprocess_pifpaf', 'prepare_pif_kps', 'factory_for_gt', 'load_cali
             'extract_labels_aux', 'cluster_outputs', 'filter_outputs', 'laplace_sampling')
 _ARCH = ('LocoModel', 'MonolocoModel')
 _CAMERA = ('pixel_to_camera', 'get_keypoints', 'xyz_from_distance', 'to_cartesian', 'back_correct_angles')
+_TRAIN = ('Trainer',)   # only with install(trainer=True): `python -m monoloco.run train` then trains on the HIP step
 
 _saved = []  # (module, name, original object, existed) of everything install() re-bound
 _pairs = []  # (name, our object, the reference's object)
@@ -54,8 +55,10 @@ def _bind(mod, name, obj):
     setattr(mod, name, obj)
 
 
-def install():
-    """Re-bind the keypoint->3D path of ``monoloco`` to the MI355X implementations; returns the ``monoloco`` package."""
+def install(trainer=False):
+    """Re-bind the keypoint->3D path of ``monoloco`` to the MI355X implementations; returns the ``monoloco`` package.
+    trainer=True also re-binds ``monoloco.train.Trainer`` (run.py:153-170, train/hyp_tuning.py) to the HIP training step --
+    opt-in, because the inference path is what a caller asks for by default and the reference's Trainer also runs on CPU."""
     import importlib.util  # noqa: F401  (find_spec)
     from . import activity, formats, network, train, utils  # noqa: F401  (import everything that gets an alias)
     from .network import architectures, net, process
@@ -74,14 +77,20 @@ def install():
     import monoloco  # the reference
     ref = {key: importlib.import_module('monoloco.' + key)
            for key in ('network', 'network.net', 'network.process', 'network.architectures', 'utils', 'utils.camera')}
+    groups = [(_NET, net, 'network.net'), (_PROCESS, process, 'network.process'), (_ARCH, architectures, 'network.architectures'),
+              (_CAMERA, camera, 'utils.camera')]
+    if trainer:
+        from .train import trainer as our_trainer
+        for key in ('train', 'train.trainer'):
+            ref[key] = importlib.import_module('monoloco.' + key)
+        groups.append((_TRAIN, our_trainer, 'train.trainer'))
     new = {}
-    for names, src in ((_NET, net), (_PROCESS, process), (_ARCH, architectures), (_CAMERA, camera)):
+    for names, src, _ in groups:
         for name in names:
             if hasattr(src, name):
                 new[name] = getattr(src, name)
     originals = {}
-    for names, key in ((_NET, 'network.net'), (_PROCESS, 'network.process'), (_ARCH, 'network.architectures'),
-                       (_CAMERA, 'utils.camera')):
+    for names, _, key in groups:
         for name in names:
             if name in new and hasattr(ref[key], name):
                 originals[name] = getattr(ref[key], name)

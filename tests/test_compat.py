@@ -73,9 +73,19 @@ import json, copy
 ann = json.load(open(%r))
 boxes, kps = monoloco.network.preprocess_pifpaf(copy.deepcopy(ann), im_size=(1238, 374), enlarge_boxes=False)
 assert len(boxes) == 16 and len(kps[0]) == 3 and len(kps[0][0]) == 17
+# the reference's Trainer stays its own unless asked for
+import monoloco.train, monoloco.train.hyp_tuning, monoloco_amd.train as T
+ref_trainer = monoloco.train.Trainer
+assert ref_trainer.__module__ == 'monoloco.train.trainer'
 C.uninstall()
 assert monoloco.network.Loco is ref_loco and monoloco.predict.Loco is ref_loco
 assert monoloco.eval.generate_kitti.pixel_to_camera.__module__ == 'monoloco.utils.camera'
+# install(trainer=True): run.py:153-170 and hyp_tuning.py then construct the HIP Trainer
+C.install(trainer=True)
+assert monoloco.train.Trainer is T.Trainer and monoloco.train.trainer.Trainer is T.Trainer
+assert monoloco.train.hyp_tuning.Trainer is T.Trainer and monoloco.network.Loco is N.Loco
+C.uninstall()
+assert monoloco.train.Trainer is ref_trainer and monoloco.train.hyp_tuning.Trainer is ref_trainer
 print('ok')
 ''' % (REF, ROOT, REF, os.path.join(G, 'pifpaf_002282.json'))
     assert _run(code, str(tmp_path)).strip().endswith('ok')
