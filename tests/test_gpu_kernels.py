@@ -273,14 +273,17 @@ def test_handles_do_not_leak_device_memory(hip_lib, cuda_device):
     kinv = engine.inverse_intrinsics(synth.KITTI_K)
     x = torch.randn(400, 34, device=cuda_device)
     y = torch.randn(400, 11, device=cuda_device).abs() + 0.5
+    xb = torch.randn(4200, 34, device=cuda_device)
+    yb = torch.randn(4200, 11, device=cuda_device).abs() + 0.5
 
     def cycle():
         eng = engine.LocoEngine(sd, device=cuda_device, reserve_rows=4096)
         eng.forward_mono(kps, kinv)
         eng.epistemic_mono(kps[:64], kinv, 5)
         eng.close()
-        tr = HipTrainer(sd, p_dropout=0.2, lr=0.001, device=cuda_device)
+        tr = HipTrainer(sd, p_dropout=0.2, lr=0.001, device=cuda_device, auto_tune_mtl=True)
         tr.step(x, y)
+        tr.step(xb, yb)     # >= 4096 rows: the line / transposed-line / packed-weight buffers of the 3-product route as well
         tr.close()
 
     cycle()
