@@ -74,6 +74,10 @@ SIGNATURES = {
     'ml_trainer_set_log_sigmas': (c_int, [_P, POINTER(c_float)]),
     'ml_trainer_step': (c_int, [_P, _P, _P, c_int, c_int64, c_int, POINTER(c_double), _P, _P]),
     'ml_trainer_num_steps': (c_int64, [_P]),
+    'ml_trainer_set_route': (c_int, [_P, c_int, c_int64]),
+    'ml_trainer_last_route': (c_int, [_P]),
+    'ml_trainer_debug_read': (c_int, [_P, c_int, POINTER(c_float), c_int64]),
+    'ml_debug_tgemm': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int64, c_int, _P]),
     'ml_trainer_destroy': (c_int, [_P]),
     'ml_train_last_error': (c_char_p, []),
     'ml_pifpaf_count': (c_int, [c_char_p, c_int64, POINTER(c_int64)]),
@@ -91,7 +95,6 @@ SIGNATURES = {
     'ml_debug_num_layers': (c_int, [_P]),
     'ml_debug_set_tuning': (c_int, [c_int, c_int, c_int]),
     'ml_debug_set_tile_kernel': (c_int, [c_int]),
-    'ml_debug_set_train_fast_rows': (c_int, [c_int64]),
     'ml_debug_get_packed': (c_int, [_P, c_int, POINTER(c_uint16), c_int64]),
     'ml_debug_get_head': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_int), POINTER(c_int)]),

@@ -15,12 +15,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "train_kernels.h"
 #include "dense_kernel_w4.h"
+#include "train_mid.h"
 
 namespace {
 
@@ -48,7 +50,9 @@ struct Slot {
 
 extern "C" const char* ml_train_last_error(void) { return t_err; }
 
-constexpr int RED_SLOTS = 64;  // fp64 reduction slots per step (25 BatchNorm statistics + a few bias sums)
+// fp64 reduction slots per step: a step takes 6 S + 8 of them (2 per BatchNorm forward / backward, the bias sums); sized per
+// trainer from its num_stage, so a fresh pre-zeroed slot always exists (two reductions never share one)
+inline int red_slots_for(int num_stage) { return 6 * num_stage + 16; }
 
 struct ml_trainer {
     int in_f, H, C, S;
@@ -65,8 +69,8 @@ struct ml_trainer {
     float *d_out = nullptr, *d_dout = nullptr, *d_y2aux = nullptr;
     float *bn_mean = nullptr, *bn_invstd = nullptr;  // (nbn x H)
     double* d_red = nullptr;                          // current slot of the fp64 reduction scratch (2*H + 32 doubles)
-    double* d_red_base = nullptr;                     // RED_SLOTS slots, zeroed once per step (one memset instead of ~27)
-    int red_slot = 0;
+    double* d_red_base = nullptr;                     // red_slots slots, zeroed once per step (one memset instead of ~27)
+    int red_slot = 0, red_slots = 0;
     float* d_splitk = nullptr;                        // split-K partials of the weight-gradient GEMMs
     size_t splitk_cap = 0;                            // floats
     int nbn = 0;
@@ -90,11 +94,26 @@ struct ml_trainer {
     float log_sigma[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ls_m1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ls_m2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float h_tw[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     float* d_tw = nullptr;
+    // route selection, per handle (ml_trainer_set_route): 0 auto, 1 exact-fp32 GEMMs only, 2 mid route whenever it can run,
+    // 3 large-batch (fast) route whenever it can run.  auto: >= fast_rows rows -> fast, below -> mid, else exact.
+    int route = 0;
+    int64_t fast_rows = 4096;
+    // mid route (train_mid.h): W^T of every H x H weight, max |W| words (two sets: the one this step's GEMMs read and the one
+    // its optimizer accumulates for the next step), max |dz| words (zeroed with the reduction slots), transposed
+    // activation / gradient buffers, a pinned landing zone for the loss values
+    float* wT = nullptr;
+    float* wmaxw[2] = {nullptr, nullptr};
+    int wmax_cur = 0;
+    bool wt_dirty = true;
+    float* dzmaxw = nullptr;
+    std::vector<float*> tbufs;       // 2S + 4 buffers [H][cap]
+    bool tbufs_owned = false;
+    double* h_loss = nullptr;
+    mlt::AdamMats mats;
+    mlt::AdamSegs segs;
+    int last_route = -1;             // route the last step took (0 exact, 1 fast, 2 mid): ml_trainer_last_route
 };
 
-// rows from which the forward and data-gradient GEMMs of the H x H layers run on the 3-product fp16 MFMA kernel (0 = never); process-global,
-// ml_debug_set_train_fast_rows is the only writer
-int64_t g_train_fast_rows = 4096;
 
 namespace {
 
@@ -184,11 +203,8 @@ unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 // column sums (fp64) of z (m x n) and of z*w2 (or z*z) into t->d_red[0..n) and [n..2n)
 int col_stats(ml_trainer* t, hipStream_t st, const float* z, const float* w2, int64_t m, int n) {
     // every reduction of a step gets a fresh, pre-zeroed slot (ml_trainer_step zeroes them all with one memset)
-    if (t->red_slot + 1 < RED_SLOTS) {
-        t->d_red = t->d_red_base + (size_t)(++t->red_slot) * (2 * t->H + 32);
-    } else {
-        T_TRY(hipMemsetAsync(t->d_red, 0, (size_t)(2 * t->H + 32) * sizeof(double), st));
-    }
+    if (t->red_slot + 1 >= t->red_slots) return tfail(ML_ERR_HIP, "out of reduction slots (internal)");
+    t->d_red = t->d_red_base + (size_t)(++t->red_slot) * (2 * t->H + 32);
     int gy = (int)((m + 255) / 256);  // 16 rows per workgroup pass; enough workgroups to fill the chip, few atomics
     if (gy > 128) gy = 128;
     if (gy < 1) gy = 1;
@@ -342,8 +358,19 @@ int fast_linear_bwd_weight(ml_trainer* t, hipStream_t st, const float* x, const 
     return 0;
 }
 
-bool fast_rows(const ml_trainer* t, int64_t m) {
-    return g_train_fast_rows > 0 && m >= g_train_fast_rows && t->H % 256 == 0 && !t->lbufs.empty();
+bool fast_possible(const ml_trainer* t) { return t->H % 256 == 0 && !t->lbufs.empty(); }
+bool mid_possible(const ml_trainer* t) { return t->H % 64 == 0 && t->wT != nullptr && !t->tbufs.empty() && t->in_f <= mlt::SK_NC; }
+// 0 exact, 1 fast (large batches: 256 x 256-tile 3-product GEMMs on line-format operands), 2 mid (train_mid.h)
+int pick_route(const ml_trainer* t, int64_t m) {
+    switch (t->route) {
+        case 1: return 0;
+        case 2: return mid_possible(t) ? 2 : 0;
+        case 3: return fast_possible(t) ? 1 : 0;
+        default: break;
+    }
+    if (t->fast_rows > 0 && m >= t->fast_rows && fast_possible(t)) return 1;
+    if (mid_possible(t)) return 2;
+    return 0;
 }
 
 // x_lines: the block input as lines (or null: exact-fp32 MFMA GEMM on b.x); y_lines: where to put the block output as
@@ -378,12 +405,9 @@ int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* r
 // dout: gradient wrt the block output (m x H), overwritten with dz; xhat: scratch (m x H).  Produces the
 // parameter gradients of the block; the caller propagates dz through the Linear to the block input.
 // fresh pre-zeroed fp64 reduction slot (2 * H + 32 doubles): see col_stats
-int next_red_slot(ml_trainer* t, hipStream_t st) {
-    if (t->red_slot + 1 < RED_SLOTS) {
-        t->d_red = t->d_red_base + (size_t)(++t->red_slot) * (2 * t->H + 32);
-    } else {
-        T_TRY(hipMemsetAsync(t->d_red, 0, (size_t)(2 * t->H + 32) * sizeof(double), st));
-    }
+int next_red_slot(ml_trainer* t, hipStream_t) {
+    if (t->red_slot + 1 >= t->red_slots) return tfail(ML_ERR_HIP, "out of reduction slots (internal)");
+    t->d_red = t->d_red_base + (size_t)(++t->red_slot) * (2 * t->H + 32);
     return 0;
 }
 
@@ -481,6 +505,26 @@ int ensure_cap(ml_trainer* t, int64_t m) {
             }
         }
     }
+    // mid route: 2S + 4 transposed fp32 buffers [H][m]; where the large-batch route's line buffers exist (same size, never
+    // used by the same step) they are shared
+    if (t->tbufs_owned)
+        for (float* p : t->tbufs) (void)hipFree(p);
+    t->tbufs.clear();
+    t->tbufs_owned = false;
+    if (t->H % 64 == 0 && t->wT) {
+        if (t->H % 256 == 0) {
+            for (char* p : t->lbufs) t->tbufs.push_back((float*)p);
+            t->tbufs.push_back((float*)t->tl_dz);
+            t->tbufs.push_back((float*)t->tl_x);
+        } else {
+            t->tbufs_owned = true;
+            for (int i = 0; i < 2 * t->S + 4; ++i) {
+                float* p = nullptr;
+                T_TRY(hipMalloc((void**)&p, (size_t)m * t->H * 4));
+                t->tbufs.push_back(p);
+            }
+        }
+    }
     if (t->d_out) (void)hipFree(t->d_out);
     if (t->d_dout) (void)hipFree(t->d_dout);
     const int nb = 4 * t->S + 8;  // a_s (S+1), t_s (S), z (2S+2), y2, y3, xhat, 2 gradient buffers
@@ -493,6 +537,242 @@ int ensure_cap(ml_trainer* t, int64_t m) {
     T_TRY(hipMalloc((void**)&t->d_dout, (size_t)m * t->C * 4));
     t->cap = m;
     return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// helpers shared by the routes: task weights of the loss, the host side of a finished step
+int upload_task_weights(ml_trainer* t, hipStream_t st, bool task_weights) {
+    if (!task_weights) return 0;
+    for (int i = 0; i < 8; ++i) {
+        const float e = std::exp(t->log_sigma[i]);
+        // lam * l (losses.py:66), or lam * l / (2.0 * (log_sigma.exp() ** 2)) (losses.py:34)
+        t->h_tw[i] = t->auto_tune ? t->lambdas[i] / (2.0f * (e * e)) : t->lambdas[i];
+    }
+    if (!t->d_tw) T_TRY(hipMalloc((void**)&t->d_tw, 8 * sizeof(float)));
+    T_TRY(hipMemcpyAsync(t->d_tw, t->h_tw, 8 * sizeof(float), hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+// lv: the 8 task means of this step (already on the host).  Fills losses_host, runs the log_sigma Adam of the auto-tuned loss.
+void finish_step_host(ml_trainer* t, const double* lv, bool task_weights, int update, float lr, float bc1, float bc2,
+                      double* losses_host) {
+    const int nt = (t->C == 10) ? 8 : 7;
+    if (losses_host) {
+        double tot = 0;
+        for (int i = 0; i < 8; ++i) {
+            // auto-tune: the training-phase values are the weighted ones, the total adds the log_sigmas (losses.py:34-39)
+            const double v = (task_weights && i < nt) ? (double)((float)lv[i] * t->h_tw[i]) : lv[i];
+            losses_host[1 + i] = v;
+            if (i < nt) tot += v + (t->auto_tune ? (double)t->log_sigma[i] : 0.0);
+        }
+        losses_host[0] = tot;
+    }
+    if (t->auto_tune && update) {   // Adam on the log_sigmas with this step's task losses (fp32 like torch, no clipping)
+        for (int i = 0; i < nt; ++i) {
+            const float g = 1.0f - 2.0f * t->h_tw[i] * (float)lv[i];   // d/ds [ l / (2 exp(2 s)) + s ]
+            t->ls_m1[i] = 0.9f * t->ls_m1[i] + 0.1f * g;
+            t->ls_m2[i] = 0.999f * t->ls_m2[i] + 0.001f * g * g;
+            const float denom = std::sqrt(t->ls_m2[i]) / std::sqrt(bc2) + 1e-8f;
+            t->log_sigma[i] -= (lr / bc1) * (t->ls_m1[i] / denom);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The mid route (train_mid.h): one training step in ~57 launches.
+int launch_tgemm(ml_trainer* t, hipStream_t st, const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N,
+                 int K, const float* bias, const float* res, const float* amax, const float* bmax, float* ct, long ldct) {
+    mlt::TGemmParams p;
+    p.a = a; p.b = b; p.c = c; p.res = res; p.bias = bias; p.amax = amax; p.bmax = bmax; p.ct = ct;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldct = ldct;
+    p.M = M; p.N = N; p.K = K;
+    // 64-row tiles once they fill the chip, 32-row tiles (twice the workgroups, the K range split inside) below
+    const int tiles64 = ((M + 63) / 64) * (N / 64);
+    if (tiles64 >= t->n_cu) hipLaunchKernelGGL(mlt::tgemm_kernel<64>, dim3(N / 64, (M + 63) / 64), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(mlt::tgemm_kernel<32>, dim3(N / 64, (M + 31) / 32), dim3(256), 0, st, p);
+    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "tgemm launch failed");
+    return 0;
+}
+
+int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m, int update,
+             double* losses_host, float* raw_out_dev, hipStream_t st) {
+    const int H = t->H, S = t->S, C = t->C;
+    const long ldt = (long)((m + 31) / 32 * 32);
+    int rc;
+    // one memset: the fp64 reduction slots and, behind them, the max |dz| words
+    T_TRY(hipMemsetAsync(t->d_red_base, 0, ((size_t)t->red_slots * (2 * H + 32) + 64) * sizeof(double), st));
+    t->red_slot = 0;
+    t->d_red = t->d_red_base;
+    float* wmax = t->wmaxw[t->wmax_cur];
+    float* wmax_next = t->wmaxw[t->wmax_cur ^ 1];
+    const dim3 tgrid((unsigned)((H / 64) * (H / 64)), (unsigned)t->mats.count);
+    if (t->wt_dirty) {   // weights written through set_tensor: rebuild W^T and max |W|
+        T_TRY(hipMemsetAsync(wmax, 0, 64 * sizeof(float), st));
+        hipLaunchKernelGGL(mlt::wt_refresh_kernel, tgrid, dim3(256), 0, st, (const float*)t->w, t->mats, H, t->wT, wmax);
+        t->wt_dirty = false;
+    }
+    // buffer plan (the exact route's; + transposed copies)
+    int bi = 0;
+    auto nb = [&]() { return t->bufs[bi++]; };
+    std::vector<float*> a(S + 1), tt(S), za(S), zb(S);
+    for (auto& p : a) p = nb();
+    for (auto& p : tt) p = nb();
+    float* z0 = nb();
+    for (int s = 0; s < S; ++s) { za[s] = nb(); zb[s] = nb(); }
+    float* z3 = nb();
+    float* y2 = nb();
+    float* y3 = nb();
+    float* gE = nb();   // (the exact route's xhat scratch)
+    float* gA = nb();
+    float* gB = nb();
+    auto aT = [&](int s) { return t->tbufs[s]; };
+    auto tT = [&](int s) { return t->tbufs[S + 1 + s]; };
+    float* y2T = t->tbufs[2 * S + 1];
+    float* dzT = t->tbufs[2 * S + 2];
+    const uint32_t seed = t->seed + (uint32_t)t->step * 977u;
+    const size_t HH = (size_t)H * H;
+    auto Wt = [&](int slot) { return t->wT + (size_t)slot * HH; };
+    auto mean_of = [&](int bn_idx) { return t->bn_mean + (size_t)bn_idx * H; };
+    auto inv_of = [&](int bn_idx) { return t->bn_invstd + (size_t)bn_idx * H; };
+    const dim3 cgrid((unsigned)(H / 16)), blk(256);
+
+    // ---------------- forward (train mode)
+    auto fwd_apply = [&](const float* z, const std::string& bn, int bn_idx, uint32_t site, const float* residual, float* y, float* yT,
+                         bool input_layer) {
+        mlt::FwdApplyParams p;
+        p.z = input_layer ? nullptr : z;
+        p.x_in = input_layer ? x_dev : nullptr;
+        p.w_in = input_layer ? P(t, "w1.weight") : nullptr;
+        p.b_in = input_layer ? P(t, "w1.bias") : nullptr;
+        p.z_out = input_layer ? const_cast<float*>(z) : nullptr;
+        p.in_dim = t->in_f;
+        p.m = (long)m; p.H = H; p.ldt = ldt;
+        p.gamma = P(t, bn + ".weight"); p.beta = P(t, bn + ".bias");
+        p.run_mean = ST(t, bn + ".running_mean"); p.run_var = ST(t, bn + ".running_var");
+        p.mean_out = mean_of(bn_idx); p.invstd_out = inv_of(bn_idx);
+        p.p_drop = t->p_drop; p.seed = seed; p.site = site;
+        p.residual = residual; p.y = y; p.yT = yT;
+        p.zero_words = input_layer && update ? wmax_next : nullptr;   // the optimizer accumulates the next step's max |W| there
+        p.n_zero = 64;
+        hipLaunchKernelGGL(mlt::fwd_apply_kernel, cgrid, blk, 0, st, p);
+    };
+    // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
+    auto lin_fwd = [&](const float* x, const std::string& lin, int slot, float* z, float* zT) {
+        return launch_tgemm(t, st, x, H, P(t, lin + ".weight"), H, z, H, (int)m, H, H, P(t, lin + ".bias"), nullptr, nullptr, wmax + slot,
+                            zT, ldt);
+    };
+    fwd_apply(z0, "batch_norm1", 0, 0, nullptr, a[0], aT(0), true);
+    for (int s = 0; s < S; ++s) {
+        const std::string p = "linear_stages." + std::to_string(s) + ".";
+        if ((rc = lin_fwd(a[s], p + "w1", 2 * s, za[s], nullptr))) return rc;
+        fwd_apply(za[s], p + "batch_norm1", 1 + 2 * s, 1 + 2 * s, nullptr, tt[s], tT(s), false);
+        if ((rc = lin_fwd(tt[s], p + "w2", 2 * s + 1, zb[s], nullptr))) return rc;
+        fwd_apply(zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, a[s], a[s + 1], aT(s + 1), false);   // a_{s+1} = a_s + block(t_s)
+    }
+    if ((rc = lin_fwd(a[S], "w2", 2 * S, y2, y2T))) return rc;
+    const bool skinny = skinny_ok(t, C - 1);
+    if (!(skinny && skinny_heads(t, st, y2, m, P(t, "w_aux.weight"), P(t, "w_aux.bias"), 1, t->d_out + (C - 1), C)))
+        if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
+    if ((rc = lin_fwd(y2, "w3", 2 * S + 1, z3, nullptr))) return rc;
+    fwd_apply(z3, "batch_norm3", 2 * S + 1, 2 * S + 1, nullptr, y3, nullptr, false);
+    if (!(skinny && skinny_heads(t, st, y3, m, P(t, "w_fin.weight"), P(t, "w_fin.bias"), C - 1, t->d_out, C)))
+        if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
+    if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
+    // ---------------- loss and its gradient (loss_kernel writes every column of dout)
+    double* d_loss = t->d_red + 2 * H;
+    const bool task_weights = t->auto_tune || t->weighted;
+    if ((rc = upload_task_weights(t, st, task_weights))) return rc;
+    hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
+                       t->d_dout, d_loss, (const float*)(task_weights ? t->d_tw : nullptr));
+    T_TRY(hipMemcpyAsync(t->h_loss, d_loss, 8 * sizeof(double), hipMemcpyDeviceToHost, st));   // pinned: does not stall the host
+    // ---------------- backward (every gradient tensor is written in full: no memset of g)
+    if ((rc = col_stats(t, st, t->d_dout, nullptr, m, C))) return rc;
+    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)t->d_red, C - 1, G(t, "w_fin.bias"));
+    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)(t->d_red + (C - 1)), 1,
+                       G(t, "w_aux.bias"));
+    if (skinny) rc = skinny_dw(t, st, t->d_dout, C, C - 1, y3, m, G(t, "w_fin.weight"), 0);
+    else rc = linear_bwd_weight(t, st, t->d_dout, C, y3, H, G(t, "w_fin.weight"), (int)m, C - 1, H);
+    if (rc) return rc;
+    int word = 0;
+    // dz of one block from its incoming gradient; returns the max |dz| word the following GEMMs scale by
+    auto bwd_apply = [&](const float* dy, bool from_heads, bool aux, const float* z, const std::string& bn, int bn_idx, uint32_t site,
+                         const std::string& lin, float* dz, float* dzTp) -> float* {
+        mlt::BwdApplyParams p;
+        p.dy = from_heads ? nullptr : dy;
+        p.dout = from_heads ? t->d_dout : nullptr;
+        p.dld = C; p.nc = C - 1;
+        p.w_head = from_heads ? P(t, "w_fin.weight") : nullptr;
+        p.aux_d = aux ? t->d_dout + (C - 1) : nullptr;
+        p.aux_ld = C;
+        p.w_aux = aux ? P(t, "w_aux.weight") : nullptr;
+        p.z = z;
+        p.mean = z ? mean_of(bn_idx) : nullptr;
+        p.invstd = z ? inv_of(bn_idx) : nullptr;
+        p.gamma = z ? P(t, bn + ".weight") : nullptr;
+        p.beta = z ? P(t, bn + ".bias") : nullptr;
+        p.p_drop = t->p_drop; p.seed = seed; p.site = site;
+        p.m = (long)m; p.H = H; p.ldt = ldt;
+        p.dz = dz; p.dzT = dzTp;
+        p.dgamma = z ? G(t, bn + ".weight") : nullptr;
+        p.dbeta = z ? G(t, bn + ".bias") : nullptr;
+        p.dbias = G(t, lin + ".bias");
+        p.dzmax = t->dzmaxw + word;
+        hipLaunchKernelGGL(mlt::bwd_apply_kernel, cgrid, blk, 0, st, p);
+        return t->dzmaxw + word++;
+    };
+    // dW (H x H) = dz^T . x from the transposed copies (reduction over the batch, zero padded to ldt)
+    auto wgrad = [&](const float* xT, const std::string& lin, const float* dzw) {
+        return launch_tgemm(t, st, dzT, ldt, xT, ldt, G(t, lin + ".weight"), H, H, H, (int)ldt, nullptr, nullptr, dzw, nullptr, nullptr, 0);
+    };
+    // dx (m x H) = dz . W (+ res) through W^T
+    auto dgrad = [&](const float* dz, int slot, const float* dzw, float* dx, const float* res) {
+        return launch_tgemm(t, st, dz, H, Wt(slot), H, dx, H, (int)m, H, H, nullptr, res, dzw, wmax + slot, nullptr, 0);
+    };
+    float* dzw = bwd_apply(nullptr, true, false, z3, "batch_norm3", 2 * S + 1, 2 * S + 1, "w3", gB, dzT);          // gB = dz3
+    if ((rc = wgrad(y2T, "w3", dzw))) return rc;
+    if ((rc = dgrad(gB, 2 * S + 1, dzw, gA, nullptr))) return rc;                                                 // gA = dy2 (w3 part)
+    if (skinny) rc = skinny_dw(t, st, t->d_dout + (C - 1), C, 1, y2, m, G(t, "w_aux.weight"), 0);
+    else rc = linear_bwd_weight(t, st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H);
+    if (rc) return rc;
+    dzw = bwd_apply(gA, false, true, nullptr, "", 0, 0, "w2", gB, dzT);                                          // gB = dz2 = dy2 + daux (x) w_aux
+    if ((rc = wgrad(aT(S), "w2", dzw))) return rc;
+    if ((rc = dgrad(gB, 2 * S, dzw, gA, nullptr))) return rc;                                                    // gA = da_S
+    for (int s = S - 1; s >= 0; --s) {   // a_{s+1} = a_s + B(A(a_s))
+        const std::string p = "linear_stages." + std::to_string(s) + ".";
+        dzw = bwd_apply(gA, false, false, zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, p + "w2", gB, dzT);      // gB = dz_b
+        if ((rc = wgrad(tT(s), p + "w2", dzw))) return rc;
+        if ((rc = dgrad(gB, 2 * s + 1, dzw, gE, nullptr))) return rc;                                             // gE = d t_s
+        dzw = bwd_apply(gE, false, false, za[s], p + "batch_norm1", 1 + 2 * s, 1 + 2 * s, p + "w1", gB, dzT);      // gB = dz_a
+        if ((rc = wgrad(aT(s), p + "w1", dzw))) return rc;
+        if ((rc = dgrad(gB, 2 * s, dzw, gA, gA))) return rc;                                                      // gA = da_s = da_{s+1} + dz_a . W
+    }
+    (void)bwd_apply(gA, false, false, z0, "batch_norm1", 0, 0, "w1", gB, nullptr);                                // gB = dz0
+    if (skinny_ok(t, t->in_f)) rc = skinny_dw(t, st, x_dev, t->in_f, t->in_f, gB, m, G(t, "w1.weight"), 1);
+    else rc = linear_bwd_weight(t, st, gB, H, x_dev, t->in_f, G(t, "w1.weight"), (int)m, H, t->in_f);
+    if (rc) return rc;
+    // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)
+    const int64_t k = t->step + 1;
+    const float lr = t->lr0 * std::pow(t->gamma, (float)(t->step / t->sched_step));
+    const float bc1 = 1.f - std::pow(0.9f, (float)k), bc2 = 1.f - std::pow(0.999f, (float)k);
+    {
+        double* d_ss = t->d_red + 2 * H + 16;  // pre-zeroed, never shared with d_loss (other offset)
+        hipLaunchKernelGGL(mlt::sumsq4_kernel, dim3(1024), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
+        mlt::AdamHyper hp;
+        hp.sumsq = d_ss; hp.max_norm = 3.0f; hp.lr = lr; hp.b1 = 0.9f; hp.b2 = 0.999f; hp.eps = 1e-8f; hp.bc1 = bc1; hp.bc2 = bc2;
+        hp.do_adam = update ? 1 : 0;
+        hipLaunchKernelGGL(mlt::adam_tile_kernel, tgrid, dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->mats, H, t->wT, wmax_next, hp);
+        hipLaunchKernelGGL(mlt::adam_small_kernel, dim3(nblk(t->segs.start[t->segs.count])), dim3(256), 0, st, t->w, t->g, t->m1, t->m2,
+                           t->segs, hp);
+        if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "optimizer launch failed");
+        if (update) {
+            t->step++;
+            t->wmax_cur ^= 1;   // the words the optimizer has just filled describe the new weights
+        }
+    }
+    T_TRY(hipStreamSynchronize(st));
+    finish_step_host(t, t->h_loss, task_weights, update, lr, bc1, bc2, losses_host);
+    return ML_OK;
 }
 
 }  // namespace
@@ -531,7 +811,51 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
     T_TRY(hipMalloc((void**)&t->stat, (size_t)t->n_stat * 4));
     T_TRY(hipMalloc((void**)&t->bn_mean, (size_t)t->nbn * hidden * 4));
     T_TRY(hipMalloc((void**)&t->bn_invstd, (size_t)t->nbn * hidden * 4));
-    T_TRY(hipMalloc((void**)&t->d_red_base, (size_t)RED_SLOTS * (2 * hidden + 32) * sizeof(double)));
+    t->red_slots = red_slots_for(num_stage);
+    // (+ 64 doubles behind the slots: the per-step max |dz| words of the mid route, zeroed by the same memset)
+    T_TRY(hipMalloc((void**)&t->d_red_base, ((size_t)t->red_slots * (2 * hidden + 32) + 64) * sizeof(double)));
+    t->dzmaxw = (float*)(t->d_red_base + (size_t)t->red_slots * (2 * hidden + 32));
+    T_TRY(hipHostMalloc((void**)&t->h_loss, 16 * sizeof(double), hipHostMallocDefault));
+    {   // flat offsets of the H x H matrices by Linear slot (2s, 2s + 1 = stage s w1 / w2, 2S = w2, 2S + 1 = w3) and the
+        // segments between them (everything else), for the mid route's optimizer
+        std::vector<std::string> names;
+        for (int s = 0; s < num_stage; ++s) {
+            names.push_back("linear_stages." + std::to_string(s) + ".w1.weight");
+            names.push_back("linear_stages." + std::to_string(s) + ".w2.weight");
+        }
+        names.push_back("w2.weight");
+        names.push_back("w3.weight");
+        t->mats.count = (int)names.size();
+        std::vector<int64_t> offs;
+        for (size_t i = 0; i < names.size(); ++i) {
+            t->mats.off[i] = t->slots[names[i]].off;
+            offs.push_back(t->slots[names[i]].off);
+        }
+        std::sort(offs.begin(), offs.end());
+        const int64_t hh = (int64_t)hidden * hidden;
+        int64_t pos = 0, total = 0;
+        t->segs.count = 0;
+        auto add_seg = [&](int64_t from, int64_t to) {
+            if (to <= from) return;
+            t->segs.off[t->segs.count] = from;
+            t->segs.start[t->segs.count] = total;
+            total += to - from;
+            ++t->segs.count;
+        };
+        for (int64_t o : offs) {
+            add_seg(pos, o);
+            pos = o + hh;
+        }
+        add_seg(pos, t->n_param);
+        t->segs.start[t->segs.count] = total;
+    }
+    if (hidden % 64 == 0) {
+        T_TRY(hipMalloc((void**)&t->wT, (size_t)t->mats.count * hidden * hidden * 4));
+        for (int k = 0; k < 2; ++k) {
+            T_TRY(hipMalloc((void**)&t->wmaxw[k], 64 * sizeof(float)));
+            T_TRY(hipMemset(t->wmaxw[k], 0, 64 * sizeof(float)));
+        }
+    }
     t->d_red = t->d_red_base;
     t->splitk_cap = (size_t)32 * hidden * (hidden > in_features ? hidden : in_features);
     T_TRY(hipMalloc((void**)&t->d_splitk, t->splitk_cap * 4));
@@ -551,7 +875,10 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (char* p : t->lbufs) (void)hipFree(p);
     for (char* p : t->wl) (void)hipFree(p);
     for (float* p : t->wbs) (void)hipFree(p);
-    void* ptrs[] = {t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    if (t->tbufs_owned)
+        for (float* p : t->tbufs) (void)hipFree(p);
+    if (t->h_loss) (void)hipHostFree(t->h_loss);
+    void* ptrs[] = {t->wT, t->wmaxw[0], t->wmaxw[1], t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -570,8 +897,10 @@ static int xfer(ml_trainer* t, const char* key, float* host, const float* chost,
     float* base = what == 2 ? t->g : (it->second.is_param ? t->w : t->stat);
     if (what == 2 && !it->second.is_param) return tfail(ML_ERR_ARG, "'%s' is a buffer, it has no gradient", key);
     T_TRY(hipDeviceSynchronize());
-    if (what == 0) T_TRY(hipMemcpy(base + it->second.off, chost, (size_t)numel * 4, hipMemcpyHostToDevice));
-    else T_TRY(hipMemcpy(host, base + it->second.off, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    if (what == 0) {
+        T_TRY(hipMemcpy(base + it->second.off, chost, (size_t)numel * 4, hipMemcpyHostToDevice));
+        t->wt_dirty = true;   // W^T / max |W| of the mid route are rebuilt by the next step
+    } else T_TRY(hipMemcpy(host, base + it->second.off, (size_t)numel * 4, hipMemcpyDeviceToHost));
     return ML_OK;
 }
 int ml_trainer_set_tensor(ml_trainer* t, const char* key, const float* host_data, int64_t numel) {
@@ -613,8 +942,45 @@ int ml_trainer_set_log_sigmas(ml_trainer* t, const float* host8) {
     return ML_OK;
 }
 
-int ml_debug_set_train_fast_rows(int64_t rows) {
-    g_train_fast_rows = rows < 0 ? 0 : rows;
+int ml_trainer_set_route(ml_trainer* t, int route, int64_t fast_rows) {
+    if (!t || route < 0 || route > 3) return tfail(ML_ERR_ARG, "bad route");
+    t->route = route;
+    if (fast_rows >= 0) t->fast_rows = fast_rows;
+    return ML_OK;
+}
+
+int ml_trainer_last_route(const ml_trainer* t) { return t ? t->last_route : -1; }
+
+int ml_trainer_debug_read(ml_trainer* t, int which, float* host_data, int64_t numel) {
+    if (!t || !host_data || numel <= 0) return tfail(ML_ERR_ARG, "bad argument");
+    const float* src = nullptr;
+    int64_t cap = 0;
+    if (which >= 0 && which < (int)t->bufs.size()) { src = t->bufs[which]; cap = t->cap * t->H; }
+    else if (which >= 100 && which - 100 < (int)t->tbufs.size()) { src = t->tbufs[which - 100]; cap = t->cap * t->H; }
+    else if (which == 200) { src = t->d_out; cap = t->cap * t->C; }
+    else if (which == 201) { src = t->d_dout; cap = t->cap * t->C; }
+    else if (which >= 300 && which - 300 < t->mats.count && t->wT) { src = t->wT + (size_t)(which - 300) * t->H * t->H; cap = (int64_t)t->H * t->H; }
+    else if (which == 400 && t->wmaxw[0]) { src = t->wmaxw[t->wmax_cur]; cap = 64; }
+    else if (which == 401 && t->dzmaxw) { src = t->dzmaxw; cap = 64; }
+    if (!src || numel > cap) return tfail(ML_ERR_ARG, "no such buffer / too many elements");
+    T_TRY(hipDeviceSynchronize());
+    T_TRY(hipMemcpy(host_data, src, (size_t)numel * 4, hipMemcpyDeviceToHost));
+    return ML_OK;
+}
+
+int ml_debug_tgemm(const float* a_dev, const float* b_dev, float* c_dev, int M, int N, int K, const float* bias_dev,
+                   const float* res_dev, const float* amax_dev, const float* bmax_dev, float* ct_dev, int64_t ldct, int tile_rows,
+                   void* stream) {
+    if (!a_dev || !b_dev || !c_dev || M < 1 || N < 64 || N % 64 || K < 32 || K % 32 || (tile_rows != 32 && tile_rows != 64))
+        return tfail(ML_ERR_ARG, "bad tgemm shape");
+    mlt::TGemmParams p;
+    p.a = a_dev; p.b = b_dev; p.c = c_dev; p.res = res_dev; p.bias = bias_dev; p.amax = amax_dev; p.bmax = bmax_dev; p.ct = ct_dev;
+    p.lda = K; p.ldb = K; p.ldc = N; p.ldct = (long)ldct;
+    p.M = M; p.N = N; p.K = K;
+    hipStream_t st = (hipStream_t)stream;
+    if (tile_rows == 64) hipLaunchKernelGGL(mlt::tgemm_kernel<64>, dim3(N / 64, (M + 63) / 64), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(mlt::tgemm_kernel<32>, dim3(N / 64, (M + 31) / 32), dim3(256), 0, st, p);
+    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "tgemm launch failed");
     return ML_OK;
 }
 
@@ -626,7 +992,10 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int H = t->H, S = t->S, C = t->C;
-    T_TRY(hipMemsetAsync(t->d_red_base, 0, (size_t)RED_SLOTS * (2 * H + 32) * sizeof(double), st));
+    const int route = pick_route(t, m);
+    t->last_route = route;
+    if (route == 2) return step_mid(t, x_dev, labels_dev, label_cols, m, update, losses_host, raw_out_dev, st);
+    T_TRY(hipMemsetAsync(t->d_red_base, 0, (size_t)t->red_slots * (2 * H + 32) * sizeof(double), st));
     t->red_slot = 0;
     t->d_red = t->d_red_base;
     // buffer plan
@@ -649,7 +1018,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     b0.lin = "w1"; b0.bn = "batch_norm1"; b0.bn_idx = 0; b0.in_dim = t->in_f; b0.x = x_dev; b0.z = z0; b0.y = a[0]; b0.site = 0;
     // fast forward path: the activations that feed an H x H Linear also exist as lines (la[s] = a_s, lt[s] = t_s, ly2 = y2);
     // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
-    const bool fast = fast_rows(t, m);
+    const bool fast = route == 1;
     if (fast) T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 2) * 32, st));
     auto la = [&](int s) { return fast ? t->lbufs[s] : (char*)nullptr; };
     auto lt = [&](int s) { return fast ? t->lbufs[S + 1 + s] : (char*)nullptr; };
@@ -682,15 +1051,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     double* d_loss = t->d_red + 2 * H;  // the tail of the current (pre-zeroed) slot
     T_TRY(hipMemsetAsync(t->d_dout, 0, (size_t)m * C * 4, st));
     const bool task_weights = t->auto_tune || t->weighted;
-    if (task_weights) {
-        for (int i = 0; i < 8; ++i) {
-            const float e = std::exp(t->log_sigma[i]);
-            // lam * l (losses.py:66), or lam * l / (2.0 * (log_sigma.exp() ** 2)) (losses.py:34)
-            t->h_tw[i] = t->auto_tune ? t->lambdas[i] / (2.0f * (e * e)) : t->lambdas[i];
-        }
-        if (!t->d_tw) T_TRY(hipMalloc((void**)&t->d_tw, 8 * sizeof(float)));
-        T_TRY(hipMemcpyAsync(t->d_tw, t->h_tw, 8 * sizeof(float), hipMemcpyHostToDevice, st));
-    }
+    if ((rc = upload_task_weights(t, st, task_weights))) return rc;
     hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
                        t->d_dout, d_loss, (const float*)(task_weights ? t->d_tw : nullptr));
     double lv[16];
@@ -764,29 +1125,13 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         hipLaunchKernelGGL(mlt::sumsq_kernel, dim3(512), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
         hipLaunchKernelGGL(mlt::clip_adam_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
                            (const double*)d_ss, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);
-        if (update) t->step++;
+        if (update) {
+            t->step++;
+            t->wt_dirty = true;   // (the mid route keeps W^T and max |W| itself; after a step of another route they are stale)
+        }
     }
     T_TRY(hipStreamSynchronize(st));
-    const int nt = (C == 10) ? 8 : 7;
-    if (losses_host) {
-        double tot = 0;
-        for (int i = 0; i < 8; ++i) {
-            // auto-tune: the training-phase values are the weighted ones, the total adds the log_sigmas (losses.py:34-39)
-            const double v = (task_weights && i < nt) ? (double)((float)lv[i] * t->h_tw[i]) : lv[i];
-            losses_host[1 + i] = v;
-            if (i < nt) tot += v + (t->auto_tune ? (double)t->log_sigma[i] : 0.0);
-        }
-        losses_host[0] = tot;
-    }
-    if (t->auto_tune && update) {   // Adam on the log_sigmas with this step's task losses (fp32 like torch, no clipping)
-        for (int i = 0; i < nt; ++i) {
-            const float g = 1.0f - 2.0f * t->h_tw[i] * (float)lv[i];   // d/ds [ l / (2 exp(2 s)) + s ]
-            t->ls_m1[i] = 0.9f * t->ls_m1[i] + 0.1f * g;
-            t->ls_m2[i] = 0.999f * t->ls_m2[i] + 0.001f * g * g;
-            const float denom = std::sqrt(t->ls_m2[i]) / std::sqrt(bc2) + 1e-8f;
-            t->log_sigma[i] -= (lr / bc1) * (t->ls_m1[i] / denom);
-        }
-    }
+    finish_step_host(t, lv, task_weights, update, lr, bc1, bc2, losses_host);
     return ML_OK;
 }
 

@@ -11,17 +11,15 @@ from ..engine import _dev_f32, _ptr, _require_cuda, _stream
 TASKS = ('d', 'x', 'y', 'h', 'w', 'l', 'ori', 'aux')
 
 
-def set_fast_forward_rows(rows):
-    """Batches of at least `rows` rows run the hidden x hidden forward GEMMs on the 3-product fp16 MFMA kernel (default
-    4096, 0 = never; process-global test hook)."""
-    check(_lib.load().ml_debug_set_train_fast_rows(int(rows)), train=True)
+ROUTES = {'auto': 0, 'exact': 1, 'mid': 2, 'fast': 3}
+ROUTE_NAMES = {-1: None, 0: 'exact', 1: 'fast', 2: 'mid'}
 
 
 class HipTrainer:
     """Parameters, Adam state and the training step live in the library; tensors cross by state_dict key."""
 
     def __init__(self, state_dict, p_dropout=0.2, lr=0.002, sched_gamma=0.98, sched_step=30, seed=1, device=None,
-                 auto_tune_mtl=False, lambdas=None):
+                 auto_tune_mtl=False, lambdas=None, route='auto', fast_rows=None):
         self._h = None
         lib = _lib.load()
         self.device = _require_cuda(device)
@@ -36,6 +34,7 @@ class HipTrainer:
                                         float(lr), float(sched_gamma), int(sched_step), int(seed), ctypes.byref(h)), train=True)
             self._h = h
             self.load_state_dict(state_dict)
+        self.set_route(route, fast_rows)
         self.auto_tune_mtl = bool(auto_tune_mtl)
         if self.auto_tune_mtl:   # AutoTuneMultiTaskLoss (reference train/losses.py:17-43)
             check(lib.ml_trainer_set_auto_tune(self._h, 1), train=True)
@@ -43,6 +42,23 @@ class HipTrainer:
             vals = [float(v) for v in lambdas] + [1.0] * 8
             assert not self.auto_tune_mtl or all(v in (0.0, 1.0) for v in vals[:8]), "auto-tune needs lambdas in {0, 1} (losses.py:21)"
             check(lib.ml_trainer_set_lambdas(self._h, (ctypes.c_float * 8)(*vals[:8])), train=True)
+
+    def set_route(self, route='auto', fast_rows=None):
+        """Which GEMM route the steps of THIS trainer take (ml_trainer_set_route): 'auto' (>= fast_rows rows, default 4096:
+        the large-batch 3-product kernels; below: the mid route of csrc/train_mid.h; else exact fp32), 'exact', 'mid', 'fast'."""
+        check(_lib.load().ml_trainer_set_route(self._h, ROUTES[route], -1 if fast_rows is None else int(fast_rows)), train=True)
+
+    @property
+    def last_route(self):
+        """'exact' | 'fast' | 'mid': the route the last step took."""
+        return ROUTE_NAMES[int(_lib.load().ml_trainer_last_route(self._h))]
+
+    def debug_read(self, which, shape):
+        """Bring-up: an internal fp32 buffer (ml_trainer_debug_read) as a CPU tensor of `shape`."""
+        arr = np.empty(shape, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            check(_lib.load().ml_trainer_debug_read(self._h, int(which), fptr(arr), arr.size), train=True)
+        return torch.from_numpy(arr)
 
     @property
     def log_sigmas(self):

@@ -336,6 +336,66 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train_big':
     golden_train_big()
 
 
+def golden_train_h1024():
+    """The reference's training loop body (trainer.py:150-161) at the HEADLINE width (hidden 1024, run.py:101) on a 512-row
+    batch (the reference's default --bs, run.py:95: the HIP step's "mid" route) and a 4096-row batch (its large-batch
+    route), dropout 0, from seeded weights: first-step outputs, losses of two steps, first-step clipped gradients -- every
+    narrow tensor in full, of each 1024 x 1024 matrix every 64th row (16 x 1024 values) and the tensor's max |g|.  The same
+    run in fp64 gives the reference's own fp32 rounding noise per tensor ('_noise/<key>' = max |g32 - g64| / max |g64|), the
+    yardstick the GPU test's tolerances are set by."""
+    import itertools
+    from monoloco.train.losses import CompositeLoss, MultiTaskLoss
+    g = {}
+    mode, in_f, out_f, hidden = 'mono', 34, 9, 1024
+    dj = json.load(open(os.path.join(REF, 'tests', 'sample_joints-kitti-%s.json' % mode)))
+    for m, seed in ((512, 51), (4096, 52)):
+        tag = 'r%d' % m
+        xb, yb = synth.big_train_batch(np.asarray(dj['train']['X'], dtype=np.float32), np.asarray(dj['train']['Y'], dtype=np.float32),
+                                       m, seed)
+        tasks = ('d', 'x', 'y', 'h', 'w', 'l', 'ori')
+        grads = {}
+        for dtype in (torch.float32, torch.float64):
+            x, y = torch.tensor(xb).to(dtype), torch.tensor(yb).to(dtype)
+            losses_tr, losses_val = CompositeLoss(tasks)()
+            mt = MultiTaskLoss(losses_tr, losses_val, (1,) * len(tasks), tasks)
+            model = LocoModel(in_f, out_f, hidden, p_dropout=0.0, device='cpu')
+            model.load_state_dict({k: torch.as_tensor(v) for k, v in synth.make_state_dict(seed, in_f, out_f, hidden).items()},
+                                  strict=False)
+            model.to(dtype).train()
+            opt = torch.optim.Adam(params=itertools.chain(model.parameters(), mt.parameters()), lr=0.001)
+            for step in range(2 if dtype == torch.float32 else 1):
+                opt.zero_grad()
+                out = model(x)
+                loss, vals = mt(out, y, phase='train')
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 3)
+                if step == 0:
+                    grads[dtype] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+                    if dtype == torch.float32:
+                        g[tag + '_out0'] = out.detach().numpy()
+                    else:
+                        g[tag + '_out0_f64'] = out.detach().numpy()
+                opt.step()
+                if dtype == torch.float32:
+                    g[tag + '_loss%d' % step] = np.array([float(loss)] + [float(v) for v in vals])
+        for k, v in grads[torch.float32].items():
+            v64 = grads[torch.float64][k]
+            g[tag + '_gmax/' + k] = np.array(v64.abs().max().item())
+            g[tag + '_noise/' + k] = np.array(((v.double() - v64).abs().max() / v64.abs().max().clamp_min(1e-300)).item())
+            if v.dim() == 2 and v.shape[0] == hidden and v.shape[1] == hidden:
+                g[tag + '_grad0/' + k] = v[::64].numpy().copy()
+            else:
+                g[tag + '_grad0/' + k] = v.numpy().copy()
+        g[tag + '_rows_seed'] = np.array([m, seed])
+        print(tag, 'loss', g[tag + '_loss0'][0], 'noise: max', max(float(v) for k, v in g.items() if k.startswith(tag + '_noise/')))
+    np.savez_compressed(os.path.join(OUT, 'golden_train_h1024.npz'), **g)
+    print('golden_train_h1024.npz %.1f KiB' % (os.path.getsize(os.path.join(OUT, 'golden_train_h1024.npz')) / 1024))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train_h1024':
+    golden_train_h1024()
+
+
 def golden_train_autotune():
     """Three iterations of the reference's loop body with its AutoTuneMultiTaskLoss (`--auto_tune_mtl`, losses.py:17-43,
     trainer.py:95-96) on the mono and stereo fixtures, hidden 128, dropout 0: per step the total and the (weighted) task

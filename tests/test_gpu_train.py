@@ -169,22 +169,18 @@ def test_fast_forward_gemms_match_exact_path(hip_lib, cuda_device, mode, hidden,
     kernel (fp32 output): same losses, outputs and gradients as the exact-fp32 MFMA GEMM path to fp32 rounding class,
     including a batch that is no multiple of the 256-row tile and dropout (same device RNG on both paths)."""
     from monoloco_amd.train import HipTrainer
-    from monoloco_amd.train.hip_trainer import set_fast_forward_rows
     in_f, out_f = (34, 9) if mode == 'mono' else (68, 10)
     x, y = _big_batch(mode, m, 5)
     sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(31, in_f, out_f, hidden).items()}
     got = {}
-    try:
-        for name, rows in (('exact', 0), ('fast', 4096)):
-            set_fast_forward_rows(rows)
-            tr = HipTrainer(sd0, p_dropout=p_drop, lr=0.001, device=cuda_device, seed=3)
-            res, out = tr.step(x, y, update=False, want_outputs=True)
-            got[name] = (res, out.cpu().numpy(), {k: v.numpy() for k, v in tr.grads().items()})
-            res2 = tr.step(x, y)          # and a real update step runs
-            assert np.isfinite(res2['loss'])
-            tr.close()
-    finally:
-        set_fast_forward_rows(4096)
+    for name in ('exact', 'fast'):
+        tr = HipTrainer(sd0, p_dropout=p_drop, lr=0.001, device=cuda_device, seed=3, route=name)
+        res, out = tr.step(x, y, update=False, want_outputs=True)
+        assert tr.last_route == name
+        got[name] = (res, out.cpu().numpy(), {k: v.numpy() for k, v in tr.grads().items()})
+        res2 = tr.step(x, y)          # and a real update step runs
+        assert np.isfinite(res2['loss'])
+        tr.close()
     (r0, o0, g0), (r1, o1, g1) = got['exact'], got['fast']
     assert not np.array_equal(o0, o1), "the fast path did not run"
     assert np.abs(o0 - o1).max() <= 2e-5 * max(1.0, np.abs(o0).max()), np.abs(o0 - o1).max()
