@@ -586,7 +586,7 @@ int launch_tgemm(ml_trainer* t, hipStream_t st, const float* a, long lda, const 
     mlt::TGemmParams p;
     p.a = a; p.b = b; p.c = c; p.res = res; p.bias = bias; p.amax = amax; p.bmax = bmax; p.ct = ct;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldct = ldct;
-    p.M = M; p.N = N; p.K = K;
+    p.M = M; p.N = N; p.K = K; p.dbg = 0;
     // 64-row tiles once they fill the chip, 32-row tiles (twice the workgroups, the K range split inside) below
     const int tiles64 = ((M + 63) / 64) * (N / 64);
     if (tiles64 >= t->n_cu) hipLaunchKernelGGL(mlt::tgemm_kernel<64>, dim3(N / 64, (M + 63) / 64), dim3(256), 0, st, p);
@@ -971,12 +971,13 @@ int ml_trainer_debug_read(ml_trainer* t, int which, float* host_data, int64_t nu
 int ml_debug_tgemm(const float* a_dev, const float* b_dev, float* c_dev, int M, int N, int K, const float* bias_dev,
                    const float* res_dev, const float* amax_dev, const float* bmax_dev, float* ct_dev, int64_t ldct, int tile_rows,
                    void* stream) {
-    if (!a_dev || !b_dev || !c_dev || M < 1 || N < 64 || N % 64 || K < 32 || K % 32 || (tile_rows != 32 && tile_rows != 64))
+    if (!a_dev || !b_dev || !c_dev || M < 1 || N < 64 || N % 64 || K < 32 || K % 32 || ((tile_rows & 255) != 32 && (tile_rows & 255) != 64))
         return tfail(ML_ERR_ARG, "bad tgemm shape");
     mlt::TGemmParams p;
     p.a = a_dev; p.b = b_dev; p.c = c_dev; p.res = res_dev; p.bias = bias_dev; p.amax = amax_dev; p.bmax = bmax_dev; p.ct = ct_dev;
     p.lda = K; p.ldb = K; p.ldc = N; p.ldct = (long)ldct;
-    p.M = M; p.N = N; p.K = K;
+    p.M = M; p.N = N; p.K = K; p.dbg = tile_rows >> 8;   // (bits 8.. of tile_rows: timing ablations, see TGemmParams::dbg)
+    tile_rows &= 255;
     hipStream_t st = (hipStream_t)stream;
     if (tile_rows == 64) hipLaunchKernelGGL(mlt::tgemm_kernel<64>, dim3(N / 64, (M + 63) / 64), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(mlt::tgemm_kernel<32>, dim3(N / 64, (M + 31) / 32), dim3(256), 0, st, p);

@@ -43,6 +43,8 @@ struct TGemmParams {
     float* ct;           // optional transposed copy CT [N][ldct]; rows M .. ldct of it are written as zeros
     long lda, ldb, ldc, ldct;
     int M, N, K;         // N % 64 == 0, K % 32 == 0, any M >= 1 (rows beyond M are clamped on load, never stored)
+    int dbg;             // timing ablations (ml_debug_tgemm only; 0 in the product): 1 no loads in the loop, 2 no conversion / LDS
+                         // stores, 4 no fragment reads / MFMAs, 8 no barriers
 };
 
 // 8 consecutive fp32 -> one 16-byte chunk of fp16 hi halves and one of lo halves of (v * d), hi clamped to +-65504
@@ -162,6 +164,20 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TGemmParams p) {
     cstore(R0, 0);
     __syncthreads();
     int t = 0;
+    if (p.dbg) {   // timing ablations: the same loop with parts left out (results are garbage)
+        for (; t + 1 < nk; t += 2) {
+            if (!(p.dbg & 1)) gload(R0, t + 2 < last ? t + 2 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(p.dbg & 4)) compute(0);
+            if (!(p.dbg & 2)) cstore(R1, 1);
+            if (!(p.dbg & 8)) __syncthreads();
+            if (!(p.dbg & 1)) gload(R1, t + 3 < last ? t + 3 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(p.dbg & 4)) compute(1);
+            if (!(p.dbg & 2)) cstore(R0, 0);
+            if (!(p.dbg & 8)) __syncthreads();
+        }
+    }
     for (; t + 1 < nk; t += 2) {
         gload(R0, t + 2 < last ? t + 2 : last);
         __builtin_amdgcn_sched_barrier(0);   // the requests leave FIRST: hipcc otherwise sinks them behind the conversion

@@ -30,6 +30,30 @@ def main(db_path, out_path=None):
             lines.append("%-40s grid=(%d,%d,%d) calls=%-5d avg_ns=%-10.0f min=%-9d max=%d" % (name[:40], gx, gy, gz, n, avg, mn, mx))
     except sqlite3.Error as e:
         lines.append("(n/a: %s)" % e)
+    lines.append("")
+    lines.append("# mid-route training GEMM (tgemm) by grid: (N/64, row tiles)")
+    try:
+        for name, gx, gy, n, avg, mn, mx in cur.execute(
+                "select name, grid_x, grid_y, count(*), avg(duration), min(duration), max(duration) from kernels "
+                "where name like '%tgemm_kernel%' group by name, grid_x, grid_y").fetchall():
+            lines.append("%-40s grid=(%d,%d) calls=%-5d avg_ns=%-10.0f min=%-9d max=%d" % (name[:40], gx, gy, n, avg, mn, mx))
+    except sqlite3.Error as e:
+        lines.append("(n/a: %s)" % e)
+    # device busy fraction: summed kernel time / (last end - first start) over the second half of the trace (warm)
+    try:
+        ks = cur.execute("select start, end from kernels order by start").fetchall()
+        if len(ks) > 20:
+            half = ks[len(ks) // 2:]
+            span = half[-1][1] - half[0][0]
+            busy = sum(e - s0 for s0, e in half)
+            gaps = [half[i + 1][0] - half[i][1] for i in range(len(half) - 1)]
+            gaps.sort()
+            lines.append("")
+            lines.append("# second half of the trace: %d launches, span %.3f ms, kernel time %.3f ms (busy %.1f %%), median gap %.2f us, "
+                         "p90 gap %.2f us" % (len(half), span / 1e6, busy / 1e6, 100.0 * busy / max(span, 1), gaps[len(gaps) // 2] / 1e3,
+                                              gaps[int(len(gaps) * 0.9)] / 1e3))
+    except sqlite3.Error as e:
+        lines.append("(timeline n/a: %s)" % e)
     txt = "\n".join(lines) + "\n"
     if out_path:
         open(out_path, 'w').write(txt)
