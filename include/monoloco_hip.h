@@ -236,14 +236,16 @@ int ml_trainer_set_log_sigmas(ml_trainer* t, const float* host8);
 int64_t ml_trainer_num_steps(const ml_trainer* t);
 /* Which GEMM route a step takes, per handle (thread-compatible: nothing process-global).  route 0 = automatic: batches of at
  * least fast_rows rows (default 4096; hidden % 256 == 0) run the hidden x hidden products on the large-batch 3-product fp16
- * MFMA kernel (256 x 256 tiles, line-format operands); smaller ones (hidden % 64 == 0) take the "mid" route -- the same
- * 3-product arithmetic on 32|64 x 64 tiles with fp32 operands split on the fly, BatchNorm statistics per column owner, the
- * optimizer keeping W^T (monoloco_amd/csrc/train_mid.h): the reference's real batch sizes (run.py:95 --bs 512); anything else
- * the exact-fp32 MFMA GEMM.  route 1 = exact-fp32 only, 2 = mid whenever it can run, 3 = large-batch route whenever it can
- * run.  fast_rows < 0 leaves the threshold unchanged. */
+ * MFMA kernel (256 x 256 tiles, line-format operands); smaller ones (hidden % 64 == 0) take the "mid" route -- exact-fp32
+ * MFMA GEMMs on 32 x 64 tiles that read the row-major tensors as they lie (weight and data gradients included), BatchNorm
+ * statistics per column owner, ~57 launches per step (monoloco_amd/csrc/train_mid.h): the reference's real batch sizes
+ * (run.py:95 --bs 512); anything else the generic exact-fp32 GEMM.  route 1 = generic exact-fp32 only, 2 = mid whenever it can
+ * run, 3 = large-batch route whenever it can run.  fast_rows < 0 leaves the threshold unchanged. */
 int ml_trainer_set_route(ml_trainer* t, int route, int64_t fast_rows);
 /* route of the last ml_trainer_step: 0 exact, 1 large-batch, 2 mid (-1: no step yet) */
 int ml_trainer_last_route(const ml_trainer* t);
+/* Columns per workgroup of the mid route's column-owner kernels (4, 8 or 16; default 8): per-handle tuning, same results. */
+int ml_trainer_set_tuning(ml_trainer* t, int apply_cols);
 int ml_trainer_destroy(ml_trainer* t);
 const char* ml_train_last_error(void);
 
@@ -307,15 +309,15 @@ int ml_debug_set_tuning(int small_rows, int small32_rows, int chunk_rows);
 int ml_debug_set_tile_kernel(int which);
 /* Training, bring-up: copy an internal fp32 buffer of the trainer to the host (after a device sync).  which: 0 .. 4S+7 the
  * (rows x hidden) activation / gradient buffers in allocation order (a_0..a_S, t_0.., z0, (za, zb)_s, z3, y2, y3, scratch,
- * gA, gB), 100 + i the transposed buffers, 200 / 201 the raw outputs / their gradient, 300 + slot a W^T image, 400 / 401 the
- * max |W| / max |dz| words. */
+ * gA, gB), 200 / 201 the raw outputs / their gradient. */
 int ml_trainer_debug_read(ml_trainer* t, int which, float* host_data, int64_t numel);
-/* The mid route's GEMM on its own: c (M, N) = a (M, K) . b (N, K)^T (+ bias (N)) (+ res (M, N)), all fp32 device pointers, N % 64
- * == 0, K % 32 == 0; amax / bmax: optional device words max |a| / max |b| (operand scaling); ct: optional transposed copy
- * (N, ldct); tile_rows 32 or 64. */
-int ml_debug_tgemm(const float* a_dev, const float* b_dev, float* c_dev, int M, int N, int K, const float* bias_dev,
-                   const float* res_dev, const float* amax_dev, const float* bmax_dev, float* ct_dev, int64_t ldct, int tile_rows,
-                   void* stream);
+/* The mid route's exact-fp32 GEMM on its own: c (M, N) = A . B^T-like product sum_k A(i, k) B(j, k) (+ bias (N)) (+ res (M, N)).
+ * layout 0: the operand is k-contiguous (A(i, k) = a[i * lda + k]; K % 32 == 0), layout 1: reduction-major (A(i, k) =
+ * a[k * lda + i]; for A: M % 32 == 0).  N % 64 == 0.  sumsq_dev: optional (N / 64) * ceil(M / 32) doubles, the per-workgroup
+ * sums of squares of c.  flags: XGemmParams::flags (1 rotated k start per workgroup, 2 row tiles on blockIdx.x).  All device
+ * pointers. */
+int ml_debug_xgemm(const float* a_dev, int64_t lda, int a_layout, const float* b_dev, int64_t ldb, int b_layout, float* c_dev, int M,
+                   int N, int K, const float* bias_dev, const float* res_dev, double* sumsq_dev, int flags, void* stream);
 /* Packed fp16 hi|lo line image of a dense layer's weights (n * kpad * 2 uint16); only kept for
  * models finalized with ML_FLAG_HOST_ONLY. */
 int ml_debug_get_packed(const ml_loco* h, int layer, uint16_t* lines_host, int64_t capacity);

@@ -98,18 +98,14 @@ struct ml_trainer {
     // 3 large-batch (fast) route whenever it can run.  auto: >= fast_rows rows -> fast, below -> mid, else exact.
     int route = 0;
     int64_t fast_rows = 4096;
-    // mid route (train_mid.h): W^T of every H x H weight, max |W| words (two sets: the one this step's GEMMs read and the one
-    // its optimizer accumulates for the next step), max |dz| words (zeroed with the reduction slots), transposed
-    // activation / gradient buffers, a pinned landing zone for the loss values
-    float* wT = nullptr;
-    float* wmaxw[2] = {nullptr, nullptr};
-    int wmax_cur = 0;
-    bool wt_dirty = true;
-    float* dzmaxw = nullptr;
-    std::vector<float*> tbufs;       // 2S + 4 buffers [H][cap]
-    bool tbufs_owned = false;
+    // mid route (train_mid.h): per-workgroup partial sums of squares of the weight-gradient GEMMs, the tables of the
+    // H x H matrices / the narrow segments between them, a pinned landing zone for the loss values
+    double* d_ssq = nullptr;
+    double* d_gn = nullptr;          // GN_PARTS partial sums of the gradient norm
+    int ssq_per_mat = 0;
+    int apply_cols = 8;              // columns a workgroup of the column-owner kernels takes (4 | 8 | 16): ml_trainer_set_tuning
     double* h_loss = nullptr;
-    mlt::AdamMats mats;
+    std::vector<int64_t> mat_off;    // flat offsets of the H x H weight matrices by Linear slot
     mlt::AdamSegs segs;
     int last_route = -1;             // route the last step took (0 exact, 1 fast, 2 mid): ml_trainer_last_route
 };
@@ -359,7 +355,7 @@ int fast_linear_bwd_weight(ml_trainer* t, hipStream_t st, const float* x, const 
 }
 
 bool fast_possible(const ml_trainer* t) { return t->H % 256 == 0 && !t->lbufs.empty(); }
-bool mid_possible(const ml_trainer* t) { return t->H % 64 == 0 && t->wT != nullptr && !t->tbufs.empty() && t->in_f <= mlt::SK_NC; }
+bool mid_possible(const ml_trainer* t) { return t->H % 64 == 0 && t->d_ssq != nullptr && t->in_f <= mlt::SK_NC; }
 // 0 exact, 1 fast (large batches: 256 x 256-tile 3-product GEMMs on line-format operands), 2 mid (train_mid.h)
 int pick_route(const ml_trainer* t, int64_t m) {
     switch (t->route) {
@@ -505,26 +501,6 @@ int ensure_cap(ml_trainer* t, int64_t m) {
             }
         }
     }
-    // mid route: 2S + 4 transposed fp32 buffers [H][m]; where the large-batch route's line buffers exist (same size, never
-    // used by the same step) they are shared
-    if (t->tbufs_owned)
-        for (float* p : t->tbufs) (void)hipFree(p);
-    t->tbufs.clear();
-    t->tbufs_owned = false;
-    if (t->H % 64 == 0 && t->wT) {
-        if (t->H % 256 == 0) {
-            for (char* p : t->lbufs) t->tbufs.push_back((float*)p);
-            t->tbufs.push_back((float*)t->tl_dz);
-            t->tbufs.push_back((float*)t->tl_x);
-        } else {
-            t->tbufs_owned = true;
-            for (int i = 0; i < 2 * t->S + 4; ++i) {
-                float* p = nullptr;
-                T_TRY(hipMalloc((void**)&p, (size_t)m * t->H * 4));
-                t->tbufs.push_back(p);
-            }
-        }
-    }
     if (t->d_out) (void)hipFree(t->d_out);
     if (t->d_dout) (void)hipFree(t->d_dout);
     const int nb = 4 * t->S + 8;  // a_s (S+1), t_s (S), z (2S+2), y2, y3, xhat, 2 gradient buffers
@@ -580,39 +556,60 @@ void finish_step_host(ml_trainer* t, const double* lv, bool task_weights, int up
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The mid route (train_mid.h): one training step in ~57 launches.
-int launch_tgemm(ml_trainer* t, hipStream_t st, const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N,
-                 int K, const float* bias, const float* res, const float* amax, const float* bmax, float* ct, long ldct) {
-    mlt::TGemmParams p;
-    p.a = a; p.b = b; p.c = c; p.res = res; p.bias = bias; p.amax = amax; p.bmax = bmax; p.ct = ct;
-    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldct = ldct;
-    p.M = M; p.N = N; p.K = K; p.dbg = 0;
-    // 64-row tiles once they fill the chip, 32-row tiles (twice the workgroups, the K range split inside) below
-    const int tiles64 = ((M + 63) / 64) * (N / 64);
-    if (tiles64 >= t->n_cu) hipLaunchKernelGGL(mlt::tgemm_kernel<64>, dim3(N / 64, (M + 63) / 64), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(mlt::tgemm_kernel<32>, dim3(N / 64, (M + 31) / 32), dim3(256), 0, st, p);
-    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "tgemm launch failed");
+// The mid route (train_mid.h): one training step in ~57 launches, every GEMM on the exact fp32 matrix instruction.
+int launch_xgemm(hipStream_t st, const float* a, long lda, int alay, const float* b, long ldb, int blay, float* c, long ldc, int M,
+                 int N, int K, const float* bias, const float* res, double* sumsq, int flags = 0) {
+    mlt::XGemmParams p;
+    p.a = a; p.b = b; p.c = c; p.res = res; p.bias = bias; p.sumsq = sumsq;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.flags = flags;
+    const unsigned gx = N / mlt::XG_BN, gy = (M + mlt::XG_BM - 1) / mlt::XG_BM;
+    const dim3 grid((flags & 2) ? gy : gx, (flags & 2) ? gx : gy), blk(256);
+    const int abl = flags >> 8;   // timing ablations of the forward layout (ml_debug_xgemm only)
+    p.flags &= 255;
+    if (abl && alay == 0 && blay == 0) {
+        switch (abl) {
+            case 1: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 1>), grid, blk, 0, st, p); break;
+            case 2: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 2>), grid, blk, 0, st, p); break;
+            case 4: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 4>), grid, blk, 0, st, p); break;
+            case 8: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 8>), grid, blk, 0, st, p); break;
+            case 12: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 12>), grid, blk, 0, st, p); break;
+            case 14: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 14>), grid, blk, 0, st, p); break;
+            case 16: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 16>), grid, blk, 0, st, p); break;
+            case 30: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 30>), grid, blk, 0, st, p); break;
+            default: return tfail(ML_ERR_ARG, "unknown xgemm ablation");
+        }
+    } else if (alay == 0 && blay == 0) hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0>), grid, blk, 0, st, p);
+    else if (alay == 0 && blay == 1) hipLaunchKernelGGL((mlt::xgemm_kernel<0, 1>), grid, blk, 0, st, p);
+    else if (alay == 1 && blay == 1) hipLaunchKernelGGL((mlt::xgemm_kernel<1, 1>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((mlt::xgemm_kernel<1, 0>), grid, blk, 0, st, p);
+    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "xgemm launch failed");
     return 0;
+}
+
+template <typename P>
+void launch_fwd_apply(const ml_trainer* t, hipStream_t st, const P& p) {
+    const dim3 blk(256);
+    if (t->apply_cols == 4) hipLaunchKernelGGL(mlt::fwd_apply_kernel<4>, dim3(t->H / 4), blk, 0, st, p);
+    else if (t->apply_cols == 8) hipLaunchKernelGGL(mlt::fwd_apply_kernel<8>, dim3(t->H / 8), blk, 0, st, p);
+    else hipLaunchKernelGGL(mlt::fwd_apply_kernel<16>, dim3(t->H / 16), blk, 0, st, p);
+}
+template <typename P>
+void launch_bwd_apply(const ml_trainer* t, hipStream_t st, const P& p) {
+    const dim3 blk(256);
+    if (t->apply_cols == 4) hipLaunchKernelGGL(mlt::bwd_apply_kernel<4>, dim3(t->H / 4), blk, 0, st, p);
+    else if (t->apply_cols == 8) hipLaunchKernelGGL(mlt::bwd_apply_kernel<8>, dim3(t->H / 8), blk, 0, st, p);
+    else hipLaunchKernelGGL(mlt::bwd_apply_kernel<16>, dim3(t->H / 16), blk, 0, st, p);
 }
 
 int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m, int update,
              double* losses_host, float* raw_out_dev, hipStream_t st) {
     const int H = t->H, S = t->S, C = t->C;
-    const long ldt = (long)((m + 31) / 32 * 32);
     int rc;
-    // one memset: the fp64 reduction slots and, behind them, the max |dz| words
-    T_TRY(hipMemsetAsync(t->d_red_base, 0, ((size_t)t->red_slots * (2 * H + 32) + 64) * sizeof(double), st));
+    T_TRY(hipMemsetAsync(t->d_red_base, 0, (size_t)t->red_slots * (2 * H + 32) * sizeof(double), st));
     t->red_slot = 0;
     t->d_red = t->d_red_base;
-    float* wmax = t->wmaxw[t->wmax_cur];
-    float* wmax_next = t->wmaxw[t->wmax_cur ^ 1];
-    const dim3 tgrid((unsigned)((H / 64) * (H / 64)), (unsigned)t->mats.count);
-    if (t->wt_dirty) {   // weights written through set_tensor: rebuild W^T and max |W|
-        T_TRY(hipMemsetAsync(wmax, 0, 64 * sizeof(float), st));
-        hipLaunchKernelGGL(mlt::wt_refresh_kernel, tgrid, dim3(256), 0, st, (const float*)t->w, t->mats, H, t->wT, wmax);
-        t->wt_dirty = false;
-    }
-    // buffer plan (the exact route's; + transposed copies)
+    // buffer plan (the exact route's)
     int bi = 0;
     auto nb = [&]() { return t->bufs[bi++]; };
     std::vector<float*> a(S + 1), tt(S), za(S), zb(S);
@@ -626,56 +623,45 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     float* gE = nb();   // (the exact route's xhat scratch)
     float* gA = nb();
     float* gB = nb();
-    auto aT = [&](int s) { return t->tbufs[s]; };
-    auto tT = [&](int s) { return t->tbufs[S + 1 + s]; };
-    float* y2T = t->tbufs[2 * S + 1];
-    float* dzT = t->tbufs[2 * S + 2];
     const uint32_t seed = t->seed + (uint32_t)t->step * 977u;
-    const size_t HH = (size_t)H * H;
-    auto Wt = [&](int slot) { return t->wT + (size_t)slot * HH; };
     auto mean_of = [&](int bn_idx) { return t->bn_mean + (size_t)bn_idx * H; };
     auto inv_of = [&](int bn_idx) { return t->bn_invstd + (size_t)bn_idx * H; };
-    const dim3 cgrid((unsigned)(H / 16)), blk(256);
 
     // ---------------- forward (train mode)
-    auto fwd_apply = [&](const float* z, const std::string& bn, int bn_idx, uint32_t site, const float* residual, float* y, float* yT,
-                         bool input_layer) {
+    auto fwd_apply = [&](float* z, const std::string& bn, int bn_idx, uint32_t site, const float* residual, float* y, bool input_layer) {
         mlt::FwdApplyParams p;
         p.z = input_layer ? nullptr : z;
         p.x_in = input_layer ? x_dev : nullptr;
         p.w_in = input_layer ? P(t, "w1.weight") : nullptr;
         p.b_in = input_layer ? P(t, "w1.bias") : nullptr;
-        p.z_out = input_layer ? const_cast<float*>(z) : nullptr;
+        p.z_out = input_layer ? z : nullptr;
         p.in_dim = t->in_f;
-        p.m = (long)m; p.H = H; p.ldt = ldt;
+        p.m = (long)m; p.H = H;
         p.gamma = P(t, bn + ".weight"); p.beta = P(t, bn + ".bias");
         p.run_mean = ST(t, bn + ".running_mean"); p.run_var = ST(t, bn + ".running_var");
         p.mean_out = mean_of(bn_idx); p.invstd_out = inv_of(bn_idx);
         p.p_drop = t->p_drop; p.seed = seed; p.site = site;
-        p.residual = residual; p.y = y; p.yT = yT;
-        p.zero_words = input_layer && update ? wmax_next : nullptr;   // the optimizer accumulates the next step's max |W| there
-        p.n_zero = 64;
-        hipLaunchKernelGGL(mlt::fwd_apply_kernel, cgrid, blk, 0, st, p);
+        p.residual = residual; p.y = y;
+        launch_fwd_apply(t, st, p);
     };
-    // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
-    auto lin_fwd = [&](const float* x, const std::string& lin, int slot, float* z, float* zT) {
-        return launch_tgemm(t, st, x, H, P(t, lin + ".weight"), H, z, H, (int)m, H, H, P(t, lin + ".bias"), nullptr, nullptr, wmax + slot,
-                            zT, ldt);
+    // z (m x H) = x . W^T + b: both operands k-contiguous
+    auto lin_fwd = [&](const float* x, const std::string& lin, float* z) {
+        return launch_xgemm(st, x, H, 0, P(t, lin + ".weight"), H, 0, z, H, (int)m, H, H, P(t, lin + ".bias"), nullptr, nullptr);
     };
-    fwd_apply(z0, "batch_norm1", 0, 0, nullptr, a[0], aT(0), true);
+    fwd_apply(z0, "batch_norm1", 0, 0, nullptr, a[0], true);
     for (int s = 0; s < S; ++s) {
         const std::string p = "linear_stages." + std::to_string(s) + ".";
-        if ((rc = lin_fwd(a[s], p + "w1", 2 * s, za[s], nullptr))) return rc;
-        fwd_apply(za[s], p + "batch_norm1", 1 + 2 * s, 1 + 2 * s, nullptr, tt[s], tT(s), false);
-        if ((rc = lin_fwd(tt[s], p + "w2", 2 * s + 1, zb[s], nullptr))) return rc;
-        fwd_apply(zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, a[s], a[s + 1], aT(s + 1), false);   // a_{s+1} = a_s + block(t_s)
+        if ((rc = lin_fwd(a[s], p + "w1", za[s]))) return rc;
+        fwd_apply(za[s], p + "batch_norm1", 1 + 2 * s, 1 + 2 * s, nullptr, tt[s], false);
+        if ((rc = lin_fwd(tt[s], p + "w2", zb[s]))) return rc;
+        fwd_apply(zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, a[s], a[s + 1], false);   // a_{s+1} = a_s + block(t_s)
     }
-    if ((rc = lin_fwd(a[S], "w2", 2 * S, y2, y2T))) return rc;
+    if ((rc = lin_fwd(a[S], "w2", y2))) return rc;
     const bool skinny = skinny_ok(t, C - 1);
     if (!(skinny && skinny_heads(t, st, y2, m, P(t, "w_aux.weight"), P(t, "w_aux.bias"), 1, t->d_out + (C - 1), C)))
         if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
-    if ((rc = lin_fwd(y2, "w3", 2 * S + 1, z3, nullptr))) return rc;
-    fwd_apply(z3, "batch_norm3", 2 * S + 1, 2 * S + 1, nullptr, y3, nullptr, false);
+    if ((rc = lin_fwd(y2, "w3", z3))) return rc;
+    fwd_apply(z3, "batch_norm3", 2 * S + 1, 2 * S + 1, nullptr, y3, false);
     if (!(skinny && skinny_heads(t, st, y3, m, P(t, "w_fin.weight"), P(t, "w_fin.bias"), C - 1, t->d_out, C)))
         if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
     if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
@@ -686,18 +672,12 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
                        t->d_dout, d_loss, (const float*)(task_weights ? t->d_tw : nullptr));
     T_TRY(hipMemcpyAsync(t->h_loss, d_loss, 8 * sizeof(double), hipMemcpyDeviceToHost, st));   // pinned: does not stall the host
-    // ---------------- backward (every gradient tensor is written in full: no memset of g)
-    if ((rc = col_stats(t, st, t->d_dout, nullptr, m, C))) return rc;
-    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)t->d_red, C - 1, G(t, "w_fin.bias"));
-    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)(t->d_red + (C - 1)), 1,
-                       G(t, "w_aux.bias"));
-    if (skinny) rc = skinny_dw(t, st, t->d_dout, C, C - 1, y3, m, G(t, "w_fin.weight"), 0);
-    else rc = linear_bwd_weight(t, st, t->d_dout, C, y3, H, G(t, "w_fin.weight"), (int)m, C - 1, H);
-    if (rc) return rc;
-    int word = 0;
-    // dz of one block from its incoming gradient; returns the max |dz| word the following GEMMs scale by
+    // ---------------- backward (every gradient tensor is written in full: no memset of g).  The narrow gradients (head weights
+    // and biases, input-layer weights) ride in the column-owner kernels of the blocks whose data they read.
+    // dz of one block from its incoming gradient
+    // extra: 0 none, 1 = block 3 (w_fin weight gradient from y3 + both head biases), 2 = w2 (w_aux weight gradient from y2)
     auto bwd_apply = [&](const float* dy, bool from_heads, bool aux, const float* z, const std::string& bn, int bn_idx, uint32_t site,
-                         const std::string& lin, float* dz, float* dzTp) -> float* {
+                         const std::string& lin, float* dz, int extra) {
         mlt::BwdApplyParams p;
         p.dy = from_heads ? nullptr : dy;
         p.dout = from_heads ? t->d_dout : nullptr;
@@ -712,63 +692,59 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
         p.gamma = z ? P(t, bn + ".weight") : nullptr;
         p.beta = z ? P(t, bn + ".bias") : nullptr;
         p.p_drop = t->p_drop; p.seed = seed; p.site = site;
-        p.m = (long)m; p.H = H; p.ldt = ldt;
-        p.dz = dz; p.dzT = dzTp;
+        p.m = (long)m; p.H = H;
+        p.dz = dz;
         p.dgamma = z ? G(t, bn + ".weight") : nullptr;
         p.dbeta = z ? G(t, bn + ".bias") : nullptr;
         p.dbias = G(t, lin + ".bias");
-        p.dzmax = t->dzmaxw + word;
-        hipLaunchKernelGGL(mlt::bwd_apply_kernel, cgrid, blk, 0, st, p);
-        return t->dzmaxw + word++;
+        p.sc = nullptr; p.sld = C; p.ns = 0; p.ysrc = nullptr; p.dwh = nullptr;
+        p.hb_src = nullptr; p.hb_ld = C; p.hb_n0 = C - 1; p.hb0 = nullptr; p.hb1 = nullptr;
+        if (extra == 1) {
+            p.sc = t->d_dout; p.ns = C - 1; p.ysrc = y3; p.dwh = G(t, "w_fin.weight");
+            p.hb_src = t->d_dout; p.hb0 = G(t, "w_fin.bias"); p.hb1 = G(t, "w_aux.bias");
+        } else if (extra == 2) {
+            p.sc = t->d_dout + (C - 1); p.ns = 1; p.ysrc = y2; p.dwh = G(t, "w_aux.weight");
+        }
+        launch_bwd_apply(t, st, p);
     };
-    // dW (H x H) = dz^T . x from the transposed copies (reduction over the batch, zero padded to ldt)
-    auto wgrad = [&](const float* xT, const std::string& lin, const float* dzw) {
-        return launch_tgemm(t, st, dzT, ldt, xT, ldt, G(t, lin + ".weight"), H, H, H, (int)ldt, nullptr, nullptr, dzw, nullptr, nullptr, 0);
+    // dW (H x H) = dz^T . x: both operands reduction-major (the batch is the reduction); leaves its sum of squares
+    auto wgrad = [&](const float* dz, const float* x, const std::string& lin, int slot) {
+        return launch_xgemm(st, dz, H, 1, x, H, 1, G(t, lin + ".weight"), H, H, H, (int)m, nullptr, nullptr,
+                            t->d_ssq + (size_t)slot * t->ssq_per_mat);
     };
-    // dx (m x H) = dz . W (+ res) through W^T
-    auto dgrad = [&](const float* dz, int slot, const float* dzw, float* dx, const float* res) {
-        return launch_tgemm(t, st, dz, H, Wt(slot), H, dx, H, (int)m, H, H, nullptr, res, dzw, wmax + slot, nullptr, 0);
+    // dx (m x H) = dz . W (+ res): dz k-contiguous, W reduction-major as it lies (W[n][k]: n is the reduction)
+    auto dgrad = [&](const float* dz, const std::string& lin, float* dx, const float* res) {
+        return launch_xgemm(st, dz, H, 0, P(t, lin + ".weight"), H, 1, dx, H, (int)m, H, H, nullptr, res, nullptr);
     };
-    float* dzw = bwd_apply(nullptr, true, false, z3, "batch_norm3", 2 * S + 1, 2 * S + 1, "w3", gB, dzT);          // gB = dz3
-    if ((rc = wgrad(y2T, "w3", dzw))) return rc;
-    if ((rc = dgrad(gB, 2 * S + 1, dzw, gA, nullptr))) return rc;                                                 // gA = dy2 (w3 part)
-    if (skinny) rc = skinny_dw(t, st, t->d_dout + (C - 1), C, 1, y2, m, G(t, "w_aux.weight"), 0);
-    else rc = linear_bwd_weight(t, st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H);
-    if (rc) return rc;
-    dzw = bwd_apply(gA, false, true, nullptr, "", 0, 0, "w2", gB, dzT);                                          // gB = dz2 = dy2 + daux (x) w_aux
-    if ((rc = wgrad(aT(S), "w2", dzw))) return rc;
-    if ((rc = dgrad(gB, 2 * S, dzw, gA, nullptr))) return rc;                                                    // gA = da_S
+    // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
+    bwd_apply(nullptr, true, false, z3, "batch_norm3", 2 * S + 1, 2 * S + 1, "w3", gB, 1);                        // gB = dz3
+    if ((rc = wgrad(gB, y2, "w3", 2 * S + 1))) return rc;
+    if ((rc = dgrad(gB, "w3", gA, nullptr))) return rc;                                                          // gA = dy2 (w3 part)
+    bwd_apply(gA, false, true, nullptr, "", 0, 0, "w2", gB, 2);                                                  // gB = dz2 = dy2 + daux (x) w_aux
+    if ((rc = wgrad(gB, a[S], "w2", 2 * S))) return rc;
+    if ((rc = dgrad(gB, "w2", gA, nullptr))) return rc;                                                          // gA = da_S
     for (int s = S - 1; s >= 0; --s) {   // a_{s+1} = a_s + B(A(a_s))
         const std::string p = "linear_stages." + std::to_string(s) + ".";
-        dzw = bwd_apply(gA, false, false, zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, p + "w2", gB, dzT);      // gB = dz_b
-        if ((rc = wgrad(tT(s), p + "w2", dzw))) return rc;
-        if ((rc = dgrad(gB, 2 * s + 1, dzw, gE, nullptr))) return rc;                                             // gE = d t_s
-        dzw = bwd_apply(gE, false, false, za[s], p + "batch_norm1", 1 + 2 * s, 1 + 2 * s, p + "w1", gB, dzT);      // gB = dz_a
-        if ((rc = wgrad(aT(s), p + "w1", dzw))) return rc;
-        if ((rc = dgrad(gB, 2 * s, dzw, gA, gA))) return rc;                                                      // gA = da_s = da_{s+1} + dz_a . W
+        bwd_apply(gA, false, false, zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, p + "w2", gB, 0);              // gB = dz_b
+        if ((rc = wgrad(gB, tt[s], p + "w2", 2 * s + 1))) return rc;
+        if ((rc = dgrad(gB, p + "w2", gE, nullptr))) return rc;                                                   // gE = d t_s
+        bwd_apply(gE, false, false, za[s], p + "batch_norm1", 1 + 2 * s, 1 + 2 * s, p + "w1", gB, 0);              // gB = dz_a
+        if ((rc = wgrad(gB, a[s], p + "w1", 2 * s))) return rc;
+        if ((rc = dgrad(gB, p + "w1", gA, gA))) return rc;                                                        // gA = da_s = da_{s+1} + dz_a . W
     }
-    (void)bwd_apply(gA, false, false, z0, "batch_norm1", 0, 0, "w1", gB, nullptr);                                // gB = dz0
-    if (skinny_ok(t, t->in_f)) rc = skinny_dw(t, st, x_dev, t->in_f, t->in_f, gB, m, G(t, "w1.weight"), 1);
-    else rc = linear_bwd_weight(t, st, gB, H, x_dev, t->in_f, G(t, "w1.weight"), (int)m, H, t->in_f);
-    if (rc) return rc;
+    bwd_apply(gA, false, false, z0, "batch_norm1", 0, 0, "w1", gB, 0);                                            // gB = dz0
+    if ((rc = skinny_dw(t, st, x_dev, t->in_f, t->in_f, gB, m, G(t, "w1.weight"), 1))) return rc;
     // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)
     const int64_t k = t->step + 1;
     const float lr = t->lr0 * std::pow(t->gamma, (float)(t->step / t->sched_step));
     const float bc1 = 1.f - std::pow(0.9f, (float)k), bc2 = 1.f - std::pow(0.999f, (float)k);
     {
-        double* d_ss = t->d_red + 2 * H + 16;  // pre-zeroed, never shared with d_loss (other offset)
-        hipLaunchKernelGGL(mlt::sumsq4_kernel, dim3(1024), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
-        mlt::AdamHyper hp;
-        hp.sumsq = d_ss; hp.max_norm = 3.0f; hp.lr = lr; hp.b1 = 0.9f; hp.b2 = 0.999f; hp.eps = 1e-8f; hp.bc1 = bc1; hp.bc2 = bc2;
-        hp.do_adam = update ? 1 : 0;
-        hipLaunchKernelGGL(mlt::adam_tile_kernel, tgrid, dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->mats, H, t->wT, wmax_next, hp);
-        hipLaunchKernelGGL(mlt::adam_small_kernel, dim3(nblk(t->segs.start[t->segs.count])), dim3(256), 0, st, t->w, t->g, t->m1, t->m2,
-                           t->segs, hp);
+        hipLaunchKernelGGL(mlt::gradnorm_kernel, dim3(mlt::GN_PARTS), dim3(256), 0, st, (const float*)t->g, t->segs,
+                           (const double*)t->d_ssq, (int)(t->mat_off.size() * t->ssq_per_mat), t->d_gn);
+        hipLaunchKernelGGL(mlt::clip_adam_parts_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
+                           (const double*)t->d_gn, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);
         if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "optimizer launch failed");
-        if (update) {
-            t->step++;
-            t->wmax_cur ^= 1;   // the words the optimizer has just filled describe the new weights
-        }
+        if (update) t->step++;
     }
     T_TRY(hipStreamSynchronize(st));
     finish_step_host(t, t->h_loss, task_weights, update, lr, bc1, bc2, losses_host);
@@ -812,12 +788,10 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
     T_TRY(hipMalloc((void**)&t->bn_mean, (size_t)t->nbn * hidden * 4));
     T_TRY(hipMalloc((void**)&t->bn_invstd, (size_t)t->nbn * hidden * 4));
     t->red_slots = red_slots_for(num_stage);
-    // (+ 64 doubles behind the slots: the per-step max |dz| words of the mid route, zeroed by the same memset)
-    T_TRY(hipMalloc((void**)&t->d_red_base, ((size_t)t->red_slots * (2 * hidden + 32) + 64) * sizeof(double)));
-    t->dzmaxw = (float*)(t->d_red_base + (size_t)t->red_slots * (2 * hidden + 32));
+    T_TRY(hipMalloc((void**)&t->d_red_base, (size_t)t->red_slots * (2 * hidden + 32) * sizeof(double)));
     T_TRY(hipHostMalloc((void**)&t->h_loss, 16 * sizeof(double), hipHostMallocDefault));
     {   // flat offsets of the H x H matrices by Linear slot (2s, 2s + 1 = stage s w1 / w2, 2S = w2, 2S + 1 = w3) and the
-        // segments between them (everything else), for the mid route's optimizer
+        // segments between them (everything else), for the mid route's gradient norm
         std::vector<std::string> names;
         for (int s = 0; s < num_stage; ++s) {
             names.push_back("linear_stages." + std::to_string(s) + ".w1.weight");
@@ -825,10 +799,9 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
         }
         names.push_back("w2.weight");
         names.push_back("w3.weight");
-        t->mats.count = (int)names.size();
         std::vector<int64_t> offs;
         for (size_t i = 0; i < names.size(); ++i) {
-            t->mats.off[i] = t->slots[names[i]].off;
+            t->mat_off.push_back(t->slots[names[i]].off);
             offs.push_back(t->slots[names[i]].off);
         }
         std::sort(offs.begin(), offs.end());
@@ -849,14 +822,11 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
         add_seg(pos, t->n_param);
         t->segs.start[t->segs.count] = total;
     }
-    if (hidden % 64 == 0) {
-        T_TRY(hipMalloc((void**)&t->wT, (size_t)t->mats.count * hidden * hidden * 4));
-        for (int k = 0; k < 2; ++k) {
-            T_TRY(hipMalloc((void**)&t->wmaxw[k], 64 * sizeof(float)));
-            T_TRY(hipMemset(t->wmaxw[k], 0, 64 * sizeof(float)));
-        }
+    if (hidden % 64 == 0) {   // one partial sum of squares per workgroup of a weight-gradient GEMM
+        t->ssq_per_mat = (hidden / mlt::XG_BN) * (hidden / mlt::XG_BM);
+        T_TRY(hipMalloc((void**)&t->d_ssq, (size_t)t->mat_off.size() * t->ssq_per_mat * sizeof(double)));
+        T_TRY(hipMalloc((void**)&t->d_gn, mlt::GN_PARTS * sizeof(double)));
     }
-    t->d_red = t->d_red_base;
     t->splitk_cap = (size_t)32 * hidden * (hidden > in_features ? hidden : in_features);
     T_TRY(hipMalloc((void**)&t->d_splitk, t->splitk_cap * 4));
     T_TRY(hipMemset(t->w, 0, (size_t)t->n_param * 4));
@@ -875,10 +845,8 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (char* p : t->lbufs) (void)hipFree(p);
     for (char* p : t->wl) (void)hipFree(p);
     for (float* p : t->wbs) (void)hipFree(p);
-    if (t->tbufs_owned)
-        for (float* p : t->tbufs) (void)hipFree(p);
     if (t->h_loss) (void)hipHostFree(t->h_loss);
-    void* ptrs[] = {t->wT, t->wmaxw[0], t->wmaxw[1], t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    void* ptrs[] = {t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -899,7 +867,6 @@ static int xfer(ml_trainer* t, const char* key, float* host, const float* chost,
     T_TRY(hipDeviceSynchronize());
     if (what == 0) {
         T_TRY(hipMemcpy(base + it->second.off, chost, (size_t)numel * 4, hipMemcpyHostToDevice));
-        t->wt_dirty = true;   // W^T / max |W| of the mid route are rebuilt by the next step
     } else T_TRY(hipMemcpy(host, base + it->second.off, (size_t)numel * 4, hipMemcpyDeviceToHost));
     return ML_OK;
 }
@@ -951,38 +918,32 @@ int ml_trainer_set_route(ml_trainer* t, int route, int64_t fast_rows) {
 
 int ml_trainer_last_route(const ml_trainer* t) { return t ? t->last_route : -1; }
 
+int ml_trainer_set_tuning(ml_trainer* t, int apply_cols) {
+    if (!t || (apply_cols != 4 && apply_cols != 8 && apply_cols != 16)) return tfail(ML_ERR_ARG, "apply_cols must be 4, 8 or 16");
+    t->apply_cols = apply_cols;
+    return ML_OK;
+}
+
 int ml_trainer_debug_read(ml_trainer* t, int which, float* host_data, int64_t numel) {
     if (!t || !host_data || numel <= 0) return tfail(ML_ERR_ARG, "bad argument");
     const float* src = nullptr;
     int64_t cap = 0;
     if (which >= 0 && which < (int)t->bufs.size()) { src = t->bufs[which]; cap = t->cap * t->H; }
-    else if (which >= 100 && which - 100 < (int)t->tbufs.size()) { src = t->tbufs[which - 100]; cap = t->cap * t->H; }
     else if (which == 200) { src = t->d_out; cap = t->cap * t->C; }
     else if (which == 201) { src = t->d_dout; cap = t->cap * t->C; }
-    else if (which >= 300 && which - 300 < t->mats.count && t->wT) { src = t->wT + (size_t)(which - 300) * t->H * t->H; cap = (int64_t)t->H * t->H; }
-    else if (which == 400 && t->wmaxw[0]) { src = t->wmaxw[t->wmax_cur]; cap = 64; }
-    else if (which == 401 && t->dzmaxw) { src = t->dzmaxw; cap = 64; }
     if (!src || numel > cap) return tfail(ML_ERR_ARG, "no such buffer / too many elements");
     T_TRY(hipDeviceSynchronize());
     T_TRY(hipMemcpy(host_data, src, (size_t)numel * 4, hipMemcpyDeviceToHost));
     return ML_OK;
 }
 
-int ml_debug_tgemm(const float* a_dev, const float* b_dev, float* c_dev, int M, int N, int K, const float* bias_dev,
-                   const float* res_dev, const float* amax_dev, const float* bmax_dev, float* ct_dev, int64_t ldct, int tile_rows,
-                   void* stream) {
-    if (!a_dev || !b_dev || !c_dev || M < 1 || N < 64 || N % 64 || K < 32 || K % 32 || ((tile_rows & 255) != 32 && (tile_rows & 255) != 64))
-        return tfail(ML_ERR_ARG, "bad tgemm shape");
-    mlt::TGemmParams p;
-    p.a = a_dev; p.b = b_dev; p.c = c_dev; p.res = res_dev; p.bias = bias_dev; p.amax = amax_dev; p.bmax = bmax_dev; p.ct = ct_dev;
-    p.lda = K; p.ldb = K; p.ldc = N; p.ldct = (long)ldct;
-    p.M = M; p.N = N; p.K = K; p.dbg = tile_rows >> 8;   // (bits 8.. of tile_rows: timing ablations, see TGemmParams::dbg)
-    tile_rows &= 255;
-    hipStream_t st = (hipStream_t)stream;
-    if (tile_rows == 64) hipLaunchKernelGGL(mlt::tgemm_kernel<64>, dim3(N / 64, (M + 63) / 64), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(mlt::tgemm_kernel<32>, dim3(N / 64, (M + 31) / 32), dim3(256), 0, st, p);
-    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "tgemm launch failed");
-    return ML_OK;
+int ml_debug_xgemm(const float* a_dev, int64_t lda, int a_layout, const float* b_dev, int64_t ldb, int b_layout, float* c_dev, int M,
+                   int N, int K, const float* bias_dev, const float* res_dev, double* sumsq_dev, int flags, void* stream) {
+    if (!a_dev || !b_dev || !c_dev || M < 1 || N < 64 || N % 64 || K < 1) return tfail(ML_ERR_ARG, "bad xgemm shape");
+    if ((a_layout == 0 && K % 32) || (a_layout == 1 && M % 32) || (b_layout == 0 && K % 32))
+        return tfail(ML_ERR_ARG, "xgemm: a k-contiguous operand needs K % 32 == 0, a reduction-major A needs M % 32 == 0");
+    return launch_xgemm((hipStream_t)stream, a_dev, (long)lda, a_layout, b_dev, (long)ldb, b_layout, c_dev, N, M, N, K, bias_dev, res_dev,
+                        sumsq_dev, flags);
 }
 
 int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m,
@@ -1126,10 +1087,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         hipLaunchKernelGGL(mlt::sumsq_kernel, dim3(512), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
         hipLaunchKernelGGL(mlt::clip_adam_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
                            (const double*)d_ss, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);
-        if (update) {
-            t->step++;
-            t->wt_dirty = true;   // (the mid route keeps W^T and max |W| itself; after a step of another route they are stale)
-        }
+        if (update) t->step++;
     }
     T_TRY(hipStreamSynchronize(st));
     finish_step_host(t, lv, task_weights, update, lr, bc1, bc2, losses_host);

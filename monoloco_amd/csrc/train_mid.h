@@ -1,248 +1,280 @@
 // train_mid.h -- the training step at the reference's REAL batch sizes (run.py:95 `--bs 512`, hyp_tuning.py:50 64..1024,
 // loop body trainer.py:150-161): a few hundred to a few thousand rows, where the 256 x 256-tile kernels of the large-batch
-// route keep a handful of CUs busy and the exact-fp32 GEMM needed ~175 launches per step.
+// route keep a handful of CUs busy and the generic exact-fp32 GEMM needed ~175 launches per step.
 //
-// Data layout of this route ("mid"): every tensor is plain fp32 in HBM.
-//   * activations / gradients that feed a GEMM exist row-major [m][H] AND transposed [H][ldt] (ldt = m rounded up to 32,
-//     pad rows zero): the weight-gradient GEMM dW = dz^T . x reduces over the batch, so both of its operands must be
-//     contiguous along the batch;
-//   * every H x H weight exists as W [n][k] and as W^T [k][n]; the optimizer maintains both (adam_tile_kernel);
-//   * per tensor one "max |.|" word (non-negative floats order like their bit patterns: atomicMax on the bits): the
-//     power-of-two scale that keeps the fp16 lo halves of the 3-product scheme in range is derived from it by the CONSUMER.
-// Kernels:
-//   tgemm_kernel<BM>   C = A . B^T (+ bias) (+ res) for row-major fp32 A [M][K], B [N][K]: 3-product fp16 MFMA
-//                      (hi.lo + lo.hi + hi.hi, fp32 accumulate) with the operands split into fp16 hi | lo ON THE FLY while
-//                      they are staged into LDS (32 x 64 or 64 x 64 tiles: 176 .. 256 workgroups for a 331 .. 512-row batch).
-//                      One kernel for forward (A = y, B = W), data gradient (A = dz, B = W^T) and weight gradient
-//                      (A = dz^T, B = y^T).
-//   fwd_apply_kernel   a workgroup OWNS 16 columns over ALL rows: batch statistics (exact, no atomics), BatchNorm, ReLU,
-//                      dropout, residual; writes y row-major and transposed.  The input layer's narrow product runs in it.
-//   bwd_apply_kernel   the same ownership backwards: (dy from the output heads |) dropout / ReLU mask, both BatchNorm
-//                      reductions, dz row-major + transposed, bias / gamma / beta gradients, max |dz|.
-//   adam_tile_kernel   clip + Adam on the H x H matrices in 64 x 64 tiles, writing W, W^T and max |W|;
-//   adam_small_kernel  the remaining (narrow) tensors;  sumsq4_kernel  the gradient norm.
+// The "mid" route: every tensor stays plain row-major fp32 in HBM -- no packed images, no transposed copies, no scales.
+//   xgemm_kernel<ALAY, BLAY>  C = A . B (+ bias) (+ res) on the EXACT fp32 matrix instruction (v_mfma_f32_32x32x2_f32 == an
+//                      fmaf chain, 64 FLOP / clk / SIMD) with 32 x 64 workgroup tiles (176 .. 512 workgroups for a
+//                      331 .. 512-row batch: every SIMD of the chip holds a wave), operands staged through LDS with
+//                      full-line loads two k-steps ahead.  Each operand is either k-contiguous ([row][k]) or
+//                      reduction-major ([k][row], read from LDS with a stride): forward z = y . W^T (k, k), data gradient
+//                      dx = dz . W (k, reduction-major W as it lies), weight gradient dW = dz^T . x (both reduction-major:
+//                      the batch is the reduction) run on the SAME row-major tensors.  A first version of this route
+//                      (round 3, profiles/r03_*_v1.txt) used the 3-product fp16 scheme with operands split on the fly:
+//                      the per-element conversion (3 VALU instructions at ~6 cycles) on every workgroup that re-reads an
+//                      operand cost more than the 16 x slower matrix instruction does at these sizes, and it needed W^T
+//                      and transposed activation copies (the transposing writes ran at 0.7 TB/s).
+//   fwd_apply_kernel<NC>  a workgroup OWNS NC columns over ALL rows: batch statistics (exact, fixed order, no atomics),
+//                      BatchNorm, ReLU, dropout, residual, in one launch behind the GEMM.  The input layer's narrow product
+//                      runs inside it.  All of a thread's rows are requested before the first is used (one memory latency).
+//   bwd_apply_kernel<NC>  the same ownership backwards: (dy from the output heads |) dropout / ReLU mask, both BatchNorm
+//                      reductions, dz, bias / gamma / beta gradients.
+//   gradnorm_kernel    the gradient norm from the per-workgroup partial sums the weight-gradient GEMMs leave (fixed order:
+//                      deterministic) + the narrow tensors.
 // Per-element arithmetic of BatchNorm, dropout, loss, clip and Adam is the exact route's (train_kernels.h).
 #pragma once
 #include "train_kernels.h"
-#include "dense_kernel_pp.h"   // mlk::split2_scaled (v_fma_mix based fp32 -> fp16 hi | lo split)
 
 namespace mlt {
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half8t __attribute__((ext_vector_type(8)));
-
 // ------------------------------------------------------------------------------------------------
-struct TGemmParams {
-    const float* a;      // [M][K] row-major, row stride lda (floats; multiple of 4, base 16-byte aligned)
-    const float* b;      // [N][K] row-major, row stride ldb
-    float* c;            // [M][N] row stride ldc
+struct XGemmParams {
+    const float* a;      // ALAY 0: A(i, k) = a[i * lda + k]   (K % 32 == 0);  ALAY 1: A(i, k) = a[k * lda + i]  (M % 32 == 0, any K)
+    const float* b;      // BLAY 0: B(j, k) = b[j * ldb + k];                  BLAY 1: B(j, k) = b[k * ldb + j]
+    float* c;            // C(i, j) = sum_k A(i, k) B(j, k), row stride ldc
     const float* res;    // optional [M][N] (stride ldc) added to the result; may alias c
     const float* bias;   // optional [N]
-    const float* amax;   // optional device word: max |A| (null: A is used unscaled)
-    const float* bmax;   // optional device word: max |B|
-    float* ct;           // optional transposed copy CT [N][ldct]; rows M .. ldct of it are written as zeros
-    long lda, ldb, ldc, ldct;
-    int M, N, K;         // N % 64 == 0, K % 32 == 0, any M >= 1 (rows beyond M are clamped on load, never stored)
-    int dbg;             // timing ablations (ml_debug_tgemm only; 0 in the product): 1 no loads in the loop, 2 no conversion / LDS
-                         // stores, 4 no fragment reads / MFMAs, 8 no barriers
+    double* sumsq;       // optional: sum of squares of this workgroup's part of C -> sumsq[blockIdx.y * gridDim.x + blockIdx.x]
+    long lda, ldb, ldc;
+    int M, N, K;         // N % 64 == 0; rows beyond M are clamped on load and never stored
+    int flags;           // 1: every workgroup starts its k loop at a different step (spreads simultaneous requests over the
+                         // address bits the memory channels are selected by); 2: blockIdx.x walks the row tiles
 };
 
-// 8 consecutive fp32 -> one 16-byte chunk of fp16 hi halves and one of lo halves of (v * d), hi clamped to +-65504
-__device__ __forceinline__ void conv8(const f32x4& v0, const f32x4& v1, float d, float lim, u32x4& h, u32x4& l) {
-    unsigned h0, l0, h1, l1, h2, l2, h3, l3;
-    mlk::split2_scaled<false>(v0[0], v0[1], d, lim, h0, l0);
-    mlk::split2_scaled<false>(v0[2], v0[3], d, lim, h1, l1);
-    mlk::split2_scaled<false>(v1[0], v1[1], d, lim, h2, l2);
-    mlk::split2_scaled<false>(v1[2], v1[3], d, lim, h3, l3);
-    h = u32x4{h0, h1, h2, h3};
-    l = u32x4{l0, l1, l2, l3};
-}
+constexpr int XG_BM = 32, XG_BN = 64;
+constexpr int XG_A_BYTES = XG_BM * 128, XG_STAGE = XG_A_BYTES + XG_BN * 128;
 
-// LDS image of one k32 step of an operand tile: one 128-byte "line" per row = 4 chunks of 8 fp16 hi halves, then 4 chunks of
-// lo halves; chunk c of row r sits at position c ^ ((r >> 1) & 7) (the layout dense_kernel.h reads conflict-free with
-// ds_read_b128: lane (r = lane & 31, h = lane >> 5) takes chunk 2 kk + h (+ 4 for lo) of the k16 half-step kk).
-template <int BM>
-__global__ __launch_bounds__(256) void tgemm_kernel(TGemmParams p) {
-    constexpr int BN = 64;
-    constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128;
-    static_assert(BM == 32 || BM == 64, "tile");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
+// One k32 step in LDS.  k-contiguous operand: a 128-byte row of 32 fp32 per tile row, its eight 16-byte chunks XOR-swizzled
+// by (row >> 1) & 7 (conflict-free ds_read_b128 for lane -> (row = lane & 31, chunk pair by lane >> 5), conflict-free
+// ds_write_b128 for 8 lanes per row).  Reduction-major operand: [32 k][tile rows] as it comes from memory; a lane reads its
+// 8 k values with a stride (32 consecutive lanes = 32 consecutive banks).
+// Waves: 2 (n halves of the 64 columns) x 2 (k16 halves of every k32 step); a wave issues 8 MFMAs per k-step: MFMA e
+// contracts k = 16 wk + e (lanes 0..31) and k = 16 wk + 8 + e (lanes 32..63).  The two k halves meet in LDS at the end.
+// ABL: compile-time timing ablations (ml_debug_xgemm only; results are garbage): 1 two accumulators, 2 no MFMAs, 4 no global
+// loads in the loop, 8 no LDS traffic in the loop, 16 no barriers in the loop
+template <int ALAY, int BLAY, int ABL = 0>
+__global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * XG_STAGE];
+    __shared__ double wsum[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // BM = 64: waves 2 (m) x 2 (n), each one 32 x 32 MFMA tile over the whole K.
-    // BM = 32: waves 2 (n) x 2 (k16 half-steps of every k32 step); the two halves meet in LDS at the end.
-    const int tn = w & 1;
-    const int tm = (BM == 64) ? (w >> 1) : 0;
-    const int wk = (BM == 64) ? 0 : (w >> 1);
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-    const int ea = p.amax ? wscale_exp(*p.amax) : 0;
-    const int eb = p.bmax ? wscale_exp(*p.bmax) : 0;
-    const float sa = ldexpf(1.0f, ea), sb = ldexpf(1.0f, eb);
-    const float descale = ldexpf(1.0f, -(ea + eb));
-    const float lima = 65504.0f / sa, limb = 65504.0f / sb;
-
-    // ---- loader.  B tile (64 rows): thread -> (row = tid / 4, 8 consecutive k = (tid % 4) * 8 ..) of the k32 step: a wave
-    // reads 16 full 128-byte row segments per instruction pair.  A tile: the same for BM = 64; for BM = 32 (4 KiB per step)
-    // thread -> (row = tid / 8, 4 consecutive k): one 16-byte load, two 8-byte LDS stores.  Every thread issues the same
-    // loads in the same order every step (no predicated or conditional load: the compiler's vmcnt counting stays exact and
-    // the loads of step t+2 really stay in flight across the conversion of step t+1).
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const int lrow = tid >> 2, kq = tid & 3;
-    const int swl = (lrow >> 1) & 7;
-    const int o_hi = lrow * 128 + ((kq ^ swl) * 16), o_lo = lrow * 128 + (((kq + 4) ^ swl) * 16);
-    const float* bp = p.b + (size_t)(n0 + lrow) * p.ldb + kq * 8;
-    const int arow_l = (BM == 64) ? lrow : (tid >> 3);
-    int ar = m0 + arow_l;
-    if (ar > p.M - 1) ar = p.M - 1;
-    const float* ap = p.a + (size_t)ar * p.lda + ((BM == 64) ? kq * 8 : (tid & 7) * 4);
-    // BM = 32: 4 floats = half a chunk: chunk (tid & 7) >> 1, 8-byte half tid & 1
-    const int swa = (arow_l >> 1) & 7;
-    const int oa_hi = (BM == 64) ? o_hi : arow_l * 128 + (((((tid & 7) >> 1)) ^ swa) * 16) + (tid & 1) * 8;
-    const int oa_lo = (BM == 64) ? o_lo : arow_l * 128 + ((((((tid & 7) >> 1)) + 4) ^ swa) * 16) + (tid & 1) * 8;
-    struct Raw {
-        f32x4 a0, a1, b0, b1;
+    const int tn = w & 1, wk = w >> 1;
+    const int bx = (p.flags & 2) ? blockIdx.y : blockIdx.x, by = (p.flags & 2) ? blockIdx.x : blockIdx.y;
+    const int m0 = by * XG_BM, n0 = bx * XG_BN;
+    const int nk = (p.K + 31) / 32, last = nk - 1;
+    const int rot = (p.flags & 1) ? (bx * 5 + by * 3) % nk : 0;
+    // position i of the k loop -> k-step (rotated start; positions past the end repeat the final one)
+    auto seq = [&](int i) -> int {
+        int t = (i < last ? i : last) + rot;
+        return t >= nk ? t - nk : t;
     };
-    Raw R0, R1;
-    auto gload = [&](Raw& R, int t) {
-        R.a0 = *(const f32x4*)(ap + t * 32);
-        if (BM == 64) R.a1 = *(const f32x4*)(ap + t * 32 + 4);
-        R.b0 = *(const f32x4*)(bp + t * 32);
-        R.b1 = *(const f32x4*)(bp + t * 32 + 4);
-    };
-    auto cstore = [&](const Raw& R, int stage) {
-        char* sbuf = smem + stage * STAGE;
-        u32x4 h, l;
-        if (BM == 64) {
-            conv8(R.a0, R.a1, sa, lima, h, l);
-            *(u32x4*)(sbuf + oa_hi) = h;
-            *(u32x4*)(sbuf + oa_lo) = l;
+
+
+    // ---- loader: every thread issues 3 16-byte loads per k-step (1 of A, 2 of B), full 128 / 256-byte row segments per
+    // 8 / 16 lanes; unconditional, same order every step.  Addresses = a wave-uniform base that moves with the k-step (SGPRs)
+    // + one loop-invariant 32-bit lane offset: NO vector register is written for an address inside the loop (hipcc otherwise
+    // computes it in the destination registers of the load, which it then believes busy: it waited for all but two of the
+    // outstanding requests at the top of every step and the prefetch depth was gone).  Reduction-major operands are read up
+    // to the end of the last k32 step: rows K .. ceil32(K) must be readable (the trainer's buffers are); their contribution
+    // is zeroed in the fragments.
+    unsigned a_off, b_off[2];
+    int a_lds, b_lds[2];
+    size_t a_step, b_step;   // bytes per k-step of the moving base
+    if (ALAY == 0) {
+        const int ra = tid >> 3, ca = tid & 7;
+        int gr = m0 + ra;
+        if (gr > p.M - 1) gr = p.M - 1;
+        a_off = (unsigned)(((size_t)gr * p.lda + ca * 4) * 4);
+        a_lds = ra * 128 + ((ca ^ ((ra >> 1) & 7)) * 16);
+        a_step = 128;
+    } else {
+        const int ak = tid >> 3;
+        a_off = (unsigned)(((size_t)ak * p.lda + m0 + (tid & 7) * 4) * 4);
+        a_lds = ak * 128 + (tid & 7) * 16;
+        a_step = (size_t)p.lda * 128;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        if (BLAY == 0) {
+            const int rb = (tid >> 3) + 32 * jj, cb = tid & 7;
+            b_off[jj] = (unsigned)(((size_t)(n0 + rb) * p.ldb + cb * 4) * 4);
+            b_lds[jj] = XG_A_BYTES + rb * 128 + ((cb ^ ((rb >> 1) & 7)) * 16);
         } else {
-            unsigned h0, l0, h1, l1;
-            mlk::split2_scaled<false>(R.a0[0], R.a0[1], sa, lima, h0, l0);
-            mlk::split2_scaled<false>(R.a0[2], R.a0[3], sa, lima, h1, l1);
-            *(u32x2*)(sbuf + oa_hi) = u32x2{h0, h1};
-            *(u32x2*)(sbuf + oa_lo) = u32x2{l0, l1};
+            const int bk = (tid >> 4) + 16 * jj;
+            b_off[jj] = (unsigned)(((size_t)bk * p.ldb + n0 + (tid & 15) * 4) * 4);
+            b_lds[jj] = XG_A_BYTES + bk * 256 + (tid & 15) * 16;
         }
-        conv8(R.b0, R.b1, sb, limb, h, l);
-        *(u32x4*)(sbuf + A_BYTES + o_hi) = h;
-        *(u32x4*)(sbuf + A_BYTES + o_lo) = l;
+    }
+    b_step = (BLAY == 0) ? 128 : (size_t)p.ldb * 128;
+    struct Raw {
+        f32x4 a, b0, b1;
+    };
+    Raw R0, R1, R2, R3;
+    auto gload = [&](Raw& R, int t) {
+        const char* ab = (const char*)p.a + (size_t)t * a_step;   // wave-uniform
+        const char* bb = (const char*)p.b + (size_t)t * b_step;
+        R.a = *(const f32x4*)(ab + a_off);
+        R.b0 = *(const f32x4*)(bb + b_off[0]);
+        R.b1 = *(const f32x4*)(bb + b_off[1]);
+    };
+    auto lstore = [&](const Raw& R, int stage) {
+        char* sbuf = smem + stage * XG_STAGE;
+        *(f32x4*)(sbuf + a_lds) = R.a;
+        *(f32x4*)(sbuf + b_lds[0]) = R.b0;
+        *(f32x4*)(sbuf + b_lds[1]) = R.b1;
     };
 
-    // ---- fragments
+    // ---- fragments: the 8 k values of this lane for both operands, read one k-step AHEAD of their MFMAs into a second
+    // register set (the LDS latency and the barrier skew hide behind the 512 cycles the previous step's MFMA chain takes)
     const int ml = lane & 31, hh = lane >> 5;
     const int swf = (lane >> 1) & 7;
-    const int a_row = (tm * 32 + ml) * 128, b_row = A_BYTES + (tn * 32 + ml) * 128;
-    f32x16 acc, accx;   // hi.hi and the two cross products on separate accumulators: no MFMA waits for its predecessor
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = accx[e] = 0.f;
-    auto step16 = [&](const char* sbuf, int kk) {
-        const int c_hi = ((kk * 2 + hh) ^ swf) * 16, c_lo = ((kk * 2 + hh + 4) ^ swf) * 16;
-        const half8t ah = *(const half8t*)(sbuf + a_row + c_hi), al = *(const half8t*)(sbuf + a_row + c_lo);
-        const half8t bh = *(const half8t*)(sbuf + b_row + c_hi), bl = *(const half8t*)(sbuf + b_row + c_lo);
-        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx, 0, 0, 0);
+    const int kq = 16 * wk + 8 * hh;   // first of this lane's 8 k values within the step
+    struct Frag {
+        float a[8], b[8];
     };
-    auto compute = [&](int stage) {
-        const char* sbuf = smem + stage * STAGE;
-        if (BM == 64) {
-            step16(sbuf, 0);
-            step16(sbuf, 1);
+    auto fragread = [&](Frag& F, int stage) {
+        const char* sbuf = smem + stage * XG_STAGE;
+        if (ALAY == 0) {
+            const char* row = sbuf + ml * 128;
+            const f32x4 v0 = *(const f32x4*)(row + (((kq >> 2)) ^ swf) * 16), v1 = *(const f32x4*)(row + (((kq >> 2) + 1) ^ swf) * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                F.a[e] = v0[e];
+                F.a[4 + e] = v1[e];
+            }
         } else {
-            step16(sbuf, wk);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) F.a[e] = *(const float*)(sbuf + (kq + e) * 128 + ml * 4);
+        }
+        if (BLAY == 0) {
+            const char* row = sbuf + XG_A_BYTES + (tn * 32 + ml) * 128;
+            const f32x4 v0 = *(const f32x4*)(row + (((kq >> 2)) ^ swf) * 16), v1 = *(const f32x4*)(row + (((kq >> 2) + 1) ^ swf) * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                F.b[e] = v0[e];
+                F.b[4 + e] = v1[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) F.b[e] = *(const float*)(sbuf + XG_A_BYTES + (kq + e) * 256 + (tn * 32 + ml) * 4);
         }
     };
-
-    // two k-steps deep: step t+2 is requested while step t is multiplied and step t+1 sits converted in the other stage.
-    // Unconditional body (loads past the end re-read the last step, the surplus conversion lands in the stage nobody reads).
-    const int nk = p.K / 32;
-    const int last = nk - 1;
-    gload(R0, 0);
-    gload(R1, last < 1 ? last : 1);
-    cstore(R0, 0);
-    __syncthreads();
-    int t = 0;
-    if (p.dbg) {   // timing ablations: the same loop with parts left out (results are garbage)
-        for (; t + 1 < nk; t += 2) {
-            if (!(p.dbg & 1)) gload(R0, t + 2 < last ? t + 2 : last);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(p.dbg & 4)) compute(0);
-            if (!(p.dbg & 2)) cstore(R1, 1);
-            if (!(p.dbg & 8)) __syncthreads();
-            if (!(p.dbg & 1)) gload(R1, t + 3 < last ? t + 3 : last);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(p.dbg & 4)) compute(1);
-            if (!(p.dbg & 2)) cstore(R0, 0);
-            if (!(p.dbg & 8)) __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const bool ragged = (p.K & 31) != 0;
+    // (uniform) the reduction's zero padding: k >= K of the last step -- both operands, whatever lies behind the matrices
+    // (NaN included) contributes exactly 0 -- and the steps that only fill the loop up to a multiple of 4
+    auto mask = [&](Frag& F, int i) {
+        const int t = seq(i);
+        if (i >= nk || (ragged && t == last)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (i >= nk || t * 32 + kq + e >= p.K) {
+                    F.a[e] = 0.f;
+                    F.b[e] = 0.f;
+                }
         }
-    }
-    for (; t + 1 < nk; t += 2) {
-        gload(R0, t + 2 < last ? t + 2 : last);
-        __builtin_amdgcn_sched_barrier(0);   // the requests leave FIRST: hipcc otherwise sinks them behind the conversion
-        compute(0);
-        cstore(R1, 1);       // step t+1; stage 1 was last read one barrier ago
-        __syncthreads();
-        gload(R1, t + 3 < last ? t + 3 : last);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1);
-        cstore(R0, 0);       // step t+2
-        __syncthreads();
-    }
-    if (t < nk) compute(0);  // odd number of steps: the last one sits in stage 0
+    };
+    f32x16 acc2;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] += accx[e];
-
-    bool fin = true;
-    if (BM == 32) {   // the k halves meet: waves 2, 3 hand their partial tile to waves 0, 1
-        float* red = (float*)smem;   // [2][16][64]
-        if (wk == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[(tn * 16 + r) * 64 + lane] = acc[r];
-        }
-        __syncthreads();
-        fin = (wk == 0);
-        if (fin) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += red[(tn * 16 + r) * 64 + lane];
-        }
-    }
-    if (!fin) return;
-
-    // ---- epilogue.  D layout of the 32 x 32 MFMA: lane holds column j = lane & 31 (a B row) and rows
-    // i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (A rows): for a fixed r the lanes 0..31 write 128 contiguous bytes of a row of C
-    const int j = n0 + tn * 32 + ml;
-    const float bj = p.bias ? p.bias[j] : 0.f;
-    const int ibase = m0 + tm * 32 + 4 * hh;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 vt;
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+    auto mma4 = [&](const Frag& F, int e0) {
+        if (ABL & 2) return;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int i = ibase + 8 * g + e;
-            float v = 0.f;
+            if ((ABL & 1) && (e & 1)) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[e0 + e], F.b[e0 + e], acc2, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[e0 + e], F.b[e0 + e], acc, 0, 0, 0);
+        }
+    };
+    // Pipeline.  The operands come from HBM / the last-level cache for the first time (the producer ran on other XCDs): ~0.8 us
+    // per request, against 0.25 us of MFMA time per k-step -- with the rows of only one further step in flight the loop ran at
+    // 0.52 us per step whatever it computed (round 3, profiles/r03_*).  So FOUR register sets: at the top of step t, stage
+    // t & 1 holds step t (its fragments already in registers), the other stage step t+1, and the sets hold the raw rows of
+    // steps t+2 .. t+4, in flight.  A step reads the fragments of step t+1, requests step t+5 into the free set, multiplies
+    // step t and moves step t+2 from its registers into the stage step t leaves (its fragment reads completed before the last
+    // barrier).  Program order inside a step = issue order (an MFMA on the same accumulator blocks the wave's issue for the 64
+    // cycles its predecessor runs, so whatever is to overlap with the chain sits BETWEEN its links): reads + requests, 4 MFMAs,
+    // the LDS stores, 4 MFMAs, barrier (the last MFMA still runs).  Requests past the end repeat the final step; what they
+    // bring is stored and read but never multiplied.
+    Frag F0, F1;
+    auto step = [&](Frag& Fc, Frag& Fn, Raw& Rl, Raw& Rs, int sc, int i) {
+        if (!(ABL & 8)) fragread(Fn, sc ^ 1);             // step i+1
+        if (!(ABL & 4)) gload(Rl, seq(i + 5));
+        mask(Fc, i);
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(Fc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 8)) lstore(Rs, sc);                   // step i+2
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(Fc, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 16)) __syncthreads();
+    };
+    gload(R0, seq(0));
+    gload(R1, seq(1));
+    gload(R2, seq(2));
+    gload(R3, seq(3));
+    lstore(R0, 0);
+    gload(R0, seq(4));
+    lstore(R1, 1);
+    __syncthreads();
+    fragread(F0, 0);
+    for (int i = 0; i < nk; i += 4) {   // whole groups of 4 steps (one exit: no register shuffling between the sets)
+        step(F0, F1, R1, R2, 0, i);
+        step(F1, F0, R2, R3, 1, i + 1);
+        step(F0, F1, R3, R0, 0, i + 2);
+        step(F1, F0, R0, R1, 1, i + 3);
+    }
+    __syncthreads();
+    if (ABL & 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
+    }
+
+    // ---- the k halves meet: waves 2, 3 hand their partial tile to waves 0, 1
+    float* red = (float*)smem;   // [2][16][64]
+    if (wk == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(tn * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    double ss = 0.0;
+    if (wk == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(tn * 16 + r) * 64 + lane];
+        // D layout of the 32 x 32 MFMA: lane holds column j = lane & 31 (a B row) and rows i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        // (A rows): for a fixed r the lanes 0..31 write 128 contiguous bytes of a row of C
+        const int j = n0 + tn * 32 + ml;
+        const float bj = p.bias ? p.bias[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (i < p.M) {
-                v = acc[g * 4 + e] * descale + bj;
+                float v = acc[r] + bj;
                 const size_t o = (size_t)i * p.ldc + j;
                 if (p.res) v += p.res[o];
                 p.c[o] = v;
+                ss += (double)v * (double)v;
             }
-            vt[e] = v;
         }
-        if (p.ct) {
-            const int i0 = ibase + 8 * g;
-            if (i0 < p.ldct) *(f32x4*)(p.ct + (size_t)j * p.ldct + i0) = vt;
-        }
+    }
+    if (p.sumsq) {   // (uniform) fixed-order sum over the workgroup: lanes by butterfly, then the two finishing waves
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (lane == 0) wsum[w] = ss;
+        __syncthreads();
+        if (tid == 0) p.sumsq[(size_t)by * (p.N / XG_BN) + bx] = wsum[0] + wsum[1];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Forward of one block Linear -> BatchNorm1d (train mode) -> ReLU -> Dropout (-> + residual), everything behind the GEMM
-// (reference architectures.py:50-52, 90-100).  One workgroup per 16 columns, all rows: thread = (row r = tid / 4 + 64 pass,
-// 4 columns) -- 64-byte row segments.  Pass 1: column sums in fp64; pass 2: the activation, written row-major and (through
-// a 16 x 64 LDS tile) transposed.  Input-layer mode (x_in != null): z = x_in . w_in^T + b_in is computed here (the narrow
-// product of train_kernels.h' skinny_out_kernel, same fma order) and written to z_out.
+// (reference architectures.py:50-52, 90-100).  One workgroup per NC columns, ALL rows: thread = (row, 4 columns); a thread
+// requests its up to AP_PMAX rows before using the first (larger batches walk in chunks of that and re-read).  Column sums
+// in fp64: per thread over its rows, butterfly over the lanes that share the columns, then the four waves in order.
+// Input-layer mode (x_in != null): z = x_in . w_in^T + b_in is computed here (train_kernels.h' skinny_out_kernel's fma
+// order) and written to z_out.
 struct FwdApplyParams {
     const float* z;
     const float* x_in;
@@ -252,7 +284,6 @@ struct FwdApplyParams {
     int in_dim;
     long m;
     int H;
-    long ldt;
     const float* gamma;
     const float* beta;
     float* run_mean;
@@ -263,59 +294,106 @@ struct FwdApplyParams {
     uint32_t seed, site;
     const float* residual;
     float* y;
-    float* yT;           // [H][ldt] or null
-    float* zero_words;   // optional: block 0 zeroes n_zero floats (the next step's max |W| words)
-    int n_zero;
 };
 
+// rows a workgroup of the column-owner kernels holds in registers at once (512: the reference's default batch); per thread
+// 512 / (rows per pass) = NC / 2 rows of 4 columns
+constexpr int AP_CHUNK = 512;
+
+// sums of v[q][0..4) over the threads of the workgroup that own the same 4 columns (lanes == cq mod TPR), fixed order:
+// butterfly inside each wave, then red[q][wave][column]; the caller adds the four waves after a barrier
+template <int NC, int NV>
+__device__ __forceinline__ void column_reduce(double (&v)[NV][4], double (*red)[4][NC], int tid) {
+    constexpr int TPR = NC / 4;
+    const int lane = tid & 63, wv = tid >> 6, cq = tid % TPR;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double s = v[q][e];
+#pragma unroll
+            for (int o = TPR; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+            v[q][e] = s;
+        }
+    if (lane < TPR) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[q][wv][cq * 4 + e] = v[q][e];
+    }
+}
+
+template <int NC>
 __global__ __launch_bounds__(256) void fwd_apply_kernel(FwdApplyParams p) {
-    __shared__ double r1[64][17], r2[64][17];
-    __shared__ float stat[2][16];
-    __shared__ __attribute__((aligned(16))) float tile[16][68];
-    __shared__ float wl[16 * SK_NC];
-    const int tid = threadIdx.x, cq = tid & 3, r = tid >> 2;
-    const int j0 = blockIdx.x * 16, j = j0 + cq * 4;
+    constexpr int TPR = NC / 4, RPP = 256 / TPR, AP_PMAX = AP_CHUNK / RPP;
+    __shared__ double red[2][4][NC];
+    __shared__ float stat[2][NC];
+    __shared__ float wl[NC * SK_NC];
+    const int tid = threadIdx.x, cq = tid % TPR, r = tid / TPR;
+    const int j0 = blockIdx.x * NC, j = j0 + cq * 4;
     const int H = p.H;
     const bool inl = p.x_in != nullptr;
-    if (p.zero_words && blockIdx.x == 0 && tid < p.n_zero) p.zero_words[tid] = 0.f;
     if (inl) {
-        for (int idx = tid; idx < 16 * p.in_dim; idx += 256) wl[idx] = p.w_in[(size_t)j0 * p.in_dim + idx];
+        for (int idx = tid; idx < NC * p.in_dim; idx += 256) wl[idx] = p.w_in[(size_t)j0 * p.in_dim + idx];
         __syncthreads();
     }
     const float* zsrc = inl ? p.z_out : p.z;
-    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-    for (long i = r; i < p.m; i += 64) {
-        f32x4 v;
-        if (inl) {
-            v = *(const f32x4*)(p.b_in + j);
-            const float* xr = p.x_in + i * p.in_dim;
-            for (int c = 0; c < p.in_dim; ++c) {
-                const float xv = xr[c];
+    const long chunk = (long)RPP * AP_PMAX;
+    const bool single = p.m <= chunk;
+    // everything that does not depend on the statistics is requested NOW (each global load costs ~1 us here: the producer ran
+    // on other XCDs; three of them used to stand one after the other behind the reduction)
+    const f32x4 ga = *(const f32x4*)(p.gamma + j), be = *(const f32x4*)(p.beta + j);
+    float rmean = 0.f, rvar = 0.f;
+    if (tid < NC) {
+        rmean = p.run_mean[j0 + tid];
+        rvar = p.run_var[j0 + tid];
+    }
+    f32x4 rr[AP_PMAX];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv, wl[(cq * 4 + e) * p.in_dim + c], v[e]);
+    for (int q = 0; q < AP_PMAX; ++q) {
+        const long i = q * RPP + r;
+        rr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (single && p.residual && i < p.m) rr[q] = *(const f32x4*)(p.residual + i * H + j);
+    }
+    f32x4 zr[AP_PMAX];
+    double s[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    for (long base = 0; base < p.m; base += chunk) {
+#pragma unroll
+        for (int q = 0; q < AP_PMAX; ++q) {
+            const long i = base + q * RPP + r;
+            zr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < p.m) {
+                if (inl) {
+                    f32x4 v = *(const f32x4*)(p.b_in + j);
+                    const float* xr = p.x_in + i * p.in_dim;
+                    for (int c = 0; c < p.in_dim; ++c) {
+                        const float xv = xr[c];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(xv, wl[(cq * 4 + e) * p.in_dim + c], v[e]);
+                    }
+                    *(f32x4*)(p.z_out + i * H + j) = v;
+                    zr[q] = v;
+                } else {
+                    zr[q] = *(const f32x4*)(p.z + i * H + j);
+                }
             }
-            *(f32x4*)(p.z_out + i * H + j) = v;
-        } else {
-            v = *(const f32x4*)(p.z + i * H + j);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[e] += (double)v[e];
-            b[e] += (double)v[e] * (double)v[e];
+        for (int q = 0; q < AP_PMAX; ++q) {
+            if (base + q * RPP + r < p.m) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[0][e] += (double)zr[q][e];
+                    s[1][e] += (double)zr[q][e] * (double)zr[q][e];
+                }
+            }
         }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        r1[r][cq * 4 + e] = a[e];
-        r2[r][cq * 4 + e] = b[e];
-    }
+    column_reduce<NC, 2>(s, red, tid);
     __syncthreads();
-    if (tid < 16) {
-        double sa = 0.0, sb = 0.0;
-        for (int g = 0; g < 64; ++g) {
-            sa += r1[g][tid];
-            sb += r2[g][tid];
-        }
+    if (tid < NC) {
+        const double sa = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+        const double sb = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
         // bn_finalize_kernel's arithmetic (train_kernels.h)
         const double mu = sa / (double)p.m;
         double var = sb / (double)p.m - mu * mu;
@@ -325,8 +403,8 @@ __global__ __launch_bounds__(256) void fwd_apply_kernel(FwdApplyParams p) {
         const int jj = j0 + tid;
         p.mean_out[jj] = mean;
         p.invstd_out[jj] = inv;
-        p.run_mean[jj] = (1.f - 0.1f) * p.run_mean[jj] + 0.1f * (float)mu;
-        p.run_var[jj] = (1.f - 0.1f) * p.run_var[jj] + 0.1f * (float)unb;
+        p.run_mean[jj] = (1.f - 0.1f) * rmean + 0.1f * (float)mu;
+        p.run_var[jj] = (1.f - 0.1f) * rvar + 0.1f * (float)unb;
         stat[0][tid] = mean;
         stat[1][tid] = inv;
     }
@@ -337,36 +415,37 @@ __global__ __launch_bounds__(256) void fwd_apply_kernel(FwdApplyParams p) {
         mu[e] = stat[0][cq * 4 + e];
         is[e] = stat[1][cq * 4 + e];
     }
-    const f32x4 ga = *(const f32x4*)(p.gamma + j), be = *(const f32x4*)(p.beta + j);
-    const long npass = ((p.yT ? p.ldt : p.m) + 63) / 64;
-    for (long ps = 0; ps < npass; ++ps) {
-        const long i = ps * 64 + r;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (i < p.m) {
-            v = *(const f32x4*)(zsrc + i * H + j);
+    for (long base = 0; base < p.m; base += chunk) {
+        if (!single) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {   // bn_relu_drop_kernel's arithmetic
-                float t = ga[e] * ((v[e] - mu[e]) * is[e]) + be[e];
-                t = t > 0.f ? t : 0.f;
-                if (p.p_drop > 0.f)
-                    t = (mlk::u01(p.seed, (uint32_t)i * 4099u + p.site, (uint32_t)(j + e)) >= p.p_drop) ? t / (1.f - p.p_drop) : 0.f;
-                v[e] = t;
+            for (int q = 0; q < AP_PMAX; ++q) {
+                const long i = base + q * RPP + r;
+                rr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i < p.m) {
+                    zr[q] = *(const f32x4*)(zsrc + i * H + j);
+                    if (p.residual) rr[q] = *(const f32x4*)(p.residual + i * H + j);
+                }
             }
-            if (p.residual) {
-                const f32x4 rr = *(const f32x4*)(p.residual + i * H + j);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += rr[e];
-            }
-            *(f32x4*)(p.y + i * H + j) = v;
         }
-        if (p.yT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tile[cq * 4 + e][r] = v[e];
-            __syncthreads();
-            const int c = tid >> 4, rq = tid & 15;
-            const long it = ps * 64 + rq * 4;
-            if (it < p.ldt) *(f32x4*)(p.yT + (size_t)(j0 + c) * p.ldt + it) = *(const f32x4*)&tile[c][rq * 4];
-            __syncthreads();
+        for (int q = 0; q < AP_PMAX; ++q) {
+            const long i = base + q * RPP + r;
+            if (i < p.m) {
+                f32x4 v = zr[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {   // bn_relu_drop_kernel's arithmetic
+                    float t = ga[e] * ((v[e] - mu[e]) * is[e]) + be[e];
+                    t = t > 0.f ? t : 0.f;
+                    if (p.p_drop > 0.f)
+                        t = (mlk::u01(p.seed, (uint32_t)i * 4099u + p.site, (uint32_t)(j + e)) >= p.p_drop) ? t / (1.f - p.p_drop) : 0.f;
+                    v[e] = t;
+                }
+                if (p.residual) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rr[q][e];
+                }
+                *(f32x4*)(p.y + i * H + j) = v;
+            }
         }
     }
 }
@@ -376,11 +455,11 @@ __global__ __launch_bounds__(256) void fwd_apply_kernel(FwdApplyParams p) {
 //   dy   = incoming * [gamma * xhat + beta > 0] * dropout_mask / (1 - p),   xhat = (z - mean) * invstd      (bwd_elem)
 //   dz   = gamma * invstd / m * (m * dy - sum(dy) - xhat * sum(dy * xhat))                                  (bn_bwd_fused_kernel)
 //   dgamma = sum(dy * xhat), dbeta = sum(dy), dbias (of the Linear) = sum(dz)
-// One workgroup per 16 columns, all rows; the incoming gradient is re-derived in both passes:
+// The incoming gradient comes
 //   * from dy (a buffer), optionally + aux_d[i] * w_aux[j] (the one-output head's data gradient, skinny_out_kernel's
 //     accumulate form), or
 //   * from the output heads: sum_c dout[i][c] * w_head[c][j]  (skinny_out_kernel's fma order).
-// z == null: a Linear without BatchNorm (w2): dz = dy.  Writes dz row-major and transposed and folds max |dz| into a word.
+// z == null: a Linear without BatchNorm (w2): dz = dy.
 struct BwdApplyParams {
     const float* dy;
     const float* dout;
@@ -398,81 +477,120 @@ struct BwdApplyParams {
     uint32_t seed, site;
     long m;
     int H;
-    long ldt;
     float* dz;
-    float* dzT;     // [H][ldt] or null
     float* dgamma;
     float* dbeta;
     float* dbias;
-    float* dzmax;   // word or null
+    // narrow weight gradients that ride along (each optional):
+    //  * of an output head that reads this block's forward activation ysrc (m x H):  dwh[c][j] = sum_i sc[i * sld + c] * ysrc[i][j],
+    //    c < ns <= 9 (w_fin: sc = dout, ysrc = y3; w_aux: sc = dout + C - 1, ysrc = y2)   (train_kernels.h: skinny_dw_kernel)
+    //  * the head biases (workgroup 0): hb0[c] = sum_i dout[i][c], c < hb_n0;  hb1[0] = sum_i dout[i][hb_n0]
+    const float* sc;
+    int sld, ns;
+    const float* ysrc;
+    float* dwh;
+    const float* hb_src;
+    int hb_ld, hb_n0;
+    float* hb0;
+    float* hb1;
 };
 
-__device__ __forceinline__ f32x4 bwd_incoming(const BwdApplyParams& p, long i, int j, const float* wh /* LDS [nc][16] */, int cq) {
-    f32x4 v;
-    if (p.dout) {
-        v = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* dr = p.dout + i * p.dld;
-        for (int c = 0; c < p.nc; ++c) {
-            const float s = dr[c];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(s, wh[c * 16 + cq * 4 + e], v[e]);
-        }
-    } else {
-        v = *(const f32x4*)(p.dy + i * p.H + j);
-    }
-    if (p.aux_d) {
-        const float s = p.aux_d[i * p.aux_ld];
-        const f32x4 wa = *(const f32x4*)(p.w_aux + j);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(s, wa[e], 0.f) + v[e];
-    }
-    return v;
-}
-
+template <int NC>
 __global__ __launch_bounds__(256) void bwd_apply_kernel(BwdApplyParams p) {
-    __shared__ double r1[64][17], r2[64][17];
-    __shared__ float stat[2][16];
-    __shared__ __attribute__((aligned(16))) float tile[16][68];
-    __shared__ float wh[16 * 16];   // head weights of these 16 columns, [c][16]
-    const int tid = threadIdx.x, cq = tid & 3, r = tid >> 2;
-    const int j0 = blockIdx.x * 16, j = j0 + cq * 4;
+    constexpr int TPR = NC / 4, RPP = 256 / TPR, AP_PMAX = AP_CHUNK / RPP;
+    __shared__ double red[2][4][NC];
+    __shared__ float stat[2][NC];
+    __shared__ float wh[16 * NC];   // head weights of these columns, [c][NC]
+    __shared__ float redf[9][4][NC];
+    const int tid = threadIdx.x, cq = tid % TPR, r = tid / TPR;
+    const int j0 = blockIdx.x * NC, j = j0 + cq * 4;
     const int H = p.H;
     const bool bn = p.z != nullptr;
     if (p.dout) {
-        for (int idx = tid; idx < p.nc * 16; idx += 256) wh[idx] = p.w_head[(size_t)(idx >> 4) * H + j0 + (idx & 15)];
+        for (int idx = tid; idx < p.nc * NC; idx += 256) wh[idx] = p.w_head[(size_t)(idx / NC) * H + j0 + (idx % NC)];
         __syncthreads();
     }
+    const long chunk = (long)RPP * AP_PMAX;
+    const bool single = p.m <= chunk;
+    f32x4 dr[AP_PMAX], zr[AP_PMAX];
+    // incoming gradient and pre-activation of up to AP_PMAX rows of this thread: every load is requested before the first use
+    auto fetch = [&](long base) {
+#pragma unroll
+        for (int q = 0; q < AP_PMAX; ++q) {
+            const long i = base + q * RPP + r;
+            dr[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            zr[q] = dr[q];
+            if (i < p.m) {
+                if (bn) zr[q] = *(const f32x4*)(p.z + i * H + j);
+                if (!p.dout) dr[q] = *(const f32x4*)(p.dy + i * H + j);
+            }
+        }
+        if (p.dout) {
+#pragma unroll
+            for (int q = 0; q < AP_PMAX; ++q) {
+                const long i = base + q * RPP + r;
+                if (i < p.m) {
+                    const float* drow = p.dout + i * p.dld;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    for (int c = 0; c < p.nc; ++c) {
+                        const float sv = drow[c];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(sv, wh[c * NC + cq * 4 + e], v[e]);
+                    }
+                    dr[q] = v;
+                }
+            }
+        }
+        if (p.aux_d) {
+            const f32x4 wa = *(const f32x4*)(p.w_aux + j);
+#pragma unroll
+            for (int q = 0; q < AP_PMAX; ++q) {
+                const long i = base + q * RPP + r;
+                if (i < p.m) {
+                    const float sv = p.aux_d[i * p.aux_ld];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dr[q][e] = __builtin_fmaf(sv, wa[e], 0.f) + dr[q][e];
+                }
+            }
+        }
+    };
     f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, ga = mu, be = mu;
     float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (single) fetch(0);
+    f32x4 yv[AP_PMAX];   // rows of the forward activation a riding head-weight gradient needs: requested with everything else
+#pragma unroll
+    for (int q = 0; q < AP_PMAX; ++q) {
+        const long i = q * RPP + r;
+        yv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (single && p.dwh && i < p.m) yv[q] = *(const f32x4*)(p.ysrc + i * H + j);
+    }
     if (bn) {
         mu = *(const f32x4*)(p.mean + j);
         is = *(const f32x4*)(p.invstd + j);
         ga = *(const f32x4*)(p.gamma + j);
         be = *(const f32x4*)(p.beta + j);
-        double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-        for (long i = r; i < p.m; i += 64) {
-            const f32x4 d = bwd_incoming(p, i, j, wh, cq);
-            const f32x4 zz = *(const f32x4*)(p.z + i * H + j);
+        double s[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        for (long base = 0; base < p.m; base += chunk) {
+            if (!single) fetch(base);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float dy, xh;
-                bwd_elem(d[e], zz[e], mu[e], is[e], ga[e], be[e], p.p_drop, p.seed, p.site, i, j + e, dy, xh);
-                a[e] += (double)dy;
-                b[e] += (double)dy * (double)xh;
+            for (int q = 0; q < AP_PMAX; ++q) {
+                const long i = base + q * RPP + r;
+                if (i < p.m) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float dy, xh;
+                        bwd_elem(dr[q][e], zr[q][e], mu[e], is[e], ga[e], be[e], p.p_drop, p.seed, p.site, i, j + e, dy, xh);
+                        s[0][e] += (double)dy;
+                        s[1][e] += (double)dy * (double)xh;
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            r1[r][cq * 4 + e] = a[e];
-            r2[r][cq * 4 + e] = b[e];
-        }
+        column_reduce<NC, 2>(s, red, tid);
         __syncthreads();
-        if (tid < 16) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int g = 0; g < 64; ++g) {
-                s1 += r1[g][tid];
-                s2 += r2[g][tid];
-            }
+        if (tid < NC) {
+            const double s1 = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
+            const double s2 = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
             stat[0][tid] = (float)s1;
             stat[1][tid] = (float)s2;
             p.dbeta[j0 + tid] = (float)s1;
@@ -486,222 +604,135 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(BwdApplyParams p) {
             gg[e] = ga[e] * is[e] / (float)p.m;
         }
     }
-    double a2[4] = {0.0, 0.0, 0.0, 0.0};
-    float mx = 0.f;
-    const long npass = ((p.dzT ? p.ldt : p.m) + 63) / 64;
-    for (long ps = 0; ps < npass; ++ps) {
-        const long i = ps * 64 + r;
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        if (i < p.m) {
-            const f32x4 d = bwd_incoming(p, i, j, wh, cq);
-            if (bn) {
-                const f32x4 zz = *(const f32x4*)(p.z + i * H + j);
+    double s2[1][4] = {{0.0, 0.0, 0.0, 0.0}};
+    for (long base = 0; base < p.m; base += chunk) {
+        if (!single) fetch(base);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float dy, xh;
-                    bwd_elem(d[e], zz[e], mu[e], is[e], ga[e], be[e], p.p_drop, p.seed, p.site, i, j + e, dy, xh);
-                    o[e] = gg[e] * ((float)p.m * dy - sa[e] - xh * sb[e]);
+        for (int q = 0; q < AP_PMAX; ++q) {
+            const long i = base + q * RPP + r;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (i < p.m) {
+                o = dr[q];
+                if (bn) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float dy, xh;
+                        bwd_elem(dr[q][e], zr[q][e], mu[e], is[e], ga[e], be[e], p.p_drop, p.seed, p.site, i, j + e, dy, xh);
+                        o[e] = gg[e] * ((float)p.m * dy - sa[e] - xh * sb[e]);
+                    }
                 }
-            } else {
-                o = d;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s2[0][e] += (double)o[e];
+                *(f32x4*)(p.dz + i * H + j) = o;
             }
+        }
+    }
+    __syncthreads();   // (red is read above by the threads tid < NC)
+    column_reduce<NC, 1>(s2, red, tid);
+    __syncthreads();
+    if (tid < NC) p.dbias[j0 + tid] = (float)((red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]));
+
+    // ---- a head's weight gradient from this block's forward activation (fp32 fma per thread over its rows, then the fixed
+    // order reduction over the threads that share the columns)
+    if (p.dwh) {   // (uniform)
+        float acc[9][4];
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c][e] = 0.f;
+        for (long base = 0; base < p.m; base += chunk) {
+            if (!single) {
+#pragma unroll
+                for (int q = 0; q < AP_PMAX; ++q) {
+                    const long i = base + q * RPP + r;
+                    yv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (i < p.m) yv[q] = *(const f32x4*)(p.ysrc + i * H + j);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < AP_PMAX; ++q) {
+                const long i = base + q * RPP + r;
+                if (i < p.m) {
+                    const float* srow = p.sc + i * p.sld;
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) {
+                        if (c < p.ns) {
+                            const float sv = srow[c];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(sv, yv[q][e], acc[c][e]);
+                        }
+                    }
+                }
+            }
+        }
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                a2[e] += (double)o[e];
-                mx = __builtin_fmaxf(mx, __builtin_fabsf(o[e]));
+                float v = acc[c][e];
+#pragma unroll
+                for (int o = TPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (lane < TPR) redf[c][wv][cq * 4 + e] = v;
             }
-            *(f32x4*)(p.dz + i * H + j) = o;
-        }
-        if (p.dzT) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tile[cq * 4 + e][r] = o[e];
-            __syncthreads();
-            const int c = tid >> 4, rq = tid & 15;
-            const long it = ps * 64 + rq * 4;
-            if (it < p.ldt) *(f32x4*)(p.dzT + (size_t)(j0 + c) * p.ldt + it) = *(const f32x4*)&tile[c][rq * 4];
-            __syncthreads();
+        __syncthreads();
+        for (int idx = tid; idx < p.ns * NC; idx += 256) {
+            const int c = idx / NC, col = idx - c * NC;
+            p.dwh[(size_t)c * H + j0 + col] = (redf[c][0][col] + redf[c][1][col]) + (redf[c][2][col] + redf[c][3][col]);
         }
     }
-    __syncthreads();
+    // ---- the head biases: column sums of dout (workgroup 0; one thread per row walks it, fp64)
+    if (p.hb0 && blockIdx.x == 0) {
+        __shared__ double redb[16][4];
+        double hs[16];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r1[r][cq * 4 + e] = a2[e];
-    __syncthreads();
-    if (tid < 16) {
-        double s = 0.0;
-        for (int g = 0; g < 64; ++g) s += r1[g][tid];
-        p.dbias[j0 + tid] = (float)s;
-    }
-    if (p.dzmax) {
+        for (int c = 0; c < 16; ++c) hs[c] = 0.0;
+        for (long i = tid; i < p.m; i += 256) {
+            const float* srow = p.hb_src + i * p.hb_ld;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
-        if ((tid & 63) == 0) {
-            if (!(mx < 3.0e38f)) mx = 3.0e38f;
-            atomicMax((unsigned*)p.dzmax, __builtin_bit_cast(unsigned, mx));
+            for (int c = 0; c < 16; ++c)
+                if (c <= p.hb_n0) hs[c] += (double)srow[c];
+        }
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            double v = hs[c];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) redb[c][wv] = v;
+        }
+        __syncthreads();
+        if (tid <= p.hb_n0) {
+            const float v = (float)((redb[tid][0] + redb[tid][1]) + (redb[tid][2] + redb[tid][3]));
+            if (tid < p.hb_n0) p.hb0[tid] = v;
+            else p.hb1[0] = v;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Optimizer.  clip_adam_kernel's arithmetic (clip_grad_norm_(3) + torch.optim.Adam defaults), on
-//   * the H x H matrices in 64 x 64 tiles: W, m1, m2, the clipped gradient, AND W^T (through LDS) and max |W| of the new
-//     weights (what the next step's GEMMs scale by);
-//   * everything else through a segment table.
+// Gradient norm^2 for clip_grad_norm_: the weight-gradient GEMMs leave one partial sum of squares per workgroup (nslots
+// doubles); the narrow tensors (everything that is not an H x H matrix: `segs`) are summed here.  Fixed order at both
+// levels: the same gradients always give the same norm (the exact route's sumsq_kernel adds with atomics).
 constexpr int MID_MAXMAT = 40;
-struct AdamMats {
-    long off[MID_MAXMAT];   // flat offsets of the H x H weight matrices
-    int count;
-};
 struct AdamSegs {
-    long off[MID_MAXMAT];     // flat offset of each segment
+    long off[MID_MAXMAT];         // flat offset of each segment
     long start[MID_MAXMAT + 1];   // prefix sums of the segment lengths
     int count;
 };
-struct AdamHyper {
-    const double* sumsq;
-    float max_norm, lr, b1, b2, eps, bc1, bc2;
-    int do_adam;
-};
 
-__device__ __forceinline__ float adam_elem(float& w, float g, float& m1, float& m2, float coef, const AdamHyper& hp) {
-    const float gi = g * coef;
-    if (hp.do_adam) {
-        const float a = m1 + (gi - m1) * (1.f - hp.b1);  // exp_avg.lerp_(grad, 1 - beta1)
-        const float v = hp.b2 * m2 + (1.f - hp.b2) * gi * gi;
-        m1 = a;
-        m2 = v;
-        const float denom = sqrtf(v) / sqrtf(hp.bc2) + hp.eps;
-        w -= (hp.lr / hp.bc1) * (a / denom);
-    }
-    return gi;
-}
-__device__ __forceinline__ float clip_coef(const AdamHyper& hp) {
-    const float norm = (float)sqrt(*hp.sumsq);
-    float coef = hp.max_norm / (norm + 1e-6f);
-    return coef > 1.f ? 1.f : coef;
-}
-
-__global__ __launch_bounds__(256) void adam_tile_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m1,
-                                                       float* __restrict__ m2, AdamMats mats, int H, float* __restrict__ wT,
-                                                       float* __restrict__ wmax, AdamHyper hp) {
-    __shared__ float tile[64][65];   // [column][row]
-    const int tid = threadIdx.x, cq = tid & 15, r = tid >> 4;
-    const int TR = H / 64;
-    const int tr = blockIdx.x / TR, tc = blockIdx.x - tr * TR;
-    const long base = mats.off[blockIdx.y];
-    const float coef = clip_coef(hp);
-    float mx = 0.f;
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int row = ps * 16 + r;
-        const long idx = base + (long)(tr * 64 + row) * H + tc * 64 + cq * 4;
-        f32x4 wv = *(const f32x4*)(w + idx), gv = *(const f32x4*)(g + idx);
-        f32x4 av = {0.f, 0.f, 0.f, 0.f}, vv = av;
-        if (hp.do_adam) {
-            av = *(const f32x4*)(m1 + idx);
-            vv = *(const f32x4*)(m2 + idx);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float we = wv[e], ae = av[e], ve = vv[e];
-            gv[e] = adam_elem(we, gv[e], ae, ve, coef, hp);
-            wv[e] = we;
-            av[e] = ae;
-            vv[e] = ve;
-            tile[cq * 4 + e][row] = we;
-            mx = __builtin_fmaxf(mx, __builtin_fabsf(we));
-        }
-        *(f32x4*)(g + idx) = gv;
-        if (hp.do_adam) {
-            *(f32x4*)(w + idx) = wv;
-            *(f32x4*)(m1 + idx) = av;
-            *(f32x4*)(m2 + idx) = vv;
-        }
-    }
-    if (!hp.do_adam) return;   // (uniform) the weights did not move: W^T and max |W| stay valid
-    __syncthreads();
-    float* dstT = wT + (size_t)blockIdx.y * H * H;
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int c = ps * 16 + r;   // column of W = row of W^T
-        const f32x4 o = {tile[c][cq * 4], tile[c][cq * 4 + 1], tile[c][cq * 4 + 2], tile[c][cq * 4 + 3]};
-        *(f32x4*)(dstT + (size_t)(tc * 64 + c) * H + tr * 64 + cq * 4) = o;
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((tid & 63) == 0) {
-        if (!(mx < 3.0e38f)) mx = 3.0e38f;
-        atomicMax((unsigned*)(wmax + blockIdx.y), __builtin_bit_cast(unsigned, mx));
-    }
-}
-
-__global__ __launch_bounds__(256) void adam_small_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m1,
-                                                        float* __restrict__ m2, AdamSegs segs, AdamHyper hp) {
-    const long id = (long)blockIdx.x * 256 + threadIdx.x;
-    if (id >= segs.start[segs.count]) return;
-    int s = 0;
-    while (s + 1 < segs.count && id >= segs.start[s + 1]) ++s;
-    const long i = segs.off[s] + (id - segs.start[s]);
-    const float coef = clip_coef(hp);
-    float we = w[i], ae = 0.f, ve = 0.f;
-    if (hp.do_adam) {
-        ae = m1[i];
-        ve = m2[i];
-    }
-    g[i] = adam_elem(we, g[i], ae, ve, coef, hp);
-    if (hp.do_adam) {
-        w[i] = we;
-        m1[i] = ae;
-        m2[i] = ve;
-    }
-}
-
-// W^T and max |W| of every H x H matrix from W (after set_tensor / load_state_dict; the words are zeroed by the caller)
-__global__ __launch_bounds__(256) void wt_refresh_kernel(const float* __restrict__ w, AdamMats mats, int H, float* __restrict__ wT,
-                                                        float* __restrict__ wmax) {
-    __shared__ float tile[64][65];
-    const int tid = threadIdx.x, cq = tid & 15, r = tid >> 4;
-    const int TR = H / 64;
-    const int tr = blockIdx.x / TR, tc = blockIdx.x - tr * TR;
-    const long base = mats.off[blockIdx.y];
-    float mx = 0.f;
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int row = ps * 16 + r;
-        const f32x4 wv = *(const f32x4*)(w + base + (long)(tr * 64 + row) * H + tc * 64 + cq * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            tile[cq * 4 + e][row] = wv[e];
-            mx = __builtin_fmaxf(mx, __builtin_fabsf(wv[e]));
-        }
-    }
-    __syncthreads();
-    float* dstT = wT + (size_t)blockIdx.y * H * H;
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int c = ps * 16 + r;
-        const f32x4 o = {tile[c][cq * 4], tile[c][cq * 4 + 1], tile[c][cq * 4 + 2], tile[c][cq * 4 + 3]};
-        *(f32x4*)(dstT + (size_t)(tc * 64 + c) * H + tr * 64 + cq * 4) = o;
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((tid & 63) == 0) {
-        if (!(mx < 3.0e38f)) mx = 3.0e38f;
-        atomicMax((unsigned*)(wmax + blockIdx.y), __builtin_bit_cast(unsigned, mx));
-    }
-}
-
-// sum of squares of a flat fp32 buffer with 16-byte loads (the gradient norm); n % 4 tail by block 0
-__global__ __launch_bounds__(256) void sumsq4_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
+constexpr int GN_PARTS = 64;
+// level 1: GN_PARTS workgroups, each a strided share of the slots and of every narrow segment -> part[blockIdx.x]
+__global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__ g, AdamSegs segs, const double* __restrict__ slots, int nslots,
+                                                       double* __restrict__ part) {
     __shared__ double red[256];
-    double a = 0;
-    const int64_t n4 = n >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const f32x4 v = *(const f32x4*)(g + i * 4);
-        a += ((double)v[0] * (double)v[0] + (double)v[1] * (double)v[1]) + ((double)v[2] * (double)v[2] + (double)v[3] * (double)v[3]);
-    }
-    if (blockIdx.x == 0 && (int64_t)threadIdx.x < (n & 3)) {
-        const double v = (double)g[n4 * 4 + threadIdx.x];
-        a += v * v;
+    const int gt = blockIdx.x * 256 + threadIdx.x, gn = GN_PARTS * 256;
+    double a = 0.0;
+    for (int i = gt; i < nslots; i += gn) a += slots[i];
+    for (int s = 0; s < segs.count; ++s) {
+        const float* gs = g + segs.off[s];
+        const long n = segs.start[s + 1] - segs.start[s];
+        for (long i = gt; i < n; i += gn) a += (double)gs[i] * (double)gs[i];
     }
     red[threadIdx.x] = a;
     __syncthreads();
@@ -709,7 +740,36 @@ __global__ __launch_bounds__(256) void sumsq4_kernel(const float* __restrict__ g
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// level 2 inside the optimizer: every workgroup adds the GN_PARTS partial sums in the same order.  clip_adam_kernel's arithmetic.
+__global__ __launch_bounds__(256) void clip_adam_parts_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m1,
+                                                             float* __restrict__ m2, int64_t n, const double* __restrict__ part,
+                                                             float max_norm, float lr, float b1, float b2, float eps, float bc1,
+                                                             float bc2, int do_adam) {
+    __shared__ double tot;
+    if (threadIdx.x < 64) {
+        double v = part[threadIdx.x];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (threadIdx.x == 0) tot = v;
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float norm = (float)sqrt(tot);
+    float coef = max_norm / (norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    const float gi = g[i] * coef;
+    g[i] = gi;
+    if (!do_adam) return;
+    const float a = m1[i] + (gi - m1[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = b2 * m2[i] + (1.f - b2) * gi * gi;
+    m1[i] = a;
+    m2[i] = v;
+    const float denom = sqrtf(v) / sqrtf(bc2) + eps;
+    w[i] -= (lr / bc1) * (a / denom);
 }
 
 }  // namespace mlt

@@ -26,13 +26,6 @@ def compare(hidden, m, p_drop, mode='mono'):
         bufs[route]['out'] = out.cpu()
         bufs[route]['dout'] = tr.debug_read(201, (m, out_f))
         res[route] = (r, tr.grads(), tr.last_route)
-        if route == 'mid':
-            for i, n in enumerate(names[:2 * S + 1]):   # transposed copies of a_s, t_s
-                tT = tr.debug_read(100 + i, (hidden, (m + 31) // 32 * 32))
-                ok = torch.equal(tT[:, :m], bufs[route][n].t()) and bool((tT[:, m:] == 0).all())
-                if not ok:
-                    print('   TRANSPOSED COPY of %s WRONG' % n)
-            print('   max|dz| words', tr.debug_read(401, (16,)).tolist()[:10])
         tr.close()
     print('hidden %d rows %d p_drop %.1f %s  routes %s %s  loss %.6f %.6f' % (hidden, m, p_drop, mode, res['exact'][2], res['mid'][2],
                                                                            res['exact'][0]['loss'], res['mid'][0]['loss']))
@@ -50,15 +43,19 @@ def timing():
         xb, yb = synth.big_train_batch(g['mono_x'], g['mono_y'], m, 3)
         x, y = torch.tensor(xb).to(dev), torch.tensor(yb).to(dev)
         out = {}
-        for name in ('exact', 'mid', 'fast'):
-            tr = HipTrainer(sd, p_dropout=0.2, lr=0.001, device=dev, route=name)
+        for name in ('exact', 'mid', 'mid4', 'mid8', 'fast'):
+            tr = HipTrainer(sd, p_dropout=0.2, lr=0.001, device=dev, route=name[:3] if name.startswith('mid') else name)
+            if name in ('mid4', 'mid8'):
+                from monoloco_amd import _lib
+                _lib.check(_lib.load().ml_trainer_set_tuning(tr._h, int(name[3:])), train=True)
             for _ in range(5): tr.step(x, y)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             n = 30
             for _ in range(n): tr.step(x, y)
             torch.cuda.synchronize(); out[name] = (time.perf_counter() - t0) / n * 1e3
             tr.close()
-        print('rows %5d: exact %.3f ms  mid %.3f ms  fast %.3f ms' % (m, out['exact'], out['mid'], out['fast']), flush=True)
+        print('rows %5d: exact %.3f ms  mid (16 / 8 / 4 columns per workgroup) %.3f / %.3f / %.3f ms  fast %.3f ms' % (
+            m, out['exact'], out['mid'], out['mid8'], out['mid4'], out['fast']), flush=True)
 
 
 if __name__ == '__main__':

@@ -31,11 +31,11 @@ def main(db_path, out_path=None):
     except sqlite3.Error as e:
         lines.append("(n/a: %s)" % e)
     lines.append("")
-    lines.append("# mid-route training GEMM (tgemm) by grid: (N/64, row tiles)")
+    lines.append("# mid-route training GEMM (xgemm) by layout and grid: (N/64, row tiles of 32)")
     try:
         for name, gx, gy, n, avg, mn, mx in cur.execute(
                 "select name, grid_x, grid_y, count(*), avg(duration), min(duration), max(duration) from kernels "
-                "where name like '%tgemm_kernel%' group by name, grid_x, grid_y").fetchall():
+                "where name like '%xgemm_kernel%' group by name, grid_x, grid_y").fetchall():
             lines.append("%-40s grid=(%d,%d) calls=%-5d avg_ns=%-10.0f min=%-9d max=%d" % (name[:40], gx, gy, n, avg, mn, mx))
     except sqlite3.Error as e:
         lines.append("(n/a: %s)" % e)
