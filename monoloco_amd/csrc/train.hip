@@ -102,6 +102,19 @@ struct ml_trainer {
     // H x H matrices / the narrow segments between them, a pinned landing zone for the loss values
     double* d_ssq = nullptr;
     double* d_gn = nullptr;          // GN_PARTS partial sums of the gradient norm
+    // the weight gradients are off the critical path (only the optimizer needs them): they run on a side stream beside the
+    // bwd_apply -> data-gradient chain.  ev_dz[k]: dz of Linear k is ready; ev_w[k]: its weight gradient has read it
+    hipStream_t st2 = nullptr;
+    std::vector<hipEvent_t> ev_dz, ev_w;
+    int side_stream = 0;             // ml_trainer_set_tuning: 1 = weight gradients on the side stream (measured: pays from ~2000 rows)
+    // 3-product GEMMs of the mid route: max |W| over the H x H matrices (two words: the one this step's GEMMs read, the one
+    // its optimizer fills for the next step), one max |dz| word per Linear (zeroed by the optimizer kernel for the next step)
+    int mid_prec = 1;                // 1 = 3-product fp16 MFMA on operands split in registers, 0 = exact fp32 MFMA
+    float* wmaxw = nullptr;          // [2][16]
+    int wmax_cur = 0;
+    bool wmax_dirty = true;
+    float* dzw = nullptr;            // 2S + 4 words
+    mlt::MatLayout lay;
     int ssq_per_mat = 0;
     int apply_cols = 8;              // columns a workgroup of the column-owner kernels takes (4 | 8 | 16): ml_trainer_set_tuning
     double* h_loss = nullptr;
@@ -503,7 +516,7 @@ int ensure_cap(ml_trainer* t, int64_t m) {
     }
     if (t->d_out) (void)hipFree(t->d_out);
     if (t->d_dout) (void)hipFree(t->d_dout);
-    const int nb = 4 * t->S + 8;  // a_s (S+1), t_s (S), z (2S+2), y2, y3, xhat, 2 gradient buffers
+    const int nb = 4 * t->S + 10;  // a_s (S+1), t_s (S), z (2S+2), y2, y3, xhat, 2 gradient buffers (+ 2: the mid route's rotating dz)
     for (int i = 0; i < nb; ++i) {
         float* p = nullptr;
         T_TRY(hipMalloc((void**)&p, (size_t)m * t->H * 4));
@@ -558,31 +571,25 @@ void finish_step_host(ml_trainer* t, const double* lv, bool task_weights, int up
 // ---------------------------------------------------------------------------------------------------------------------
 // The mid route (train_mid.h): one training step in ~57 launches, every GEMM on the exact fp32 matrix instruction.
 int launch_xgemm(hipStream_t st, const float* a, long lda, int alay, const float* b, long ldb, int blay, float* c, long ldc, int M,
-                 int N, int K, const float* bias, const float* res, double* sumsq, int flags = 0) {
+                 int N, int K, const float* bias, const float* res, double* sumsq, int prec = 0, const float* amax = nullptr,
+                 const float* bmax = nullptr) {
     mlt::XGemmParams p;
     p.a = a; p.b = b; p.c = c; p.res = res; p.bias = bias; p.sumsq = sumsq;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.M = M; p.N = N; p.K = K; p.flags = flags;
-    const unsigned gx = N / mlt::XG_BN, gy = (M + mlt::XG_BM - 1) / mlt::XG_BM;
-    const dim3 grid((flags & 2) ? gy : gx, (flags & 2) ? gx : gy), blk(256);
-    const int abl = flags >> 8;   // timing ablations of the forward layout (ml_debug_xgemm only)
-    p.flags &= 255;
-    if (abl && alay == 0 && blay == 0) {
-        switch (abl) {
-            case 1: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 1>), grid, blk, 0, st, p); break;
-            case 2: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 2>), grid, blk, 0, st, p); break;
-            case 4: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 4>), grid, blk, 0, st, p); break;
-            case 8: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 8>), grid, blk, 0, st, p); break;
-            case 12: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 12>), grid, blk, 0, st, p); break;
-            case 14: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 14>), grid, blk, 0, st, p); break;
-            case 16: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 16>), grid, blk, 0, st, p); break;
-            case 30: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 30>), grid, blk, 0, st, p); break;
-            default: return tfail(ML_ERR_ARG, "unknown xgemm ablation");
-        }
-    } else if (alay == 0 && blay == 0) hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0>), grid, blk, 0, st, p);
-    else if (alay == 0 && blay == 1) hipLaunchKernelGGL((mlt::xgemm_kernel<0, 1>), grid, blk, 0, st, p);
-    else if (alay == 1 && blay == 1) hipLaunchKernelGGL((mlt::xgemm_kernel<1, 1>), grid, blk, 0, st, p);
-    else hipLaunchKernelGGL((mlt::xgemm_kernel<1, 0>), grid, blk, 0, st, p);
+    p.M = M; p.N = N; p.K = K;
+    p.amax = amax; p.bmax = bmax;
+    const dim3 grid(N / mlt::XG_BN, (M + mlt::XG_BM - 1) / mlt::XG_BM), blk(256);
+    const int v = (alay ? 2 : 0) | (blay ? 1 : 0) | (prec ? 4 : 0);
+    switch (v) {
+        case 0: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 0>), grid, blk, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 1, 0>), grid, blk, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((mlt::xgemm_kernel<1, 0, 0>), grid, blk, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((mlt::xgemm_kernel<1, 1, 0>), grid, blk, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 1>), grid, blk, 0, st, p); break;
+        case 5: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 1, 1>), grid, blk, 0, st, p); break;
+        case 6: hipLaunchKernelGGL((mlt::xgemm_kernel<1, 0, 1>), grid, blk, 0, st, p); break;
+        default: hipLaunchKernelGGL((mlt::xgemm_kernel<1, 1, 1>), grid, blk, 0, st, p); break;
+    }
     if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "xgemm launch failed");
     return 0;
 }
@@ -622,7 +629,19 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     float* y3 = nb();
     float* gE = nb();   // (the exact route's xhat scratch)
     float* gA = nb();
-    float* gB = nb();
+    float* gBs[3] = {nb(), nb(), nb()};   // dz of consecutive Linears rotate through three buffers: the weight gradient of Linear k
+                                          // (side stream) may still read its dz while the main stream writes the next two
+    const int prec = t->mid_prec;
+    float* wmax = prec ? t->wmaxw + 16 * t->wmax_cur : nullptr;
+    float* wmax_next = prec ? t->wmaxw + 16 * (t->wmax_cur ^ 1) : nullptr;
+    if (prec && t->wmax_dirty) {   // weights written through set_tensor / by another route: recompute max |W|
+        T_TRY(hipMemsetAsync(wmax, 0, sizeof(float), st));
+        hipLaunchKernelGGL(mlt::wmax_mats_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, (const float*)t->w, t->n_param, t->lay, wmax);
+        t->wmax_dirty = false;
+    }
+    const bool side = t->side_stream && t->st2;
+    hipStream_t sw = side ? t->st2 : st;
+    int nlin = 0;                         // Linears whose backward has started (index into the events / the rotation)
     const uint32_t seed = t->seed + (uint32_t)t->step * 977u;
     auto mean_of = [&](int bn_idx) { return t->bn_mean + (size_t)bn_idx * H; };
     auto inv_of = [&](int bn_idx) { return t->bn_invstd + (size_t)bn_idx * H; };
@@ -646,7 +665,8 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     };
     // z (m x H) = x . W^T + b: both operands k-contiguous
     auto lin_fwd = [&](const float* x, const std::string& lin, float* z) {
-        return launch_xgemm(st, x, H, 0, P(t, lin + ".weight"), H, 0, z, H, (int)m, H, H, P(t, lin + ".bias"), nullptr, nullptr);
+        return launch_xgemm(st, x, H, 0, P(t, lin + ".weight"), H, 0, z, H, (int)m, H, H, P(t, lin + ".bias"), nullptr, nullptr, prec, nullptr,
+                            wmax);
     };
     fwd_apply(z0, "batch_norm1", 0, 0, nullptr, a[0], true);
     for (int s = 0; s < S; ++s) {
@@ -694,6 +714,7 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
         p.p_drop = t->p_drop; p.seed = seed; p.site = site;
         p.m = (long)m; p.H = H;
         p.dz = dz;
+        p.dzmax = prec ? t->dzw + nlin : nullptr;
         p.dgamma = z ? G(t, bn + ".weight") : nullptr;
         p.dbeta = z ? G(t, bn + ".bias") : nullptr;
         p.dbias = G(t, lin + ".bias");
@@ -707,42 +728,75 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
         }
         launch_bwd_apply(t, st, p);
     };
-    // dW (H x H) = dz^T . x: both operands reduction-major (the batch is the reduction); leaves its sum of squares
+    // the dz buffer of the next Linear; before it is overwritten the weight gradient that read it three Linears ago must be done
+    auto next_dz = [&]() -> float* {
+        if (side && nlin >= 3) (void)hipStreamWaitEvent(st, t->ev_w[nlin - 3], 0);
+        return gBs[nlin % 3];
+    };
+    // dW (H x H) = dz^T . x: both operands reduction-major (the batch is the reduction); leaves its sum of squares.  On the side
+    // stream, behind the event that says dz is complete.
     auto wgrad = [&](const float* dz, const float* x, const std::string& lin, int slot) {
-        return launch_xgemm(st, dz, H, 1, x, H, 1, G(t, lin + ".weight"), H, H, H, (int)m, nullptr, nullptr,
-                            t->d_ssq + (size_t)slot * t->ssq_per_mat);
+        if (side) {
+            (void)hipEventRecord(t->ev_dz[nlin], st);
+            (void)hipStreamWaitEvent(sw, t->ev_dz[nlin], 0);
+        }
+        const int r = launch_xgemm(sw, dz, H, 1, x, H, 1, G(t, lin + ".weight"), H, H, H, (int)m, nullptr, nullptr,
+                                   t->d_ssq + (size_t)slot * t->ssq_per_mat, prec, prec ? t->dzw + nlin : nullptr, nullptr);
+        if (side) (void)hipEventRecord(t->ev_w[nlin], sw);
+        ++nlin;
+        return r;
     };
     // dx (m x H) = dz . W (+ res): dz k-contiguous, W reduction-major as it lies (W[n][k]: n is the reduction)
     auto dgrad = [&](const float* dz, const std::string& lin, float* dx, const float* res) {
-        return launch_xgemm(st, dz, H, 0, P(t, lin + ".weight"), H, 1, dx, H, (int)m, H, H, nullptr, res, nullptr);
+        // (called after wgrad of the same Linear: its word is dzw[nlin - 1])
+        return launch_xgemm(st, dz, H, 0, P(t, lin + ".weight"), H, 1, dx, H, (int)m, H, H, nullptr, res, nullptr, prec,
+                            prec ? t->dzw + (nlin - 1) : nullptr, wmax);
     };
     // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
+    float* gB = next_dz();
     bwd_apply(nullptr, true, false, z3, "batch_norm3", 2 * S + 1, 2 * S + 1, "w3", gB, 1);                        // gB = dz3
     if ((rc = wgrad(gB, y2, "w3", 2 * S + 1))) return rc;
     if ((rc = dgrad(gB, "w3", gA, nullptr))) return rc;                                                          // gA = dy2 (w3 part)
+    gB = next_dz();
     bwd_apply(gA, false, true, nullptr, "", 0, 0, "w2", gB, 2);                                                  // gB = dz2 = dy2 + daux (x) w_aux
     if ((rc = wgrad(gB, a[S], "w2", 2 * S))) return rc;
     if ((rc = dgrad(gB, "w2", gA, nullptr))) return rc;                                                          // gA = da_S
     for (int s = S - 1; s >= 0; --s) {   // a_{s+1} = a_s + B(A(a_s))
         const std::string p = "linear_stages." + std::to_string(s) + ".";
+        gB = next_dz();
         bwd_apply(gA, false, false, zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, p + "w2", gB, 0);              // gB = dz_b
         if ((rc = wgrad(gB, tt[s], p + "w2", 2 * s + 1))) return rc;
         if ((rc = dgrad(gB, p + "w2", gE, nullptr))) return rc;                                                   // gE = d t_s
+        gB = next_dz();
         bwd_apply(gE, false, false, za[s], p + "batch_norm1", 1 + 2 * s, 1 + 2 * s, p + "w1", gB, 0);              // gB = dz_a
         if ((rc = wgrad(gB, a[s], p + "w1", 2 * s))) return rc;
         if ((rc = dgrad(gB, p + "w1", gA, gA))) return rc;                                                        // gA = da_s = da_{s+1} + dz_a . W
     }
+    gB = next_dz();
     bwd_apply(gA, false, false, z0, "batch_norm1", 0, 0, "w1", gB, 0);                                            // gB = dz0
-    if ((rc = skinny_dw(t, st, x_dev, t->in_f, t->in_f, gB, m, G(t, "w1.weight"), 1))) return rc;
+    {   // the input layer's weight gradient, also beside the main stream (it is the last thing before the optimizer)
+        if (side) {
+            (void)hipEventRecord(t->ev_dz[nlin], st);
+            (void)hipStreamWaitEvent(sw, t->ev_dz[nlin], 0);
+        }
+        if ((rc = skinny_dw(t, sw, x_dev, t->in_f, t->in_f, gB, m, G(t, "w1.weight"), 1))) return rc;
+        if (side) {   // the optimizer needs every gradient: the main stream joins the side stream here
+            (void)hipEventRecord(t->ev_w[nlin], sw);
+            (void)hipStreamWaitEvent(st, t->ev_w[nlin], 0);
+        }
+        ++nlin;
+    }
     // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)
     const int64_t k = t->step + 1;
     const float lr = t->lr0 * std::pow(t->gamma, (float)(t->step / t->sched_step));
     const float bc1 = 1.f - std::pow(0.9f, (float)k), bc2 = 1.f - std::pow(0.999f, (float)k);
     {
         hipLaunchKernelGGL(mlt::gradnorm_kernel, dim3(mlt::GN_PARTS), dim3(256), 0, st, (const float*)t->g, t->segs,
-                           (const double*)t->d_ssq, (int)(t->mat_off.size() * t->ssq_per_mat), t->d_gn);
+                           (const double*)t->d_ssq, (int)(t->mat_off.size() * t->ssq_per_mat), t->d_gn, wmax_next);
         hipLaunchKernelGGL(mlt::clip_adam_parts_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
-                           (const double*)t->d_gn, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);
+                           (const double*)t->d_gn, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0, t->lay, wmax_next,
+                           prec ? t->dzw : (float*)nullptr, 64);
+        if (prec) t->wmax_cur ^= 1;   // the word the optimizer has just filled describes the weights as they are now
         if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "optimizer launch failed");
         if (update) t->step++;
     }
@@ -826,6 +880,26 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
         t->ssq_per_mat = (hidden / mlt::XG_BN) * (hidden / mlt::XG_BM);
         T_TRY(hipMalloc((void**)&t->d_ssq, (size_t)t->mat_off.size() * t->ssq_per_mat * sizeof(double)));
         T_TRY(hipMalloc((void**)&t->d_gn, mlt::GN_PARTS * sizeof(double)));
+        T_TRY(hipMalloc((void**)&t->wmaxw, 32 * sizeof(float)));
+        T_TRY(hipMemset(t->wmaxw, 0, 32 * sizeof(float)));
+        T_TRY(hipMalloc((void**)&t->dzw, 64 * sizeof(float)));
+        T_TRY(hipMemset(t->dzw, 0, 64 * sizeof(float)));
+        t->lay.hh = (long)hidden * hidden;
+        t->lay.stride = t->lay.hh + 3L * hidden;
+        t->lay.nreg = 2 * num_stage;
+        t->lay.base0 = num_stage ? t->mat_off[0] : 0;
+        t->lay.off_w2 = t->mat_off[2 * num_stage];
+        t->lay.off_w3 = t->mat_off[2 * num_stage + 1];
+        for (int k = 0; k < 2 * num_stage; ++k)
+            if (t->mat_off[k] != t->lay.base0 + k * t->lay.stride) return tfail(ML_ERR_HIP, "unexpected parameter layout (internal)");
+        T_TRY(hipStreamCreateWithFlags(&t->st2, hipStreamNonBlocking));
+        for (int i = 0; i < 2 * num_stage + 3; ++i) {
+            hipEvent_t e0, e1;
+            T_TRY(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+            T_TRY(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            t->ev_dz.push_back(e0);
+            t->ev_w.push_back(e1);
+        }
     }
     t->splitk_cap = (size_t)32 * hidden * (hidden > in_features ? hidden : in_features);
     T_TRY(hipMalloc((void**)&t->d_splitk, t->splitk_cap * 4));
@@ -846,7 +920,10 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (char* p : t->wl) (void)hipFree(p);
     for (float* p : t->wbs) (void)hipFree(p);
     if (t->h_loss) (void)hipHostFree(t->h_loss);
-    void* ptrs[] = {t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    for (hipEvent_t e : t->ev_dz) (void)hipEventDestroy(e);
+    for (hipEvent_t e : t->ev_w) (void)hipEventDestroy(e);
+    if (t->st2) (void)hipStreamDestroy(t->st2);
+    void* ptrs[] = {t->wmaxw, t->dzw, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -867,6 +944,7 @@ static int xfer(ml_trainer* t, const char* key, float* host, const float* chost,
     T_TRY(hipDeviceSynchronize());
     if (what == 0) {
         T_TRY(hipMemcpy(base + it->second.off, chost, (size_t)numel * 4, hipMemcpyHostToDevice));
+        t->wmax_dirty = true;   // the mid route's max |W| word is recomputed by its next step
     } else T_TRY(hipMemcpy(host, base + it->second.off, (size_t)numel * 4, hipMemcpyDeviceToHost));
     return ML_OK;
 }
@@ -918,9 +996,15 @@ int ml_trainer_set_route(ml_trainer* t, int route, int64_t fast_rows) {
 
 int ml_trainer_last_route(const ml_trainer* t) { return t ? t->last_route : -1; }
 
-int ml_trainer_set_tuning(ml_trainer* t, int apply_cols) {
-    if (!t || (apply_cols != 4 && apply_cols != 8 && apply_cols != 16)) return tfail(ML_ERR_ARG, "apply_cols must be 4, 8 or 16");
-    t->apply_cols = apply_cols;
+int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream, int mid_precision) {
+    if (!t || (apply_cols != 0 && apply_cols != 4 && apply_cols != 8 && apply_cols != 16))
+        return tfail(ML_ERR_ARG, "apply_cols must be 4, 8 or 16 (0: unchanged)");
+    if (apply_cols) t->apply_cols = apply_cols;
+    if (side_stream >= 0) t->side_stream = side_stream ? 1 : 0;
+    if (mid_precision >= 0) {
+        if ((mid_precision != 0) != (t->mid_prec != 0)) t->wmax_dirty = true;
+        t->mid_prec = mid_precision ? 1 : 0;
+    }
     return ML_OK;
 }
 
@@ -938,12 +1022,13 @@ int ml_trainer_debug_read(ml_trainer* t, int which, float* host_data, int64_t nu
 }
 
 int ml_debug_xgemm(const float* a_dev, int64_t lda, int a_layout, const float* b_dev, int64_t ldb, int b_layout, float* c_dev, int M,
-                   int N, int K, const float* bias_dev, const float* res_dev, double* sumsq_dev, int flags, void* stream) {
+                   int N, int K, const float* bias_dev, const float* res_dev, double* sumsq_dev, int precision, const float* amax_dev,
+                   const float* bmax_dev, void* stream) {
     if (!a_dev || !b_dev || !c_dev || M < 1 || N < 64 || N % 64 || K < 1) return tfail(ML_ERR_ARG, "bad xgemm shape");
     if ((a_layout == 0 && K % 32) || (a_layout == 1 && M % 32) || (b_layout == 0 && K % 32))
         return tfail(ML_ERR_ARG, "xgemm: a k-contiguous operand needs K % 32 == 0, a reduction-major A needs M % 32 == 0");
     return launch_xgemm((hipStream_t)stream, a_dev, (long)lda, a_layout, b_dev, (long)ldb, b_layout, c_dev, N, M, N, K, bias_dev, res_dev,
-                        sumsq_dev, flags);
+                        sumsq_dev, precision, amax_dev, bmax_dev);
 }
 
 int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m,
@@ -1087,7 +1172,10 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         hipLaunchKernelGGL(mlt::sumsq_kernel, dim3(512), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
         hipLaunchKernelGGL(mlt::clip_adam_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
                            (const double*)d_ss, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);
-        if (update) t->step++;
+        if (update) {
+            t->step++;
+            t->wmax_dirty = true;
+        }
     }
     T_TRY(hipStreamSynchronize(st));
     finish_step_host(t, lv, task_weights, update, lr, bc1, bc2, losses_host);

@@ -37,8 +37,8 @@ struct XGemmParams {
     double* sumsq;       // optional: sum of squares of this workgroup's part of C -> sumsq[blockIdx.y * gridDim.x + blockIdx.x]
     long lda, ldb, ldc;
     int M, N, K;         // N % 64 == 0; rows beyond M are clamped on load and never stored
-    int flags;           // 1: every workgroup starts its k loop at a different step (spreads simultaneous requests over the
-                         // address bits the memory channels are selected by); 2: blockIdx.x walks the row tiles
+    const float* amax;   // PREC 1: optional device words max |A| / max |B| (power-of-two operand scaling; null: unscaled, clamped)
+    const float* bmax;
 };
 
 constexpr int XG_BM = 32, XG_BN = 64;
@@ -50,24 +50,31 @@ constexpr int XG_A_BYTES = XG_BM * 128, XG_STAGE = XG_A_BYTES + XG_BN * 128;
 // 8 k values with a stride (32 consecutive lanes = 32 consecutive banks).
 // Waves: 2 (n halves of the 64 columns) x 2 (k16 halves of every k32 step); a wave issues 8 MFMAs per k-step: MFMA e
 // contracts k = 16 wk + e (lanes 0..31) and k = 16 wk + 8 + e (lanes 32..63).  The two k halves meet in LDS at the end.
-// ABL: compile-time timing ablations (ml_debug_xgemm only; results are garbage): 1 two accumulators, 2 no MFMAs, 4 no global
-// loads in the loop, 8 no LDS traffic in the loop, 16 no barriers in the loop
-template <int ALAY, int BLAY, int ABL = 0>
+// PREC 0: the exact fp32 matrix instruction (8 x v_mfma_f32_32x32x2_f32 per wave and k-step: 512 cycles).
+// PREC 1: the 3-product fp16 scheme of the inference path (dense_kernel.h): the 8 fp32 values a lane holds per operand ARE
+//   the A / B register of v_mfma_f32_32x32x16_f16 for its k16 half; they are split into fp16 hi | lo in registers (2 VALU per
+//   value, v_fma_mix) and multiplied as hi.lo + lo.hi + hi.hi = 3 x 32 cycles, fp32 accumulate: fp32-class accuracy (2^-22
+//   per operand) at a third of the loop time.  An operand with a max |.| word is scaled by the power of two that puts its
+//   maximum at 2^13..2^14 (gradients would sit in fp16's subnormal range otherwise); one without is clamped to +-65504.
+template <int ALAY, int BLAY, int PREC = 0>
 __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * XG_STAGE];
     __shared__ double wsum[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tn = w & 1, wk = w >> 1;
-    const int bx = (p.flags & 2) ? blockIdx.y : blockIdx.x, by = (p.flags & 2) ? blockIdx.x : blockIdx.y;
+    const int bx = blockIdx.x, by = blockIdx.y;
     const int m0 = by * XG_BM, n0 = bx * XG_BN;
     const int nk = (p.K + 31) / 32, last = nk - 1;
-    const int rot = (p.flags & 1) ? (bx * 5 + by * 3) % nk : 0;
-    // position i of the k loop -> k-step (rotated start; positions past the end repeat the final one)
-    auto seq = [&](int i) -> int {
-        int t = (i < last ? i : last) + rot;
-        return t >= nk ? t - nk : t;
-    };
+    // position i of the k loop -> k-step (positions past the end repeat the final one)
+    auto seq = [&](int i) -> int { return i < last ? i : last; };
+    float sa = 1.f, sb = 1.f, descale = 1.f;
+    if (PREC == 1) {
+        const int ea = p.amax ? wscale_exp(*p.amax) : 0, eb = p.bmax ? wscale_exp(*p.bmax) : 0;
+        sa = ldexpf(1.0f, ea);
+        sb = ldexpf(1.0f, eb);
+        descale = ldexpf(1.0f, -(ea + eb));
+    }
 
 
     // ---- loader: every thread issues 3 16-byte loads per k-step (1 of A, 2 of B), full 128 / 256-byte row segments per
@@ -176,17 +183,45 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
                 }
         }
     };
-    f32x16 acc2;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
     auto mma4 = [&](const Frag& F, int e0) {
-        if (ABL & 2) return;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if ((ABL & 1) && (e & 1)) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[e0 + e], F.b[e0 + e], acc2, 0, 0, 0);
-            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[e0 + e], F.b[e0 + e], acc, 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[e0 + e], F.b[e0 + e], acc, 0, 0, 0);
     };
+    // PREC 1: 8 fp32 -> packed fp16 hi and lo halves of (v * d): v_fma_mixlo/hi write the rounded product, then the rounded
+    // remainder against it (exact subtraction).  clampd: without a scale word the value is first clamped to the fp16 range.
+    typedef _Float16 half8x __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4x __attribute__((ext_vector_type(4)));
+    auto split8 = [&](const float (&v)[8], float d, bool clampd, half8x& hi, half8x& lo) {
+        u32x4x h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float c0 = v[2 * q], c1 = v[2 * q + 1];
+            if (clampd) {
+                const float lim = 65504.0f;
+                asm("v_med3_f32 %0, %1, -%2, %2" : "=v"(c0) : "v"(c0), "v"(lim));
+                asm("v_med3_f32 %0, %1, -%2, %2" : "=v"(c1) : "v"(c1), "v"(lim));
+            }
+            unsigned hh2, ll2;
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh2) : "v"(c0), "v"(d));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh2) : "v"(c1), "v"(d));
+            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ll2) : "v"(c0), "v"(d), "v"(hh2));
+            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll2) : "v"(c1), "v"(d), "v"(hh2));
+            h[q] = hh2;
+            l[q] = ll2;
+        }
+        hi = __builtin_bit_cast(half8x, h);
+        lo = __builtin_bit_cast(half8x, l);
+    };
+    const bool clamp_a = p.amax == nullptr, clamp_b = p.bmax == nullptr;
+    auto mma3 = [&](const Frag& F) {
+        half8x ah, al, bh, bl;
+        split8(F.a, sa, clamp_a, ah, al);
+        split8(F.b, sb, clamp_b, bh, bl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+    };
+
     // Pipeline.  The operands come from HBM / the last-level cache for the first time (the producer ran on other XCDs): ~0.8 us
     // per request, against 0.25 us of MFMA time per k-step -- with the rows of only one further step in flight the loop ran at
     // 0.52 us per step whatever it computed (round 3, profiles/r03_*).  So FOUR register sets: at the top of step t, stage
@@ -199,17 +234,23 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
     // bring is stored and read but never multiplied.
     Frag F0, F1;
     auto step = [&](Frag& Fc, Frag& Fn, Raw& Rl, Raw& Rs, int sc, int i) {
-        if (!(ABL & 8)) fragread(Fn, sc ^ 1);             // step i+1
-        if (!(ABL & 4)) gload(Rl, seq(i + 5));
+        fragread(Fn, sc ^ 1);             // step i+1
+        gload(Rl, seq(i + 5));
         mask(Fc, i);
         __builtin_amdgcn_sched_barrier(0);
-        mma4(Fc, 0);
+        if (PREC == 0) {
+            mma4(Fc, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(Rs, sc);               // step i+2
+            __builtin_amdgcn_sched_barrier(0);
+            mma4(Fc, 4);
+        } else {
+            mma3(Fc);                     // (the conversion's VALU work covers the three MFMAs; the stores follow)
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(Rs, sc);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 8)) lstore(Rs, sc);                   // step i+2
-        __builtin_amdgcn_sched_barrier(0);
-        mma4(Fc, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 16)) __syncthreads();
+        __syncthreads();
     };
     gload(R0, seq(0));
     gload(R1, seq(1));
@@ -227,10 +268,6 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
         step(F1, F0, R0, R1, 1, i + 3);
     }
     __syncthreads();
-    if (ABL & 1) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
-    }
 
     // ---- the k halves meet: waves 2, 3 hand their partial tile to waves 0, 1
     float* red = (float*)smem;   // [2][16][64]
@@ -251,7 +288,7 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
         for (int r = 0; r < 16; ++r) {
             const int i = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (i < p.M) {
-                float v = acc[r] + bj;
+                float v = (PREC == 1 ? acc[r] * descale : acc[r]) + bj;
                 const size_t o = (size_t)i * p.ldc + j;
                 if (p.res) v += p.res[o];
                 p.c[o] = v;
@@ -264,7 +301,7 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
         for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
         if (lane == 0) wsum[w] = ss;
         __syncthreads();
-        if (tid == 0) p.sumsq[(size_t)by * (p.N / XG_BN) + bx] = wsum[0] + wsum[1];
+        if (tid == 0) p.sumsq[(size_t)by * gridDim.x + bx] = wsum[0] + wsum[1];
     }
 }
 
@@ -478,6 +515,7 @@ struct BwdApplyParams {
     long m;
     int H;
     float* dz;
+    float* dzmax;    // optional word: max |dz| folded in with atomicMax (the scale of the 3-product GEMMs that read dz)
     float* dgamma;
     float* dbeta;
     float* dbias;
@@ -605,6 +643,7 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(BwdApplyParams p) {
         }
     }
     double s2[1][4] = {{0.0, 0.0, 0.0, 0.0}};
+    float mx = 0.f;
     for (long base = 0; base < p.m; base += chunk) {
         if (!single) fetch(base);
 #pragma unroll
@@ -622,9 +661,20 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(BwdApplyParams p) {
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s2[0][e] += (double)o[e];
+                for (int e = 0; e < 4; ++e) {
+                    s2[0][e] += (double)o[e];
+                    mx = __builtin_fmaxf(mx, __builtin_fabsf(o[e]));
+                }
                 *(f32x4*)(p.dz + i * H + j) = o;
             }
+        }
+    }
+    if (p.dzmax) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((tid & 63) == 0) {
+            if (!(mx < 3.0e38f)) mx = 3.0e38f;
+            atomicMax((unsigned*)p.dzmax, __builtin_bit_cast(unsigned, mx));
         }
     }
     __syncthreads();   // (red is read above by the threads tid < NC)
@@ -724,8 +774,9 @@ struct AdamSegs {
 constexpr int GN_PARTS = 64;
 // level 1: GN_PARTS workgroups, each a strided share of the slots and of every narrow segment -> part[blockIdx.x]
 __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__ g, AdamSegs segs, const double* __restrict__ slots, int nslots,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, float* __restrict__ zero_word) {
     __shared__ double red[256];
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0.f;   // max |W| of the weights the optimizer is about to write
     const int gt = blockIdx.x * 256 + threadIdx.x, gn = GN_PARTS * 256;
     double a = 0.0;
     for (int i = gt; i < nslots; i += gn) a += slots[i];
@@ -743,33 +794,88 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
-// level 2 inside the optimizer: every workgroup adds the GN_PARTS partial sums in the same order.  clip_adam_kernel's arithmetic.
+// Where the H x H weight matrices lie in the flat parameter buffer: 2 S of them at base0 + k * stride (a stage Linear is
+// followed by its bias and one BatchNorm's weight + bias: stride = H^2 + 3 H), then w2 and w3.
+struct MatLayout {
+    long base0, stride, hh, off_w2, off_w3;
+    int nreg;
+};
+__device__ __forceinline__ bool block_in_matrix(const MatLayout& L, long i0, long i1) {   // [i0, i1] inside ONE matrix
+    if (i0 >= L.off_w3) return i1 < L.off_w3 + L.hh;
+    if (i0 >= L.off_w2) return i1 < L.off_w2 + L.hh;
+    if (i0 < L.base0) return false;
+    const long q = (i0 - L.base0) / L.stride, r0 = (i0 - L.base0) - q * L.stride;
+    return q < L.nreg && r0 + (i1 - i0) < L.hh;
+}
+
+// level 2 inside the optimizer: every workgroup adds the GN_PARTS partial sums in the same order.  clip_adam_kernel's
+// arithmetic.  On the way: max |w| over the H x H matrices after the update -> wmax_next (zeroed by gradnorm_kernel; the scale
+// of the next step's 3-product GEMMs; workgroups that straddle a matrix edge -- 2 per matrix -- do not contribute), and
+// workgroup 0 zeroes the per-step max |dz| words for the next step.
 __global__ __launch_bounds__(256) void clip_adam_parts_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m1,
                                                              float* __restrict__ m2, int64_t n, const double* __restrict__ part,
                                                              float max_norm, float lr, float b1, float b2, float eps, float bc1,
-                                                             float bc2, int do_adam) {
+                                                             float bc2, int do_adam, MatLayout lay, float* __restrict__ wmax_next,
+                                                             float* __restrict__ zero_words, int n_zero) {
     __shared__ double tot;
+    __shared__ float wmx[4];
     if (threadIdx.x < 64) {
         double v = part[threadIdx.x];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
         if (threadIdx.x == 0) tot = v;
     }
+    if (blockIdx.x == 0 && zero_words && (int)threadIdx.x < n_zero) zero_words[threadIdx.x] = 0.f;
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float norm = (float)sqrt(tot);
-    float coef = max_norm / (norm + 1e-6f);
-    coef = coef > 1.f ? 1.f : coef;
-    const float gi = g[i] * coef;
-    g[i] = gi;
-    if (!do_adam) return;
-    const float a = m1[i] + (gi - m1[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
-    const float v = b2 * m2[i] + (1.f - b2) * gi * gi;
-    m1[i] = a;
-    m2[i] = v;
-    const float denom = sqrtf(v) / sqrtf(bc2) + eps;
-    w[i] -= (lr / bc1) * (a / denom);
+    float wn = 0.f;
+    if (i < n) {
+        const float norm = (float)sqrt(tot);
+        float coef = max_norm / (norm + 1e-6f);
+        coef = coef > 1.f ? 1.f : coef;
+        const float gi = g[i] * coef;
+        g[i] = gi;
+        wn = w[i];
+        if (do_adam) {
+            const float a = m1[i] + (gi - m1[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
+            const float v = b2 * m2[i] + (1.f - b2) * gi * gi;
+            m1[i] = a;
+            m2[i] = v;
+            const float denom = sqrtf(v) / sqrtf(bc2) + eps;
+            wn -= (lr / bc1) * (a / denom);
+            w[i] = wn;
+        }
+    }
+    if (wmax_next) {   // (uniform)
+        const int64_t i0 = (int64_t)blockIdx.x * 256;
+        const int64_t i1 = i0 + 255 < n - 1 ? i0 + 255 : n - 1;
+        if (block_in_matrix(lay, i0, i1)) {   // (uniform)
+            float mx = __builtin_fabsf(wn);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+            if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                mx = __builtin_fmaxf(__builtin_fmaxf(wmx[0], wmx[1]), __builtin_fmaxf(wmx[2], wmx[3]));
+                if (!(mx < 3.0e38f)) mx = 3.0e38f;
+                atomicMax((unsigned*)wmax_next, __builtin_bit_cast(unsigned, mx));
+            }
+        }
+    }
+}
+
+// max |w| over the H x H matrices (after set_tensor / a step of another route; the word is zeroed by the caller)
+__global__ __launch_bounds__(256) void wmax_mats_kernel(const float* __restrict__ w, int64_t n, MatLayout lay, float* __restrict__ wmax) {
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    const int64_t i1 = i0 + 255 < n - 1 ? i0 + 255 : n - 1;
+    if (!block_in_matrix(lay, i0, i1)) return;
+    float mx = __builtin_fabsf(w[i0 + threadIdx.x]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        if (!(mx < 3.0e38f)) mx = 3.0e38f;
+        atomicMax((unsigned*)wmax, __builtin_bit_cast(unsigned, mx));
+    }
 }
 
 }  // namespace mlt

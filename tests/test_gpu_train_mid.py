@@ -21,7 +21,7 @@ def _batch(mode, val=False):
     return torch.tensor(g[mode + '_x' + s]), torch.tensor(g[mode + '_y' + s])
 
 
-def _xgemm(lib, dev, a, alay, b, blay, M, N, K, bias=None, res=None, want_sumsq=False, flags=0):
+def _xgemm(lib, dev, a, alay, b, blay, M, N, K, bias=None, res=None, want_sumsq=False, prec=0, amax=None, bmax=None):
     from monoloco_amd._lib import check
     from monoloco_amd.engine import _ptr, _stream
     c = torch.full((M, N), float('nan'), dtype=torch.float32, device=dev)
@@ -29,7 +29,7 @@ def _xgemm(lib, dev, a, alay, b, blay, M, N, K, bias=None, res=None, want_sumsq=
     ssq = torch.full((nwg,), float('nan'), dtype=torch.float64, device=dev) if want_sumsq else None
     with torch.cuda.device(dev):
         check(lib.ml_debug_xgemm(_ptr(a), a.shape[1], alay, _ptr(b), b.shape[1], blay, _ptr(c), M, N, K, _ptr(bias), _ptr(res),
-                                 _ptr(ssq), flags, _stream(dev)), train=True)
+                                 _ptr(ssq), prec, _ptr(amax), _ptr(bmax), _stream(dev)), train=True)
     torch.cuda.synchronize()
     return c, ssq
 
@@ -53,13 +53,23 @@ def test_xgemm_layouts_against_fp64(hip_lib, cuda_device, M, N, K):
             continue                                  # a k-contiguous operand needs whole k32 steps (hidden % 64 == 0 in the step)
         if alay == 1 and M % 32:
             continue
-        a = A if alay == 0 else A.t().contiguous()
-        b = B if blay == 0 else B.t().contiguous()
-        for flags in (0, 1, 2, 3):
-            c, _ = _xgemm(hip_lib, dev, a, alay, b, blay, M, N, K, flags=flags)
+        # a reduction-major operand is read to the end of the last k32 step: rows K .. ceil32(K) must exist (NaN there: they must
+        # contribute exactly 0)
+        Kp = (K + 31) // 32 * 32
+        def rm(X):
+            buf = torch.full((Kp, X.shape[0]), float('nan'), device=dev)
+            buf[:K] = X.t()
+            return buf
+        a = A if alay == 0 else rm(A)
+        b = B if blay == 0 else rm(B)
+        amax, bmax = A.abs().max().reshape(1).clone(), B.abs().max().reshape(1).clone()
+        for prec, am, bm in ((0, None, None), (1, None, bmax), (1, amax, bmax)):
+            c, _ = _xgemm(hip_lib, dev, a, alay, b, blay, M, N, K, prec=prec, amax=am, bmax=bm)
             err = (c.double() - ref).abs()
-            assert torch.isfinite(c).all() and (err / mag).max().item() <= 5e-7 * max(1.0, K / 256) ** 0.5, (alay, blay, flags, (err / mag).max().item())
-            assert err.max().item() <= max(4 * e32, 1e-6 * mag.max().item()), (alay, blay, flags, err.max().item(), e32)
+            # exact fp32 products (prec 0) / 2^-22 per operand (prec 1): a few 1e-7 of sum |a| |b|
+            assert torch.isfinite(c).all() and (err / mag).max().item() <= (5e-7 if prec == 0 else 1.5e-6) * max(1.0, K / 256) ** 0.5, \
+                (alay, blay, prec, (err / mag).max().item())
+            assert err.max().item() <= max(4 * e32, (1e-6 if prec == 0 else 3e-6) * mag.max().item()), (alay, blay, prec, err.max().item(), e32)
 
 
 def test_xgemm_epilogue(hip_lib, cuda_device):
@@ -72,7 +82,15 @@ def test_xgemm_epilogue(hip_lib, cuda_device):
     bias = torch.randn(N, generator=gen).to(dev)
     res = torch.randn(M, N, generator=gen).to(dev)
     ref = a.double() @ b.double().t() + bias.double() + res.double()
-    c, ssq = _xgemm(hip_lib, dev, a, 0, b, 0, M, N, K, bias=bias, res=res, want_sumsq=True, flags=3)
+    g = (torch.randn(M, K, generator=gen) * 3e-6).to(dev)            # a gradient-sized operand: needs its scale word
+    gmax = g.abs().max().reshape(1).clone()
+    refg = g.double() @ b.double().t()
+    magg = g.double().abs() @ b.double().abs().t()
+    cg, _ = _xgemm(hip_lib, dev, g, 0, b, 0, M, N, K, prec=1, amax=gmax, bmax=b.abs().max().reshape(1).clone())
+    cg0, _ = _xgemm(hip_lib, dev, g, 0, b, 0, M, N, K, prec=1)
+    eg, eg0 = ((cg.double() - refg).abs() / magg).max().item(), ((cg0.double() - refg).abs() / magg).max().item()
+    assert eg <= 3e-6 and eg0 > 4 * eg, (eg, eg0)                      # unscaled: fp16 subnormals, visibly worse
+    c, ssq = _xgemm(hip_lib, dev, a, 0, b, 0, M, N, K, bias=bias, res=res, want_sumsq=True)
     assert (c.double() - ref).abs().max().item() <= 2e-5
     assert abs(ssq.sum().item() - (c.double() ** 2).sum().item()) <= 1e-9 * (c.double() ** 2).sum().item()
     tiles = (c.double() ** 2).reshape(M, N // 64, 64).sum(2)                # per (row, column tile)
@@ -121,7 +139,7 @@ def test_mid_route_matches_exact_route(hip_lib, cuda_device, mode, hidden, p_dro
 
 def test_mid_route_after_reload_and_route_switches(hip_lib, cuda_device):
     """The mid route keeps no derived state: after load_state_dict and after steps on other routes it computes with the current
-    weights; the column-ownership width is a pure tuning knob (same results for 4, 8 and 16 columns per workgroup)."""
+    weights; the column-ownership width and the side stream of the weight gradients are pure tuning knobs (same results)."""
     from monoloco_amd._lib import check
     from monoloco_amd.train import HipTrainer
     x, y = _batch('mono')
@@ -139,7 +157,7 @@ def test_mid_route_after_reload_and_route_switches(hip_lib, cuda_device):
     outs = {}
     for cols in (4, 8, 16):
         fresh = HipTrainer(sd1, p_dropout=0.2, lr=0.001, device=cuda_device, route='mid', seed=5)
-        check(hip_lib.ml_trainer_set_tuning(fresh._h, cols), train=True)
+        check(hip_lib.ml_trainer_set_tuning(fresh._h, cols, 1 if cols == 8 else 0, -1), train=True)
         r, out = fresh.step(x, y, update=False, want_outputs=True)
         outs[cols] = (r['loss'], out.cpu(), fresh.grads())
         fresh.close()
@@ -151,6 +169,14 @@ def test_mid_route_after_reload_and_route_switches(hip_lib, cuda_device):
     gb = fresh.grads()
     assert a['loss'] == b['loss']                                     # deterministic: the same weights give the same bits
     assert all(torch.equal(ga[k], gb[k]) for k in ga)
+    # the exact-fp32 matrix instruction instead of the 3-product scheme: same step to fp32 rounding class
+    check(hip_lib.ml_trainer_set_tuning(fresh._h, 0, -1, 0), train=True)
+    c = fresh.step(x, y, update=False)
+    gc = fresh.grads()
+    assert abs(c['loss'] - b['loss']) <= 1e-5 * abs(b['loss'])
+    gmax = max(v.abs().max().item() for v in gb.values())
+    for k in gb:
+        assert (gb[k] - gc[k]).abs().max().item() <= 1e-2 * max(gb[k].abs().max().item(), 1e-4 * gmax), k
     tr.close()
     fresh.close()
 
