@@ -237,20 +237,23 @@ int64_t ml_trainer_num_steps(const ml_trainer* t);
 /* Which GEMM route a step takes, per handle (thread-compatible: nothing process-global).  route 0 = automatic: batches of at
  * least fast_rows rows (default 4096; hidden % 256 == 0) run the hidden x hidden products on the large-batch 3-product fp16
  * MFMA kernel (256 x 256 tiles, line-format operands); smaller ones (hidden % 64 == 0) take the "mid" route -- exact-fp32
- * MFMA-class GEMMs on 32 x 64 tiles that read the row-major fp32 tensors as they lie (weight and data gradients included;
- * 3-product fp16 MFMA on operands split in registers, or the exact fp32 matrix instruction), BatchNorm statistics per column
- * owner, ~50 launches per step (monoloco_amd/csrc/train_mid.h): the reference's real batch sizes
+ * MFMA GEMMs on 32 x 64 tiles that read the row-major fp32 tensors as they lie (weight and data gradients included), BatchNorm
+ * statistics per column owner, ~50 launches per step (monoloco_amd/csrc/train_mid.h): the reference's real batch sizes
  * (run.py:95 --bs 512); anything else the generic exact-fp32 GEMM.  route 1 = generic exact-fp32 only, 2 = mid whenever it can
  * run, 3 = large-batch route whenever it can run.  fast_rows < 0 leaves the threshold unchanged. */
 int ml_trainer_set_route(ml_trainer* t, int route, int64_t fast_rows);
 /* route of the last ml_trainer_step: 0 exact, 1 large-batch, 2 mid (-1: no step yet) */
 int ml_trainer_last_route(const ml_trainer* t);
-/* Per-handle tuning of the mid route: apply_cols = columns per workgroup of the column-owner kernels (4, 8 or 16; default 8;
- * 0 leaves it); side_stream = 1: the weight-gradient GEMMs, which only the optimizer needs, run on an internal side stream
- * beside the data-gradient chain (events both ways; pays from ~2000 rows), 0 (default): everything on the caller's stream;
- * mid_precision = 1 (default): the GEMMs run the 3-product fp16 MFMA scheme on operands split in registers (fp32-class
- * accuracy), 0: the exact fp32 matrix instruction.  Negative values leave a setting unchanged. */
-int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream, int mid_precision);
+/* The two validation-type values of the last step's (train-mode) outputs that differ from the training task values
+ * (losses.py:85-96; the reference logs them for the training phase too, trainer.py:163-165): host2[0] = mean |mu - d| (L1 instead
+ * of the Laplace loss), host2[1] = mean |atan2(out7, out8) - atan2(sin, cos)| in radians.  The other validation-type values equal
+ * the task values ml_trainer_step returns (x, y, h, w, l: L1; aux: BCE). */
+int ml_trainer_last_val_values(const ml_trainer* t, double* host2);
+/* Per-handle tuning of the mid route, same results: apply_cols = columns per workgroup of the column-owner kernels (4, 8 or 16;
+ * default 8; 0 leaves it); side_stream = 1: the weight-gradient GEMMs, which only the optimizer needs, run on an internal side
+ * stream beside the data-gradient chain (events both ways; measured to pay from ~2000 rows), 0 (default): everything on the
+ * caller's stream; < 0 leaves it. */
+int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream);
 int ml_trainer_destroy(ml_trainer* t);
 const char* ml_train_last_error(void);
 
@@ -316,15 +319,12 @@ int ml_debug_set_tile_kernel(int which);
  * (rows x hidden) activation / gradient buffers in allocation order (a_0..a_S, t_0.., z0, (za, zb)_s, z3, y2, y3, scratch,
  * gA, gB), 200 / 201 the raw outputs / their gradient. */
 int ml_trainer_debug_read(ml_trainer* t, int which, float* host_data, int64_t numel);
-/* The mid route's GEMM on its own: c (M, N) = sum_k A(i, k) B(j, k) (+ bias (N)) (+ res (M, N)).
+/* The mid route's exact-fp32 MFMA GEMM on its own: c (M, N) = sum_k A(i, k) B(j, k) (+ bias (N)) (+ res (M, N)).
  * layout 0: the operand is k-contiguous (A(i, k) = a[i * lda + k]; K % 32 == 0), layout 1: reduction-major (A(i, k) =
  * a[k * lda + i]; for A: M % 32 == 0; rows K .. ceil32(K) of such an operand must be readable, they contribute 0).  N % 64 == 0.
- * sumsq_dev: optional (N / 64) * ceil(M / 32) doubles, the per-workgroup sums of squares of c.  precision 0: exact fp32
- * MFMA; 1: 3-product fp16 MFMA, amax_dev / bmax_dev = optional device words max |A| / max |B| (operand scaling; NULL:
- * unscaled, clamped to the fp16 range).  All device pointers. */
+ * sumsq_dev: optional (N / 64) * ceil(M / 32) doubles, the per-workgroup sums of squares of c.  All device pointers. */
 int ml_debug_xgemm(const float* a_dev, int64_t lda, int a_layout, const float* b_dev, int64_t ldb, int b_layout, float* c_dev, int M,
-                   int N, int K, const float* bias_dev, const float* res_dev, double* sumsq_dev, int precision, const float* amax_dev,
-                   const float* bmax_dev, void* stream);
+                   int N, int K, const float* bias_dev, const float* res_dev, double* sumsq_dev, void* stream);
 /* Packed fp16 hi|lo line image of a dense layer's weights (n * kpad * 2 uint16); only kept for
  * models finalized with ML_FLAG_HOST_ONLY. */
 int ml_debug_get_packed(const ml_loco* h, int layer, uint16_t* lines_host, int64_t capacity);

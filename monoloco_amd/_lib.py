@@ -76,9 +76,10 @@ SIGNATURES = {
     'ml_trainer_num_steps': (c_int64, [_P]),
     'ml_trainer_set_route': (c_int, [_P, c_int, c_int64]),
     'ml_trainer_last_route': (c_int, [_P]),
+    'ml_trainer_last_val_values': (c_int, [_P, POINTER(c_double)]),
     'ml_trainer_debug_read': (c_int, [_P, c_int, POINTER(c_float), c_int64]),
-    'ml_trainer_set_tuning': (c_int, [_P, c_int, c_int, c_int]),
-    'ml_debug_xgemm': (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P]),
+    'ml_trainer_set_tuning': (c_int, [_P, c_int, c_int]),
+    'ml_debug_xgemm': (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     'ml_trainer_destroy': (c_int, [_P]),
     'ml_train_last_error': (c_char_p, []),
     'ml_pifpaf_count': (c_int, [c_char_p, c_int64, POINTER(c_int64)]),

@@ -53,6 +53,7 @@ extern "C" const char* ml_train_last_error(void) { return t_err; }
 // fp64 reduction slots per step: a step takes 6 S + 8 of them (2 per BatchNorm forward / backward, the bias sums); sized per
 // trainer from its num_stage, so a fresh pre-zeroed slot always exists (two reductions never share one)
 inline int red_slots_for(int num_stage) { return 6 * num_stage + 16; }
+constexpr int HL_GRID = 256;   // most workgroups heads_loss_kernel is launched with (partial sums the host adds)
 
 struct ml_trainer {
     int in_f, H, C, S;
@@ -107,17 +108,11 @@ struct ml_trainer {
     hipStream_t st2 = nullptr;
     std::vector<hipEvent_t> ev_dz, ev_w;
     int side_stream = 0;             // ml_trainer_set_tuning: 1 = weight gradients on the side stream (measured: pays from ~2000 rows)
-    // 3-product GEMMs of the mid route: max |W| over the H x H matrices (two words: the one this step's GEMMs read, the one
-    // its optimizer fills for the next step), one max |dz| word per Linear (zeroed by the optimizer kernel for the next step)
-    int mid_prec = 1;                // 1 = 3-product fp16 MFMA on operands split in registers, 0 = exact fp32 MFMA
-    float* wmaxw = nullptr;          // [2][16]
-    int wmax_cur = 0;
-    bool wmax_dirty = true;
-    float* dzw = nullptr;            // 2S + 4 words
-    mlt::MatLayout lay;
     int ssq_per_mat = 0;
     int apply_cols = 8;              // columns a workgroup of the column-owner kernels takes (4 | 8 | 16): ml_trainer_set_tuning
-    double* h_loss = nullptr;
+    double* h_loss = nullptr;        // pinned: up to HL_GRID x LOSS_NV partial sums
+    double* d_lpart = nullptr;       // the same on the device (heads_loss_kernel)
+    double last_vals[2] = {0, 0};    // validation-type d (L1) and ori (angle, radians) means of the last step's outputs
     std::vector<int64_t> mat_off;    // flat offsets of the H x H weight matrices by Linear slot
     mlt::AdamSegs segs;
     int last_route = -1;             // route the last step took (0 exact, 1 fast, 2 mid): ml_trainer_last_route
@@ -368,7 +363,9 @@ int fast_linear_bwd_weight(ml_trainer* t, hipStream_t st, const float* x, const 
 }
 
 bool fast_possible(const ml_trainer* t) { return t->H % 256 == 0 && !t->lbufs.empty(); }
-bool mid_possible(const ml_trainer* t) { return t->H % 64 == 0 && t->d_ssq != nullptr && t->in_f <= mlt::SK_NC; }
+bool mid_possible(const ml_trainer* t) {
+    return t->H % 64 == 0 && t->d_ssq != nullptr && t->in_f <= mlt::SK_NC && (int64_t)t->C * t->H <= mlt::HL_MAXW;
+}
 // 0 exact, 1 fast (large batches: 256 x 256-tile 3-product GEMMs on line-format operands), 2 mid (train_mid.h)
 int pick_route(const ml_trainer* t, int64_t m) {
     switch (t->route) {
@@ -547,6 +544,8 @@ int upload_task_weights(ml_trainer* t, hipStream_t st, bool task_weights) {
 void finish_step_host(ml_trainer* t, const double* lv, bool task_weights, int update, float lr, float bc1, float bc2,
                       double* losses_host) {
     const int nt = (t->C == 10) ? 8 : 7;
+    t->last_vals[0] = lv[8];
+    t->last_vals[1] = lv[9];
     if (losses_host) {
         double tot = 0;
         for (int i = 0; i < 8; ++i) {
@@ -571,25 +570,16 @@ void finish_step_host(ml_trainer* t, const double* lv, bool task_weights, int up
 // ---------------------------------------------------------------------------------------------------------------------
 // The mid route (train_mid.h): one training step in ~57 launches, every GEMM on the exact fp32 matrix instruction.
 int launch_xgemm(hipStream_t st, const float* a, long lda, int alay, const float* b, long ldb, int blay, float* c, long ldc, int M,
-                 int N, int K, const float* bias, const float* res, double* sumsq, int prec = 0, const float* amax = nullptr,
-                 const float* bmax = nullptr) {
+                 int N, int K, const float* bias, const float* res, double* sumsq) {
     mlt::XGemmParams p;
     p.a = a; p.b = b; p.c = c; p.res = res; p.bias = bias; p.sumsq = sumsq;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K;
-    p.amax = amax; p.bmax = bmax;
     const dim3 grid(N / mlt::XG_BN, (M + mlt::XG_BM - 1) / mlt::XG_BM), blk(256);
-    const int v = (alay ? 2 : 0) | (blay ? 1 : 0) | (prec ? 4 : 0);
-    switch (v) {
-        case 0: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 0>), grid, blk, 0, st, p); break;
-        case 1: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 1, 0>), grid, blk, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((mlt::xgemm_kernel<1, 0, 0>), grid, blk, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((mlt::xgemm_kernel<1, 1, 0>), grid, blk, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0, 1>), grid, blk, 0, st, p); break;
-        case 5: hipLaunchKernelGGL((mlt::xgemm_kernel<0, 1, 1>), grid, blk, 0, st, p); break;
-        case 6: hipLaunchKernelGGL((mlt::xgemm_kernel<1, 0, 1>), grid, blk, 0, st, p); break;
-        default: hipLaunchKernelGGL((mlt::xgemm_kernel<1, 1, 1>), grid, blk, 0, st, p); break;
-    }
+    if (alay == 0 && blay == 0) hipLaunchKernelGGL((mlt::xgemm_kernel<0, 0>), grid, blk, 0, st, p);
+    else if (alay == 0 && blay == 1) hipLaunchKernelGGL((mlt::xgemm_kernel<0, 1>), grid, blk, 0, st, p);
+    else if (alay == 1 && blay == 1) hipLaunchKernelGGL((mlt::xgemm_kernel<1, 1>), grid, blk, 0, st, p);
+    else hipLaunchKernelGGL((mlt::xgemm_kernel<1, 0>), grid, blk, 0, st, p);
     if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "xgemm launch failed");
     return 0;
 }
@@ -613,9 +603,6 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
              double* losses_host, float* raw_out_dev, hipStream_t st) {
     const int H = t->H, S = t->S, C = t->C;
     int rc;
-    T_TRY(hipMemsetAsync(t->d_red_base, 0, (size_t)t->red_slots * (2 * H + 32) * sizeof(double), st));
-    t->red_slot = 0;
-    t->d_red = t->d_red_base;
     // buffer plan (the exact route's)
     int bi = 0;
     auto nb = [&]() { return t->bufs[bi++]; };
@@ -631,14 +618,6 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     float* gA = nb();
     float* gBs[3] = {nb(), nb(), nb()};   // dz of consecutive Linears rotate through three buffers: the weight gradient of Linear k
                                           // (side stream) may still read its dz while the main stream writes the next two
-    const int prec = t->mid_prec;
-    float* wmax = prec ? t->wmaxw + 16 * t->wmax_cur : nullptr;
-    float* wmax_next = prec ? t->wmaxw + 16 * (t->wmax_cur ^ 1) : nullptr;
-    if (prec && t->wmax_dirty) {   // weights written through set_tensor / by another route: recompute max |W|
-        T_TRY(hipMemsetAsync(wmax, 0, sizeof(float), st));
-        hipLaunchKernelGGL(mlt::wmax_mats_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, (const float*)t->w, t->n_param, t->lay, wmax);
-        t->wmax_dirty = false;
-    }
     const bool side = t->side_stream && t->st2;
     hipStream_t sw = side ? t->st2 : st;
     int nlin = 0;                         // Linears whose backward has started (index into the events / the rotation)
@@ -665,8 +644,7 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     };
     // z (m x H) = x . W^T + b: both operands k-contiguous
     auto lin_fwd = [&](const float* x, const std::string& lin, float* z) {
-        return launch_xgemm(st, x, H, 0, P(t, lin + ".weight"), H, 0, z, H, (int)m, H, H, P(t, lin + ".bias"), nullptr, nullptr, prec, nullptr,
-                            wmax);
+        return launch_xgemm(st, x, H, 0, P(t, lin + ".weight"), H, 0, z, H, (int)m, H, H, P(t, lin + ".bias"), nullptr, nullptr);
     };
     fwd_apply(z0, "batch_norm1", 0, 0, nullptr, a[0], true);
     for (int s = 0; s < S; ++s) {
@@ -677,21 +655,27 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
         fwd_apply(zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, a[s], a[s + 1], false);   // a_{s+1} = a_s + block(t_s)
     }
     if ((rc = lin_fwd(a[S], "w2", y2))) return rc;
-    const bool skinny = skinny_ok(t, C - 1);
-    if (!(skinny && skinny_heads(t, st, y2, m, P(t, "w_aux.weight"), P(t, "w_aux.bias"), 1, t->d_out + (C - 1), C)))
-        if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
     if ((rc = lin_fwd(y2, "w3", z3))) return rc;
     fwd_apply(z3, "batch_norm3", 2 * S + 1, 2 * S + 1, nullptr, y3, false);
-    if (!(skinny && skinny_heads(t, st, y3, m, P(t, "w_fin.weight"), P(t, "w_fin.bias"), C - 1, t->d_out, C)))
-        if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
-    if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
-    // ---------------- loss and its gradient (loss_kernel writes every column of dout)
-    double* d_loss = t->d_red + 2 * H;
+    // ---------------- both heads, the loss and its gradient: one launch, per-workgroup partial sums the host adds
     const bool task_weights = t->auto_tune || t->weighted;
     if ((rc = upload_task_weights(t, st, task_weights))) return rc;
-    hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
-                       t->d_dout, d_loss, (const float*)(task_weights ? t->d_tw : nullptr));
-    T_TRY(hipMemcpyAsync(t->h_loss, d_loss, 8 * sizeof(double), hipMemcpyDeviceToHost, st));   // pinned: does not stall the host
+    int hl_grid = (int)((m + 3) / 4);
+    if (hl_grid > HL_GRID) hl_grid = HL_GRID;
+    {
+        mlt::HeadsLossParams p;
+        p.y3 = y3; p.y2 = y2;
+        p.w_fin = P(t, "w_fin.weight"); p.b_fin = P(t, "w_fin.bias");
+        p.w_aux = P(t, "w_aux.weight"); p.b_aux = P(t, "w_aux.bias");
+        p.lab = labels_dev; p.L = label_cols; p.m = (long)m; p.H = H;
+        p.out = t->d_out; p.dout = t->d_dout;
+        p.tw = task_weights ? t->d_tw : nullptr;
+        p.part = t->d_lpart;
+        if (C == 10) hipLaunchKernelGGL(mlt::heads_loss_kernel<10>, dim3(hl_grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(mlt::heads_loss_kernel<9>, dim3(hl_grid), dim3(256), 0, st, p);
+    }
+    if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
+    T_TRY(hipMemcpyAsync(t->h_loss, t->d_lpart, (size_t)hl_grid * mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));   // pinned
     // ---------------- backward (every gradient tensor is written in full: no memset of g).  The narrow gradients (head weights
     // and biases, input-layer weights) ride in the column-owner kernels of the blocks whose data they read.
     // dz of one block from its incoming gradient
@@ -714,7 +698,6 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
         p.p_drop = t->p_drop; p.seed = seed; p.site = site;
         p.m = (long)m; p.H = H;
         p.dz = dz;
-        p.dzmax = prec ? t->dzw + nlin : nullptr;
         p.dgamma = z ? G(t, bn + ".weight") : nullptr;
         p.dbeta = z ? G(t, bn + ".bias") : nullptr;
         p.dbias = G(t, lin + ".bias");
@@ -741,16 +724,14 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
             (void)hipStreamWaitEvent(sw, t->ev_dz[nlin], 0);
         }
         const int r = launch_xgemm(sw, dz, H, 1, x, H, 1, G(t, lin + ".weight"), H, H, H, (int)m, nullptr, nullptr,
-                                   t->d_ssq + (size_t)slot * t->ssq_per_mat, prec, prec ? t->dzw + nlin : nullptr, nullptr);
+                                   t->d_ssq + (size_t)slot * t->ssq_per_mat);
         if (side) (void)hipEventRecord(t->ev_w[nlin], sw);
         ++nlin;
         return r;
     };
     // dx (m x H) = dz . W (+ res): dz k-contiguous, W reduction-major as it lies (W[n][k]: n is the reduction)
     auto dgrad = [&](const float* dz, const std::string& lin, float* dx, const float* res) {
-        // (called after wgrad of the same Linear: its word is dzw[nlin - 1])
-        return launch_xgemm(st, dz, H, 0, P(t, lin + ".weight"), H, 1, dx, H, (int)m, H, H, nullptr, res, nullptr, prec,
-                            prec ? t->dzw + (nlin - 1) : nullptr, wmax);
+        return launch_xgemm(st, dz, H, 0, P(t, lin + ".weight"), H, 1, dx, H, (int)m, H, H, nullptr, res, nullptr);
     };
     // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
     float* gB = next_dz();
@@ -792,16 +773,20 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     const float bc1 = 1.f - std::pow(0.9f, (float)k), bc2 = 1.f - std::pow(0.999f, (float)k);
     {
         hipLaunchKernelGGL(mlt::gradnorm_kernel, dim3(mlt::GN_PARTS), dim3(256), 0, st, (const float*)t->g, t->segs,
-                           (const double*)t->d_ssq, (int)(t->mat_off.size() * t->ssq_per_mat), t->d_gn, wmax_next);
+                           (const double*)t->d_ssq, (int)(t->mat_off.size() * t->ssq_per_mat), t->d_gn);
         hipLaunchKernelGGL(mlt::clip_adam_parts_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
-                           (const double*)t->d_gn, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0, t->lay, wmax_next,
-                           prec ? t->dzw : (float*)nullptr, 64);
-        if (prec) t->wmax_cur ^= 1;   // the word the optimizer has just filled describes the weights as they are now
+                           (const double*)t->d_gn, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);
         if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "optimizer launch failed");
         if (update) t->step++;
     }
     T_TRY(hipStreamSynchronize(st));
-    finish_step_host(t, t->h_loss, task_weights, update, lr, bc1, bc2, losses_host);
+    double lv[mlt::LOSS_NV];
+    for (int q = 0; q < mlt::LOSS_NV; ++q) {
+        double a = 0.0;
+        for (int b = 0; b < hl_grid; ++b) a += t->h_loss[b * mlt::LOSS_NV + q];
+        lv[q] = a;
+    }
+    finish_step_host(t, lv, task_weights, update, lr, bc1, bc2, losses_host);
     return ML_OK;
 }
 
@@ -843,7 +828,8 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
     T_TRY(hipMalloc((void**)&t->bn_invstd, (size_t)t->nbn * hidden * 4));
     t->red_slots = red_slots_for(num_stage);
     T_TRY(hipMalloc((void**)&t->d_red_base, (size_t)t->red_slots * (2 * hidden + 32) * sizeof(double)));
-    T_TRY(hipHostMalloc((void**)&t->h_loss, 16 * sizeof(double), hipHostMallocDefault));
+    T_TRY(hipHostMalloc((void**)&t->h_loss, HL_GRID * mlt::LOSS_NV * sizeof(double), hipHostMallocDefault));
+    T_TRY(hipMalloc((void**)&t->d_lpart, HL_GRID * mlt::LOSS_NV * sizeof(double)));
     {   // flat offsets of the H x H matrices by Linear slot (2s, 2s + 1 = stage s w1 / w2, 2S = w2, 2S + 1 = w3) and the
         // segments between them (everything else), for the mid route's gradient norm
         std::vector<std::string> names;
@@ -880,18 +866,6 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
         t->ssq_per_mat = (hidden / mlt::XG_BN) * (hidden / mlt::XG_BM);
         T_TRY(hipMalloc((void**)&t->d_ssq, (size_t)t->mat_off.size() * t->ssq_per_mat * sizeof(double)));
         T_TRY(hipMalloc((void**)&t->d_gn, mlt::GN_PARTS * sizeof(double)));
-        T_TRY(hipMalloc((void**)&t->wmaxw, 32 * sizeof(float)));
-        T_TRY(hipMemset(t->wmaxw, 0, 32 * sizeof(float)));
-        T_TRY(hipMalloc((void**)&t->dzw, 64 * sizeof(float)));
-        T_TRY(hipMemset(t->dzw, 0, 64 * sizeof(float)));
-        t->lay.hh = (long)hidden * hidden;
-        t->lay.stride = t->lay.hh + 3L * hidden;
-        t->lay.nreg = 2 * num_stage;
-        t->lay.base0 = num_stage ? t->mat_off[0] : 0;
-        t->lay.off_w2 = t->mat_off[2 * num_stage];
-        t->lay.off_w3 = t->mat_off[2 * num_stage + 1];
-        for (int k = 0; k < 2 * num_stage; ++k)
-            if (t->mat_off[k] != t->lay.base0 + k * t->lay.stride) return tfail(ML_ERR_HIP, "unexpected parameter layout (internal)");
         T_TRY(hipStreamCreateWithFlags(&t->st2, hipStreamNonBlocking));
         for (int i = 0; i < 2 * num_stage + 3; ++i) {
             hipEvent_t e0, e1;
@@ -923,7 +897,7 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (hipEvent_t e : t->ev_dz) (void)hipEventDestroy(e);
     for (hipEvent_t e : t->ev_w) (void)hipEventDestroy(e);
     if (t->st2) (void)hipStreamDestroy(t->st2);
-    void* ptrs[] = {t->wmaxw, t->dzw, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    void* ptrs[] = {t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -944,7 +918,6 @@ static int xfer(ml_trainer* t, const char* key, float* host, const float* chost,
     T_TRY(hipDeviceSynchronize());
     if (what == 0) {
         T_TRY(hipMemcpy(base + it->second.off, chost, (size_t)numel * 4, hipMemcpyHostToDevice));
-        t->wmax_dirty = true;   // the mid route's max |W| word is recomputed by its next step
     } else T_TRY(hipMemcpy(host, base + it->second.off, (size_t)numel * 4, hipMemcpyDeviceToHost));
     return ML_OK;
 }
@@ -996,15 +969,18 @@ int ml_trainer_set_route(ml_trainer* t, int route, int64_t fast_rows) {
 
 int ml_trainer_last_route(const ml_trainer* t) { return t ? t->last_route : -1; }
 
-int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream, int mid_precision) {
+int ml_trainer_last_val_values(const ml_trainer* t, double* host2) {
+    if (!t || !host2) return tfail(ML_ERR_ARG, "null argument");
+    host2[0] = t->last_vals[0];
+    host2[1] = t->last_vals[1];
+    return ML_OK;
+}
+
+int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream) {
     if (!t || (apply_cols != 0 && apply_cols != 4 && apply_cols != 8 && apply_cols != 16))
         return tfail(ML_ERR_ARG, "apply_cols must be 4, 8 or 16 (0: unchanged)");
     if (apply_cols) t->apply_cols = apply_cols;
     if (side_stream >= 0) t->side_stream = side_stream ? 1 : 0;
-    if (mid_precision >= 0) {
-        if ((mid_precision != 0) != (t->mid_prec != 0)) t->wmax_dirty = true;
-        t->mid_prec = mid_precision ? 1 : 0;
-    }
     return ML_OK;
 }
 
@@ -1022,13 +998,12 @@ int ml_trainer_debug_read(ml_trainer* t, int which, float* host_data, int64_t nu
 }
 
 int ml_debug_xgemm(const float* a_dev, int64_t lda, int a_layout, const float* b_dev, int64_t ldb, int b_layout, float* c_dev, int M,
-                   int N, int K, const float* bias_dev, const float* res_dev, double* sumsq_dev, int precision, const float* amax_dev,
-                   const float* bmax_dev, void* stream) {
+                   int N, int K, const float* bias_dev, const float* res_dev, double* sumsq_dev, void* stream) {
     if (!a_dev || !b_dev || !c_dev || M < 1 || N < 64 || N % 64 || K < 1) return tfail(ML_ERR_ARG, "bad xgemm shape");
     if ((a_layout == 0 && K % 32) || (a_layout == 1 && M % 32) || (b_layout == 0 && K % 32))
         return tfail(ML_ERR_ARG, "xgemm: a k-contiguous operand needs K % 32 == 0, a reduction-major A needs M % 32 == 0");
     return launch_xgemm((hipStream_t)stream, a_dev, (long)lda, a_layout, b_dev, (long)ldb, b_layout, c_dev, N, M, N, K, bias_dev, res_dev,
-                        sumsq_dev, precision, amax_dev, bmax_dev);
+                        sumsq_dev);
 }
 
 int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m,
@@ -1102,7 +1077,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
                        t->d_dout, d_loss, (const float*)(task_weights ? t->d_tw : nullptr));
     double lv[16];
-    T_TRY(hipMemcpyAsync(lv, d_loss, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    T_TRY(hipMemcpyAsync(lv, d_loss, mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));
     // ---------------- backward
     T_TRY(hipMemsetAsync(t->g, 0, (size_t)t->n_param * 4, st));
     // heads: column sums of dout give both biases
@@ -1172,10 +1147,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         hipLaunchKernelGGL(mlt::sumsq_kernel, dim3(512), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
         hipLaunchKernelGGL(mlt::clip_adam_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
                            (const double*)d_ss, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);
-        if (update) {
-            t->step++;
-            t->wmax_dirty = true;
-        }
+        if (update) t->step++;
     }
     T_TRY(hipStreamSynchronize(st));
     finish_step_host(t, lv, task_weights, update, lr, bc1, bc2, losses_host);

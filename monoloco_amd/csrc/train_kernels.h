@@ -829,63 +829,73 @@ __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const f
 // [theta, psi, z, d, h, w, l, sin, cos, yaw(, aux)] (process.py:293-301).  Writes dout (m, C) = dLoss/dout and
 // accumulates the 8 per-task mean losses in fp64 (index 0..7 = d, x, y, h, w, l, ori, aux).
 // tw (8 floats, or null = all 1): per-task weights of AutoTuneMultiTaskLoss (losses.py:17-43), 1 / (2 exp(log_sigma)^2);
-// they scale dout only -- the accumulated means stay the plain task losses.
+// they scale dout only -- the accumulated means stay the plain task losses.  losses: LOSS_NV doubles (see loss_row).
+// one row: o = raw network row (C), y = label row; g (C) receives dLoss/dout (null: values only); t[0..8) = the task terms d, x,
+// y, h, w, l, ori, aux of this row (to be averaged over the batch); t[8], t[9] = the two VALIDATION-type terms that differ from
+// the training ones (losses.py:85-96): |mu - d| (L1 instead of Laplace) and the angle error |atan2(o7, o8) - atan2(y7, y8)| in
+// radians (the reference logs them for the training phase as well, trainer.py:163-165).
+__device__ __forceinline__ void loss_row(const float* o, const float* y, int C, int64_t m, const float* w8, float* g, double* t) {
+    const float invm = 1.f / (float)m;
+    // LaplacianLoss on (mu, s) = out[2:4] vs d = lab[3]: |1 - mu/x| exp(-s) + 0.01 + s + 2   (losses.py:112-131)
+    const float mu = o[2], s = o[3], x = y[3];
+    const float norm = 1.f - mu / x, es = expf(-s);
+    t[0] = (double)(fabsf(norm) * es + 0.01f + s + 2.f);
+    const float sg = norm > 0.f ? 1.f : (norm < 0.f ? -1.f : 0.f);
+    if (g) {
+        g[2] = -sg / x * es * invm * w8[0];
+        g[3] = (1.f - fabsf(norm) * es) * invm * w8[0];
+    }
+    // L1 on x (col 0 vs lab 0), y (1 vs 1), h, w, l (4..6 vs 4..6)
+    const int oc[5] = {0, 1, 4, 5, 6}, lc[5] = {0, 1, 4, 5, 6};
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const float d = o[oc[q]] - y[lc[q]];
+        t[1 + q] = (double)fabsf(d);
+        if (g) g[oc[q]] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * invm * w8[1 + q];
+    }
+    // L1 on ori (cols 7,8 vs lab 7,8): mean over 2m elements
+    double so = 0;
+#pragma unroll
+    for (int q = 7; q < 9; ++q) {
+        const float d = o[q] - y[q];
+        so += (double)fabsf(d);
+        if (g) g[q] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * invm * 0.5f * w8[6];
+    }
+    t[6] = so * 0.5;
+    t[7] = 0.0;
+    if (C == 10) {  // BCEWithLogits on the aux logit vs lab[10]
+        const float a = o[9], yy = y[10];
+        t[7] = (double)(fmaxf(a, 0.f) - a * yy + log1pf(expf(-fabsf(a))));
+        if (g) g[9] = (1.f / (1.f + expf(-a)) - yy) * invm * w8[7];
+    }   // (mono: column 8 is (sin, cos)[1]; the aux head is the last column only for stereo)
+    t[8] = (double)fabsf(mu - x);
+    t[9] = (double)fabsf(atan2f(o[7], o[8]) - atan2f(y[7], y[8]));
+}
+
+constexpr int LOSS_NV = 10;   // values per row / per step: 8 task terms + the two validation-type ones
+
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out, int C, const float* __restrict__ lab, int L,
                                                   int64_t m, float* __restrict__ dout, double* __restrict__ losses,
                                                   const float* __restrict__ tw) {
-    __shared__ double red[8][256];
+    __shared__ double red[LOSS_NV][256];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double t[LOSS_NV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (i < m) {
-        const float* o = out + i * C;
-        const float* y = lab + i * L;
-        float* g = dout + i * C;
-        const float invm = 1.f / (float)m;
         float w8[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) w8[q] = tw ? tw[q] : 1.f;
-        // LaplacianLoss on (mu, s) = out[2:4] vs d = lab[3]: |1 - mu/x| exp(-s) + 0.01 + s + 2   (losses.py:112-131)
-        const float mu = o[2], s = o[3], x = y[3];
-        const float norm = 1.f - mu / x, es = expf(-s);
-        t[0] = (double)(fabsf(norm) * es + 0.01f + s + 2.f);
-        const float sg = norm > 0.f ? 1.f : (norm < 0.f ? -1.f : 0.f);
-        g[2] = -sg / x * es * invm * w8[0];
-        g[3] = (1.f - fabsf(norm) * es) * invm * w8[0];
-        // L1 on x (col 0 vs lab 0), y (1 vs 1), h, w, l (4..6 vs 4..6)
-        const int oc[5] = {0, 1, 4, 5, 6}, lc[5] = {0, 1, 4, 5, 6};
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const float d = o[oc[q]] - y[lc[q]];
-            t[1 + q] = (double)fabsf(d);
-            g[oc[q]] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * invm * w8[1 + q];
-        }
-        // L1 on ori (cols 7,8 vs lab 7,8): mean over 2m elements
-        double so = 0;
-#pragma unroll
-        for (int q = 7; q < 9; ++q) {
-            const float d = o[q] - y[q];
-            so += (double)fabsf(d);
-            g[q] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * invm * 0.5f * w8[6];
-        }
-        t[6] = so * 0.5;
-        if (C == 10) {  // BCEWithLogits on the aux logit vs lab[10]
-            const float a = o[9], yy = y[10];
-            t[7] = (double)(fmaxf(a, 0.f) - a * yy + log1pf(expf(-fabsf(a))));
-            g[9] = (1.f / (1.f + expf(-a)) - yy) * invm * w8[7];
-        } else if (C == 9) {
-            // mono: column 8 is (sin,cos)[1]; the aux head is the last column only for stereo -- nothing to do
-        }
+        loss_row(out + i * C, lab + i * L, C, m, w8, dout + i * C, t);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) red[q][threadIdx.x] = t[q];
+    for (int q = 0; q < LOSS_NV; ++q) red[q][threadIdx.x] = t[q];
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+            for (int q = 0; q < LOSS_NV; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x < 8) atomicAdd(&losses[threadIdx.x], red[threadIdx.x][0] / (double)m);
+    if (threadIdx.x < LOSS_NV) atomicAdd(&losses[threadIdx.x], red[threadIdx.x][0] / (double)m);
 }
 
 // sum of squares of a flat fp32 buffer (gradient norm), fp64

@@ -37,8 +37,6 @@ struct XGemmParams {
     double* sumsq;       // optional: sum of squares of this workgroup's part of C -> sumsq[blockIdx.y * gridDim.x + blockIdx.x]
     long lda, ldb, ldc;
     int M, N, K;         // N % 64 == 0; rows beyond M are clamped on load and never stored
-    const float* amax;   // PREC 1: optional device words max |A| / max |B| (power-of-two operand scaling; null: unscaled, clamped)
-    const float* bmax;
 };
 
 constexpr int XG_BM = 32, XG_BN = 64;
@@ -50,13 +48,11 @@ constexpr int XG_A_BYTES = XG_BM * 128, XG_STAGE = XG_A_BYTES + XG_BN * 128;
 // 8 k values with a stride (32 consecutive lanes = 32 consecutive banks).
 // Waves: 2 (n halves of the 64 columns) x 2 (k16 halves of every k32 step); a wave issues 8 MFMAs per k-step: MFMA e
 // contracts k = 16 wk + e (lanes 0..31) and k = 16 wk + 8 + e (lanes 32..63).  The two k halves meet in LDS at the end.
-// PREC 0: the exact fp32 matrix instruction (8 x v_mfma_f32_32x32x2_f32 per wave and k-step: 512 cycles).
-// PREC 1: the 3-product fp16 scheme of the inference path (dense_kernel.h): the 8 fp32 values a lane holds per operand ARE
-//   the A / B register of v_mfma_f32_32x32x16_f16 for its k16 half; they are split into fp16 hi | lo in registers (2 VALU per
-//   value, v_fma_mix) and multiplied as hi.lo + lo.hi + hi.hi = 3 x 32 cycles, fp32 accumulate: fp32-class accuracy (2^-22
-//   per operand) at a third of the loop time.  An operand with a max |.| word is scaled by the power of two that puts its
-//   maximum at 2^13..2^14 (gradients would sit in fp16's subnormal range otherwise); one without is clamped to +-65504.
-template <int ALAY, int BLAY, int PREC = 0>
+// (Round 3 also measured the 3-product fp16 scheme with the operands split in the consumer's registers -- the 8 fp32 values a
+// lane holds per operand ARE the A / B register of v_mfma_f32_32x32x16_f16 for its k16 half -- at 20.0 us per 331 x 1024 x 1024
+// product against 15.7 us for this kernel: 40 conversion instructions per wave and k-step cost more than the 16 x slower matrix
+// instruction; profiles/r03_train_kernel_stats_rows331_f16x3_in_registers.txt.)
+template <int ALAY, int BLAY>
 __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * XG_STAGE];
     __shared__ double wsum[4];
@@ -68,14 +64,6 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
     const int nk = (p.K + 31) / 32, last = nk - 1;
     // position i of the k loop -> k-step (positions past the end repeat the final one)
     auto seq = [&](int i) -> int { return i < last ? i : last; };
-    float sa = 1.f, sb = 1.f, descale = 1.f;
-    if (PREC == 1) {
-        const int ea = p.amax ? wscale_exp(*p.amax) : 0, eb = p.bmax ? wscale_exp(*p.bmax) : 0;
-        sa = ldexpf(1.0f, ea);
-        sb = ldexpf(1.0f, eb);
-        descale = ldexpf(1.0f, -(ea + eb));
-    }
-
 
     // ---- loader: every thread issues 3 16-byte loads per k-step (1 of A, 2 of B), full 128 / 256-byte row segments per
     // 8 / 16 lanes; unconditional, same order every step.  Addresses = a wave-uniform base that moves with the k-step (SGPRs)
@@ -187,41 +175,6 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[e0 + e], F.b[e0 + e], acc, 0, 0, 0);
     };
-    // PREC 1: 8 fp32 -> packed fp16 hi and lo halves of (v * d): v_fma_mixlo/hi write the rounded product, then the rounded
-    // remainder against it (exact subtraction).  clampd: without a scale word the value is first clamped to the fp16 range.
-    typedef _Float16 half8x __attribute__((ext_vector_type(8)));
-    typedef unsigned u32x4x __attribute__((ext_vector_type(4)));
-    auto split8 = [&](const float (&v)[8], float d, bool clampd, half8x& hi, half8x& lo) {
-        u32x4x h, l;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float c0 = v[2 * q], c1 = v[2 * q + 1];
-            if (clampd) {
-                const float lim = 65504.0f;
-                asm("v_med3_f32 %0, %1, -%2, %2" : "=v"(c0) : "v"(c0), "v"(lim));
-                asm("v_med3_f32 %0, %1, -%2, %2" : "=v"(c1) : "v"(c1), "v"(lim));
-            }
-            unsigned hh2, ll2;
-            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh2) : "v"(c0), "v"(d));
-            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh2) : "v"(c1), "v"(d));
-            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ll2) : "v"(c0), "v"(d), "v"(hh2));
-            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ll2) : "v"(c1), "v"(d), "v"(hh2));
-            h[q] = hh2;
-            l[q] = ll2;
-        }
-        hi = __builtin_bit_cast(half8x, h);
-        lo = __builtin_bit_cast(half8x, l);
-    };
-    const bool clamp_a = p.amax == nullptr, clamp_b = p.bmax == nullptr;
-    auto mma3 = [&](const Frag& F) {
-        half8x ah, al, bh, bl;
-        split8(F.a, sa, clamp_a, ah, al);
-        split8(F.b, sb, clamp_b, bh, bl);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-    };
-
     // Pipeline.  The operands come from HBM / the last-level cache for the first time (the producer ran on other XCDs): ~0.8 us
     // per request, against 0.25 us of MFMA time per k-step -- with the rows of only one further step in flight the loop ran at
     // 0.52 us per step whatever it computed (round 3, profiles/r03_*).  So FOUR register sets: at the top of step t, stage
@@ -238,17 +191,11 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
         gload(Rl, seq(i + 5));
         mask(Fc, i);
         __builtin_amdgcn_sched_barrier(0);
-        if (PREC == 0) {
-            mma4(Fc, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            lstore(Rs, sc);               // step i+2
-            __builtin_amdgcn_sched_barrier(0);
-            mma4(Fc, 4);
-        } else {
-            mma3(Fc);                     // (the conversion's VALU work covers the three MFMAs; the stores follow)
-            __builtin_amdgcn_sched_barrier(0);
-            lstore(Rs, sc);
-        }
+        mma4(Fc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(Rs, sc);                   // step i+2
+        __builtin_amdgcn_sched_barrier(0);
+        mma4(Fc, 4);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     };
@@ -288,7 +235,7 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
         for (int r = 0; r < 16; ++r) {
             const int i = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (i < p.M) {
-                float v = (PREC == 1 ? acc[r] * descale : acc[r]) + bj;
+                float v = acc[r] + bj;
                 const size_t o = (size_t)i * p.ldc + j;
                 if (p.res) v += p.res[o];
                 p.c[o] = v;
@@ -515,7 +462,6 @@ struct BwdApplyParams {
     long m;
     int H;
     float* dz;
-    float* dzmax;    // optional word: max |dz| folded in with atomicMax (the scale of the 3-product GEMMs that read dz)
     float* dgamma;
     float* dbeta;
     float* dbias;
@@ -643,7 +589,6 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(BwdApplyParams p) {
         }
     }
     double s2[1][4] = {{0.0, 0.0, 0.0, 0.0}};
-    float mx = 0.f;
     for (long base = 0; base < p.m; base += chunk) {
         if (!single) fetch(base);
 #pragma unroll
@@ -661,20 +606,9 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(BwdApplyParams p) {
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s2[0][e] += (double)o[e];
-                    mx = __builtin_fmaxf(mx, __builtin_fabsf(o[e]));
-                }
+                for (int e = 0; e < 4; ++e) s2[0][e] += (double)o[e];
                 *(f32x4*)(p.dz + i * H + j) = o;
             }
-        }
-    }
-    if (p.dzmax) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
-        if ((tid & 63) == 0) {
-            if (!(mx < 3.0e38f)) mx = 3.0e38f;
-            atomicMax((unsigned*)p.dzmax, __builtin_bit_cast(unsigned, mx));
         }
     }
     __syncthreads();   // (red is read above by the threads tid < NC)
@@ -761,6 +695,90 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(BwdApplyParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Both output heads + the multi-task loss + its gradient in ONE launch (train_kernels.h: skinny_heads_kernel<1>,
+// skinny_heads_kernel<8|9>, loss_kernel, and the memset their atomics needed): a wave per row computes the C dot products
+// (w_fin on y3, w_aux on y2; skinny_heads_kernel's fma order and butterfly), lane 0 evaluates loss_row and writes the raw row
+// and dLoss/dout; the per-workgroup sums of the LOSS_NV row terms go to part[blockIdx.x][.] / m -- the host adds the few
+// workgroups in order (no atomics, no zeroing).  dout == null: values only (evaluation).
+struct HeadsLossParams {
+    const float* y3;
+    const float* y2;
+    const float* w_fin;   // [C-1][H]
+    const float* b_fin;
+    const float* w_aux;   // [H]
+    const float* b_aux;
+    const float* lab;
+    int L;
+    long m;
+    int H;
+    float* out;           // [m][C]
+    float* dout;          // [m][C] or null
+    const float* tw;      // 8 task weights or null
+    double* part;         // [gridDim.x][LOSS_NV]
+};
+constexpr int HL_MAXW = 15360;   // floats of head weights a workgroup stages in LDS (C * H <= HL_MAXW)
+
+template <int C>
+__global__ __launch_bounds__(256) void heads_loss_kernel(HeadsLossParams p) {
+    __shared__ __attribute__((aligned(16))) float wl[HL_MAXW];
+    __shared__ double wred[4][LOSS_NV];
+    const int n = p.H;
+    for (int idx = threadIdx.x; idx < (C - 1) * n; idx += 256) wl[idx] = p.w_fin[idx];
+    for (int idx = threadIdx.x; idx < n; idx += 256) wl[(C - 1) * n + idx] = p.w_aux[idx];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float w8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w8[q] = p.tw ? p.tw[q] : 1.f;
+    double tsum[LOSS_NV];
+#pragma unroll
+    for (int q = 0; q < LOSS_NV; ++q) tsum[q] = 0.0;
+    for (long i = (long)blockIdx.x * 4 + wv; i < p.m; i += (long)gridDim.x * 4) {
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+        for (int j = lane * 4; j < n; j += 256) {
+            const f32x4 v3 = *(const f32x4*)(p.y3 + i * n + j), v2 = *(const f32x4*)(p.y2 + i * n + j);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const f32x4 ww = *(const f32x4*)&wl[c * n + j];
+                const f32x4 v = (c == C - 1) ? v2 : v3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c] = __builtin_fmaf(v[e], ww[e], acc[c]);
+            }
+        }
+        float o[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float a = acc[c];
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) a += __shfl_xor(a, s, 64);
+            o[c] = a + (c == C - 1 ? p.b_aux[0] : p.b_fin[c]);
+        }
+        if (lane == 0) {
+            float g[C];
+            double t[LOSS_NV];
+            loss_row(o, p.lab + i * p.L, C, p.m, w8, p.dout ? g : nullptr, t);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                p.out[i * C + c] = o[c];
+                if (p.dout) p.dout[i * C + c] = g[c];
+            }
+#pragma unroll
+            for (int q = 0; q < LOSS_NV; ++q) tsum[q] += t[q];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < LOSS_NV; ++q) wred[wv][q] = tsum[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < LOSS_NV)
+        p.part[(size_t)blockIdx.x * LOSS_NV + threadIdx.x] =
+            ((wred[0][threadIdx.x] + wred[1][threadIdx.x]) + (wred[2][threadIdx.x] + wred[3][threadIdx.x])) / (double)p.m;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Gradient norm^2 for clip_grad_norm_: the weight-gradient GEMMs leave one partial sum of squares per workgroup (nslots
 // doubles); the narrow tensors (everything that is not an H x H matrix: `segs`) are summed here.  Fixed order at both
 // levels: the same gradients always give the same norm (the exact route's sumsq_kernel adds with atomics).
@@ -774,9 +792,8 @@ struct AdamSegs {
 constexpr int GN_PARTS = 64;
 // level 1: GN_PARTS workgroups, each a strided share of the slots and of every narrow segment -> part[blockIdx.x]
 __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__ g, AdamSegs segs, const double* __restrict__ slots, int nslots,
-                                                       double* __restrict__ part, float* __restrict__ zero_word) {
+                                                       double* __restrict__ part) {
     __shared__ double red[256];
-    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0.f;   // max |W| of the weights the optimizer is about to write
     const int gt = blockIdx.x * 256 + threadIdx.x, gn = GN_PARTS * 256;
     double a = 0.0;
     for (int i = gt; i < nslots; i += gn) a += slots[i];
@@ -794,88 +811,33 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(const float* __restrict__
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
-// Where the H x H weight matrices lie in the flat parameter buffer: 2 S of them at base0 + k * stride (a stage Linear is
-// followed by its bias and one BatchNorm's weight + bias: stride = H^2 + 3 H), then w2 and w3.
-struct MatLayout {
-    long base0, stride, hh, off_w2, off_w3;
-    int nreg;
-};
-__device__ __forceinline__ bool block_in_matrix(const MatLayout& L, long i0, long i1) {   // [i0, i1] inside ONE matrix
-    if (i0 >= L.off_w3) return i1 < L.off_w3 + L.hh;
-    if (i0 >= L.off_w2) return i1 < L.off_w2 + L.hh;
-    if (i0 < L.base0) return false;
-    const long q = (i0 - L.base0) / L.stride, r0 = (i0 - L.base0) - q * L.stride;
-    return q < L.nreg && r0 + (i1 - i0) < L.hh;
-}
-
-// level 2 inside the optimizer: every workgroup adds the GN_PARTS partial sums in the same order.  clip_adam_kernel's
-// arithmetic.  On the way: max |w| over the H x H matrices after the update -> wmax_next (zeroed by gradnorm_kernel; the scale
-// of the next step's 3-product GEMMs; workgroups that straddle a matrix edge -- 2 per matrix -- do not contribute), and
-// workgroup 0 zeroes the per-step max |dz| words for the next step.
+// level 2 inside the optimizer: every workgroup adds the GN_PARTS partial sums in the same order.  clip_adam_kernel's arithmetic.
 __global__ __launch_bounds__(256) void clip_adam_parts_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m1,
                                                              float* __restrict__ m2, int64_t n, const double* __restrict__ part,
                                                              float max_norm, float lr, float b1, float b2, float eps, float bc1,
-                                                             float bc2, int do_adam, MatLayout lay, float* __restrict__ wmax_next,
-                                                             float* __restrict__ zero_words, int n_zero) {
+                                                             float bc2, int do_adam) {
     __shared__ double tot;
-    __shared__ float wmx[4];
     if (threadIdx.x < 64) {
         double v = part[threadIdx.x];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
         if (threadIdx.x == 0) tot = v;
     }
-    if (blockIdx.x == 0 && zero_words && (int)threadIdx.x < n_zero) zero_words[threadIdx.x] = 0.f;
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float wn = 0.f;
-    if (i < n) {
-        const float norm = (float)sqrt(tot);
-        float coef = max_norm / (norm + 1e-6f);
-        coef = coef > 1.f ? 1.f : coef;
-        const float gi = g[i] * coef;
-        g[i] = gi;
-        wn = w[i];
-        if (do_adam) {
-            const float a = m1[i] + (gi - m1[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
-            const float v = b2 * m2[i] + (1.f - b2) * gi * gi;
-            m1[i] = a;
-            m2[i] = v;
-            const float denom = sqrtf(v) / sqrtf(bc2) + eps;
-            wn -= (lr / bc1) * (a / denom);
-            w[i] = wn;
-        }
-    }
-    if (wmax_next) {   // (uniform)
-        const int64_t i0 = (int64_t)blockIdx.x * 256;
-        const int64_t i1 = i0 + 255 < n - 1 ? i0 + 255 : n - 1;
-        if (block_in_matrix(lay, i0, i1)) {   // (uniform)
-            float mx = __builtin_fabsf(wn);
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
-            if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                mx = __builtin_fmaxf(__builtin_fmaxf(wmx[0], wmx[1]), __builtin_fmaxf(wmx[2], wmx[3]));
-                if (!(mx < 3.0e38f)) mx = 3.0e38f;
-                atomicMax((unsigned*)wmax_next, __builtin_bit_cast(unsigned, mx));
-            }
-        }
-    }
-}
-
-// max |w| over the H x H matrices (after set_tensor / a step of another route; the word is zeroed by the caller)
-__global__ __launch_bounds__(256) void wmax_mats_kernel(const float* __restrict__ w, int64_t n, MatLayout lay, float* __restrict__ wmax) {
-    const int64_t i0 = (int64_t)blockIdx.x * 256;
-    const int64_t i1 = i0 + 255 < n - 1 ? i0 + 255 : n - 1;
-    if (!block_in_matrix(lay, i0, i1)) return;
-    float mx = __builtin_fabsf(w[i0 + threadIdx.x]);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) {
-        if (!(mx < 3.0e38f)) mx = 3.0e38f;
-        atomicMax((unsigned*)wmax, __builtin_bit_cast(unsigned, mx));
-    }
+    if (i >= n) return;
+    const float norm = (float)sqrt(tot);
+    float coef = max_norm / (norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    const float gi = g[i] * coef;
+    g[i] = gi;
+    if (!do_adam) return;
+    const float a = m1[i] + (gi - m1[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = b2 * m2[i] + (1.f - b2) * gi * gi;
+    m1[i] = a;
+    m2[i] = v;
+    const float denom = sqrtf(v) / sqrtf(bc2) + eps;
+    w[i] -= (lr / bc1) * (a / denom);
 }
 
 }  // namespace mlt

@@ -1,5 +1,5 @@
-# round 3, GPU call I: mid route on the exact-fp32 xgemm
-O=$GRAFT_REPO_ROOT/gpurun_out/r03i; mkdir -p $O; cd $GRAFT_REPO_ROOT
+# round 3, GPU call J: mid route on the exact-fp32 xgemm
+O=$GRAFT_REPO_ROOT/gpurun_out/r03j; mkdir -p $O; cd $GRAFT_REPO_ROOT
 timeout 600 python -m pytest tests/test_gpu_train_mid.py tests/test_gpu_train.py -q -m gpu --timeout 300 > $O/pytest_train.txt 2>&1; echo "pytest rc $?"
 tail -15 $O/pytest_train.txt
 timeout 300 python tools/r03_mid_bringup.py compare > $O/compare.txt 2>&1; echo "compare rc $?"
