@@ -244,11 +244,23 @@ int64_t ml_trainer_num_steps(const ml_trainer* t);
 int ml_trainer_set_route(ml_trainer* t, int route, int64_t fast_rows);
 /* route of the last ml_trainer_step: 0 exact, 1 large-batch, 2 mid (-1: no step yet) */
 int ml_trainer_last_route(const ml_trainer* t);
-/* The two validation-type values of the last step's (train-mode) outputs that differ from the training task values
- * (losses.py:85-96; the reference logs them for the training phase too, trainer.py:163-165): host2[0] = mean |mu - d| (L1 instead
- * of the Laplace loss), host2[1] = mean |atan2(out7, out8) - atan2(sin, cos)| in radians.  The other validation-type values equal
- * the task values ml_trainer_step returns (x, y, h, w, l: L1; aux: BCE). */
-int ml_trainer_last_val_values(const ml_trainer* t, double* host2);
+/* The unweighted values of the last step's (train-mode) outputs the reference logs for the training phase as well
+ * (trainer.py:163-165, losses.py:85-96): host10[0..7] = the plain task means d (Laplace), x, y, h, w, l, ori (L1), aux (BCE) --
+ * ml_trainer_step reports them weighted when task weights are set --, host10[8] = mean |mu - d| (the validation-type value of d),
+ * host10[9] = mean |atan2(out7, out8) - atan2(sin, cos)| in radians (that of ori). */
+int ml_trainer_last_val_values(const ml_trainer* t, double* host10);
+/* The validation pass of the reference's loop (trainer.py:167-178: model.eval(), no_grad) on the trainer's OWN weights: eval-mode
+ * forward (BatchNorm with the running statistics, no dropout; nothing is updated) of a batch resident on the device, on the mid
+ * route's kernels (hidden % 64 == 0; ML_ERR_SHAPE otherwise: use ml_loco_* on the state_dict).  vals_host (10): the means of the
+ * training-type task terms d (Laplace), x, y, h, w, l, ori, aux, then the validation-type d (L1) and ori (angle, radians).
+ * raw_out_dev (m, out_features) optionally receives the outputs.  Synchronises the stream. */
+int ml_trainer_eval(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m, double* vals_host,
+                    float* raw_out_dev, void* stream);
+/* The best-epoch bookkeeping of the reference's loop (trainer.py:173-177, 183: deepcopy of the state_dict / load_state_dict) without
+ * leaving the device: snapshot = parameters + BatchNorm running statistics copied aside (device to device), restore = copied back
+ * (optimizer state untouched, like load_state_dict). */
+int ml_trainer_snapshot(ml_trainer* t, void* stream);
+int ml_trainer_restore(ml_trainer* t, void* stream);
 /* Per-handle tuning of the mid route, same results: apply_cols = columns per workgroup of the column-owner kernels (4, 8 or 16;
  * default 8; 0 leaves it); side_stream = 1: the weight-gradient GEMMs, which only the optimizer needs, run on an internal side
  * stream beside the data-gradient chain (events both ways; measured to pay from ~2000 rows), 0 (default): everything on the
@@ -298,6 +310,8 @@ int ml_loco_profile_end(ml_loco* h, int64_t* launches, double* total_ms, double*
  * The 256x256-tile kernel runs it unless ML_DEBUG_SMALL_PATH is or-ed into `precision` (then the
  * small-row kernels the model path takes for <= 2048 rows). */
 #define ML_DEBUG_SMALL_PATH 256
+#define ML_DEBUG_TILE_PP 512    /* ... the tile path on dense_kernel_pp */
+#define ML_DEBUG_TILE_W4 1024   /* ... the tile path on dense_kernel_w4 wherever it runs (default: w4 for K > 128) */
 int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, const float* b_host,
                     int n, int relu, const float* res_dev, float* y_dev, int precision, void* stream);
 /* Host fp32 -> fp16 hi/lo split used by the packer (round-to-nearest-even), for unit tests. */
@@ -307,14 +321,12 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
 int ml_debug_get_layer(const ml_loco* h, int layer, float* w_host, float* b_host, int* n, int* k,
                        int* scale_pow2);
 int ml_debug_num_layers(const ml_loco* h);
-/* Process-global path selection, for tests that compare the paths (negative = leave unchanged; defaults
- * 2048 / 128 / 0): rows <= small_rows take the small-row dense kernels, above small32_rows those use
- * 32x32 tiles; chunk_rows > 0 walks the batch in row chunks of that size through all layers. */
-int ml_debug_set_tuning(int small_rows, int small32_rows, int chunk_rows);
-/* Which kernel runs the 256x256-tile path: 4 = dense_kernel_w4 for the long-K layers, dense_kernel_pp for the short
- * input layer and the fused-head layer (default); 2 = dense_kernel_pp everywhere; 4 | 256 = dense_kernel_w4 wherever it
- * can run (tests). */
-int ml_debug_set_tile_kernel(int which);
+/* Path selection of ONE handle, for tests / A-B runs that compare the paths (negative = leave unchanged; defaults 2048 / 128 /
+ * 0 / 4): rows <= small_rows take the small-row dense kernels, above small32_rows those use 32x32 tiles; chunk_rows > 0 walks
+ * the batch in row chunks of that size through all layers; tile_kernel: 4 = dense_kernel_w4 for the long-K layers,
+ * dense_kernel_pp for the short input layer and the fused-head layer (default), 2 = dense_kernel_pp everywhere, 4 | 256 =
+ * dense_kernel_w4 wherever it can run.  Nothing here is process-global: handles stay thread-compatible. */
+int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel);
 /* Training, bring-up: copy an internal fp32 buffer of the trainer to the host (after a device sync).  which: 0 .. 4S+7 the
  * (rows x hidden) activation / gradient buffers in allocation order (a_0..a_S, t_0.., z0, (za, zb)_s, z3, y2, y3, scratch,
  * gA, gB), 200 / 201 the raw outputs / their gradient. */

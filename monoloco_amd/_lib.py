@@ -22,6 +22,8 @@ ML_PREC_F16X2 = 0
 ML_PREC_F16 = 1
 ML_PREC_BF16 = 2
 ML_DEBUG_SMALL_PATH = 256
+ML_DEBUG_TILE_PP = 512
+ML_DEBUG_TILE_W4 = 1024
 ML_FLAG_MERGE_W2W3 = 1
 ML_FLAG_HOST_ONLY = 256
 ML_OUT_STRIDE = 16
@@ -77,6 +79,9 @@ SIGNATURES = {
     'ml_trainer_set_route': (c_int, [_P, c_int, c_int64]),
     'ml_trainer_last_route': (c_int, [_P]),
     'ml_trainer_last_val_values': (c_int, [_P, POINTER(c_double)]),
+    'ml_trainer_eval': (c_int, [_P, _P, _P, c_int, c_int64, POINTER(c_double), _P, _P]),
+    'ml_trainer_snapshot': (c_int, [_P, _P]),
+    'ml_trainer_restore': (c_int, [_P, _P]),
     'ml_trainer_debug_read': (c_int, [_P, c_int, POINTER(c_float), c_int64]),
     'ml_trainer_set_tuning': (c_int, [_P, c_int, c_int]),
     'ml_debug_xgemm': (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
@@ -95,8 +100,7 @@ SIGNATURES = {
     'ml_debug_get_layer': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
                                    POINTER(c_int)]),
     'ml_debug_num_layers': (c_int, [_P]),
-    'ml_debug_set_tuning': (c_int, [c_int, c_int, c_int]),
-    'ml_debug_set_tile_kernel': (c_int, [c_int]),
+    'ml_loco_set_tuning': (c_int, [_P, c_int, c_int, c_int, c_int]),
     'ml_debug_get_packed': (c_int, [_P, c_int, POINTER(c_uint16), c_int64]),
     'ml_debug_get_head': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_int), POINTER(c_int)]),

@@ -145,7 +145,18 @@ struct Head {
 
 }  // namespace
 
+// Path selection of ONE handle (ml_loco_set_tuning; nothing process-global: a handle per device / stream stays thread-compatible):
+//   rows <= small_rows take the small-row dense kernels (no LDS staging) instead of the 256x256-tile persistent kernel; above
+//   small32_rows those use 32x32 output tiles (16x16 below); chunk_rows > 0 walks the batch in row chunks through all layers
+//   (Infinity-Cache residency experiment, off by default); tile_kernel 4 = dense_kernel_w4 for the long-K layers +
+//   dense_kernel_pp for the input / fused-head layers, 2 = dense_kernel_pp everywhere; tile_all: dense_kernel_w4 wherever it runs.
+struct Tuning {
+    int small_rows = 2048, small32_rows = 128, chunk_rows = 0;
+    int tile_kernel = 4, tile_all = 0;
+};
+
 struct ml_loco {
+    Tuning tune;
     int in_f = 0, hidden = 0, out_f = 0, num_stage = 0;
     int hidden_real = 0;  // the checkpoint's linear_size; `hidden` is that rounded up to the 256-column tile
     int precision = ML_PREC_F16X2, flags = 0;
@@ -433,27 +444,17 @@ int trace_after_launch(unsigned long long* buf, size_t n, int grid, const mlk::D
 
 #endif
 
-// Path selection (process-global; ml_debug_set_tuning is the only writer -- tests switch paths through it):
-//   rows <= g_small_rows take the small-row dense kernels (no LDS staging) instead of the 256x256-tile persistent
-//   kernel; above g_small32_rows those use 32x32 output tiles (16x16 below); g_chunk_rows > 0 walks the batch in row
-//   chunks through all layers (Infinity-Cache residency experiment, off by default).
-int g_small_rows = 2048, g_small32_rows = 128, g_chunk_rows = 0;
-int g_tile_kernel = 4;
-int g_tile_kernel_all = 0;  // test hook: 1 = dense_kernel_w4 for EVERY layer it supports (ml_debug_set_tile_kernel(4 | 256))  // 4 = dense_kernel_w4 (one wave per SIMD, 4-slot ring), 2 = dense_kernel_pp (ping-pong)
-int small_rows_env() { return g_small_rows; }
-int small32_rows_env() { return g_small32_rows; }
-
-bool use_small_path(int precision, int64_t rows) {
+bool use_small_path(const Tuning& tu, int precision, int64_t rows) {
     // (the bf16 comparison mode exists on the tile path only)
-    return dense_variant() != 1 && !dense_debug_bits() && precision != ML_PREC_BF16 && rows <= small_rows_env();
+    return dense_variant() != 1 && !dense_debug_bits() && precision != ML_PREC_BF16 && rows <= tu.small_rows;
 }
 
 // does the tile path run dense_kernel_w4 for a layer with this K (and fused head width)?
-bool w4_runs(int K, int head_nh) {
-    return g_tile_kernel == 4 && K % 64 == 0 && (g_tile_kernel_all || (K > 128 && head_nh <= 0));
+bool w4_runs(const Tuning& tu, int K, int head_nh) {
+    return tu.tile_kernel == 4 && K % 64 == 0 && (tu.tile_all || (K > 128 && head_nh <= 0));
 }
 
-int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0, int64_t rows = -1) {
+int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0, int64_t rows = -1) {
     mlk::DenseParams p = p_in;
     p.debug = dense_debug_bits();
     p.trace = nullptr;
@@ -461,7 +462,7 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, in
     if (rows >= 0 && head_nh == 0) {  // the caller chose the small-row path
         // 16x16 tiles while they are few (latency: more workgroups), 32x32 tiles (half the L2 traffic) once there
         // are at least ~256 of those
-        const bool t32 = rows > small32_rows_env();
+        const bool t32 = rows > tu.small32_rows;
         const int T = t32 ? 32 : 16;
         const dim3 grid((unsigned)(p.N / T), (unsigned)((rows + T - 1) / T));
         if (grid.y == 0) return ML_OK;
@@ -489,7 +490,7 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, in
     }
 
     const int tiles = (p.M_pad / mlk::BM) * (p.N / mlk::BN);
-    if (head_nh == -1 && !w4_runs(p.K, 0)) return fail(ML_ERR_STATE, "fused aux head needs dense_kernel_w4");
+    if (head_nh == -1 && !w4_runs(tu, p.K, 0)) return fail(ML_ERR_STATE, "fused aux head needs dense_kernel_w4");
 #ifdef ML_BRINGUP
     if (dense_variant() == 1) {
         if (precision == ML_PREC_F16X2)
@@ -510,12 +511,11 @@ int launch_dense(int precision, const mlk::DenseParams& p_in, hipStream_t st, in
     int grid = tiles < num_cus() ? tiles : num_cus();
 #ifdef ML_BRINGUP
     if (getenv("ML_GRID_CAP") && atoi(getenv("ML_GRID_CAP")) > 0 && grid > atoi(getenv("ML_GRID_CAP"))) grid = atoi(getenv("ML_GRID_CAP"));
-    if (getenv("ML_TILE_KERNEL")) g_tile_kernel = atoi(getenv("ML_TILE_KERNEL"));  
 #endif
     // dense_kernel_w4 for the long-K layers; the short input layer (K <= 128: two or four k-steps per tile, all epilogue)
     // and the layer with the fused output head stay on dense_kernel_pp, whose two waves per SIMD overlap those
     // VALU-heavy epilogues (measured: 0.063 vs 0.077 ms and 0.351 vs 0.381 ms per layer at 65536 rows)
-    if (w4_runs(p.K, head_nh)) {
+    if (w4_runs(tu, p.K, head_nh)) {
 #define ML_W4(NS, RL, RS, HD) \
     hipLaunchKernelGGL((mlk::dense_kernel_w4<NS, RL, RS, HD>), dim3(grid), dim3(mlk::W4_THREADS), 0, st, p)
 #define ML_W4_NS(NS)                                              \
@@ -600,7 +600,6 @@ int launch_heads(const Head& hd, const char* act, int H, float* raw, int raw_str
     return ML_OK;
 }
 
-int chunk_rows_env() { return g_chunk_rows / 256 * 256; }
 
 // Runs the dense chain + heads on `rows` network rows whose line-format input already sits in
 // buf[0]; leaves raw (rows, out_f) fp32 in raw_out.
@@ -626,8 +625,9 @@ struct TailMono {
 int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass mc = McPass(), TailMono* tail = nullptr) {
     const int64_t m_pad_all = round_up64(rows, 256);
     // (row chunking is an inference experiment knob; the batched MC-dropout passes index their masks by global row)
-    const int64_t chunk = (chunk_rows_env() > 0 && mc.p <= 0.f) ? chunk_rows_env() : m_pad_all;
-    const bool small = use_small_path(h->precision, rows);  // decided on the whole call, not per chunk
+    const int64_t chunk_rows = h->tune.chunk_rows / 256 * 256;
+    const int64_t chunk = (chunk_rows > 0 && mc.p <= 0.f) ? chunk_rows : m_pad_all;
+    const bool small = use_small_path(h->tune, h->precision, rows);  // decided on the whole call, not per chunk
     const bool defer = tail && chunk == m_pad_all;   // head reductions wait for the end of the (single) chunk
     const Head *def_fin = nullptr, *def_aux = nullptr;
     const int nparts = 2 * h->hidden / 256;
@@ -676,7 +676,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             // residual+relu layer when w3*w2 are merged, the plain w2 layer otherwise); its partials have their own region
             // behind the w_fin head's
             const Head* fused_aux = nullptr;
-            if (!fused && !small && mc.p <= 0.f && !dense_debug_bits() && dense_variant() != 1 && w4_runs(L.kpad, 0) &&
+            if (!fused && !small && mc.p <= 0.f && !dense_debug_bits() && dense_variant() != 1 && w4_runs(h->tune, L.kpad, 0) &&
                 ((L.relu && L.res >= 0) || (!L.relu && L.res < 0)))
                 for (const Head& hd : h->heads)
                     if (hd.after_layer == (int)li && hd.nh == 1 && hd.src == L.dst) fused_aux = &hd;
@@ -686,7 +686,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             }
             const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
             if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
-            int rc = launch_dense(h->precision, p, st, fused ? fused->nh : (fused_aux ? -1 : 0), small ? rows_here : -1);
+            int rc = launch_dense(h->tune, h->precision, p, st, fused ? fused->nh : (fused_aux ? -1 : 0), small ? rows_here : -1);
             if (rc) return rc;
             if (timed) {
                 HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));
@@ -1195,7 +1195,7 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
     const mlk::Kinv ki = make_kinv(kinv_host);
     // the small-row dense kernels read whole 32-row tiles only: no need to zero-fill up to the 256-row panel
     hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(m_pad / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
-                       (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, use_small_path(h->precision, m) ? round_up64(m, 32) : m_pad, 0);
+                       (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, use_small_path(h->tune, h->precision, m) ? round_up64(m, 32) : m_pad, 0);
     HIP_TRY(hipGetLastError());
     float* raw = raw_dev ? raw_dev : h->d_raw;
     TailMono tail{h->d_centre, ki, box_conf_dev, out_dev, xyzds_dev, raw_dev};
@@ -1325,20 +1325,18 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
     return ML_OK;
 }
 
-int ml_debug_set_tile_kernel(int which) {
-    const int all = (which & 256) ? 1 : 0;
-    which &= 255;
-    if (which != 2 && which != 4) return fail(ML_ERR_ARG, "tile kernel must be 2 (ping-pong) or 4 (one wave per SIMD)");
-    g_tile_kernel = which;
-    g_tile_kernel_all = all;
-    return ML_OK;
-}
-
-int ml_debug_set_tuning(int small_rows, int small32_rows, int chunk_rows) {
-    // negative = keep; the defaults are 2048 / 128 / 0
-    if (small_rows >= 0) g_small_rows = small_rows;
-    if (small32_rows >= 0) g_small32_rows = small32_rows;
-    if (chunk_rows >= 0) g_chunk_rows = chunk_rows;
+int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel) {
+    // negative = keep; the defaults are 2048 / 128 / 0 / 4
+    if (!h) return fail(ML_ERR_ARG, "null handle");
+    if (tile_kernel >= 0) {
+        const int which = tile_kernel & 255;
+        if (which != 2 && which != 4) return fail(ML_ERR_ARG, "tile kernel must be 2 (ping-pong) or 4 (one wave per SIMD)");
+        h->tune.tile_kernel = which;
+        h->tune.tile_all = (tile_kernel & 256) ? 1 : 0;
+    }
+    if (small_rows >= 0) h->tune.small_rows = small_rows;
+    if (small32_rows >= 0) h->tune.small32_rows = small32_rows;
+    if (chunk_rows >= 0) h->tune.chunk_rows = chunk_rows;
     return ML_OK;
 }
 
@@ -1383,7 +1381,10 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
         return fail(ML_ERR_ARG, "bad argument (n must be a multiple of 256)");
     // the tile kernel unless ML_DEBUG_SMALL_PATH is or-ed into `precision` (then the small-row kernels, any m)
     const bool small_path = (precision & ML_DEBUG_SMALL_PATH) != 0;
-    precision &= ~ML_DEBUG_SMALL_PATH;
+    Tuning tu;   // which tile kernel: ML_DEBUG_TILE_PP = dense_kernel_pp, ML_DEBUG_TILE_W4 = dense_kernel_w4 wherever it runs
+    if (precision & ML_DEBUG_TILE_PP) tu.tile_kernel = 2;
+    if (precision & ML_DEBUG_TILE_W4) tu.tile_all = 1;
+    precision &= ~(ML_DEBUG_SMALL_PATH | ML_DEBUG_TILE_PP | ML_DEBUG_TILE_W4);
     if (small_path && precision == ML_PREC_BF16) return fail(ML_ERR_ARG, "the bf16 mode has no small-row kernels");
     hipStream_t st = (hipStream_t)stream;
     ml_loco tmp;
@@ -1436,7 +1437,7 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
                 hipLaunchKernelGGL(mlk::lines_to_bf16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, rl, pairs);
             }
         }
-        rc = launch_dense(precision, p, st, 0, small_path ? m : -1);
+        rc = launch_dense(tu, precision, p, st, 0, small_path ? m : -1);
         if (!rc) {
             const int64_t groups = m * (n / 8);
             hipLaunchKernelGGL(mlk::lines_to_f32_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, p.y, m,

@@ -112,7 +112,8 @@ struct ml_trainer {
     int apply_cols = 8;              // columns a workgroup of the column-owner kernels takes (4 | 8 | 16): ml_trainer_set_tuning
     double* h_loss = nullptr;        // pinned: up to HL_GRID x LOSS_NV partial sums
     double* d_lpart = nullptr;       // the same on the device (heads_loss_kernel)
-    double last_vals[2] = {0, 0};    // validation-type d (L1) and ori (angle, radians) means of the last step's outputs
+    float* w_snap = nullptr;         // ml_trainer_snapshot: parameters + running statistics kept on the device (best epoch)
+    double last_vals[10] = {0};      // plain task means + validation-type d (L1) / ori (angle, radians) of the last step's outputs
     std::vector<int64_t> mat_off;    // flat offsets of the H x H weight matrices by Linear slot
     mlt::AdamSegs segs;
     int last_route = -1;             // route the last step took (0 exact, 1 fast, 2 mid): ml_trainer_last_route
@@ -226,6 +227,7 @@ int skinny_out(ml_trainer* t, hipStream_t st, const float* s, int lds, int nc, c
     if (gy > 128) gy = 128;
     hipLaunchKernelGGL(mlt::skinny_out_kernel, dim3(t->H / 64, (unsigned)gy), dim3(256), 0, st, s, lds, nc, w, wsc, wsj, bias, out, m,
                        t->H, accumulate);
+    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "skinny product launch failed");
     return 0;
 }
 
@@ -244,7 +246,8 @@ int skinny_dw(ml_trainer* t, hipStream_t st, const float* s, int lds, int nc, co
     return 0;
 }
 
-// out[i][c] = x[i] . w[c] + b[c], c < nc in {1, 8, 9}; false: no kernel for this shape (the caller takes the GEMM)
+// out[i][c] = x[i] . w[c] + b[c], c < nc in {1, 8, 9}; false: no kernel for this shape (H % 4, nc * H <= 15360 floats of LDS): the caller
+// takes the GEMM
 bool skinny_heads(ml_trainer* t, hipStream_t st, const float* x, int64_t m, const float* w, const float* b, int nc, float* out, int ldo) {
     if (t->H % 4 != 0 || (int64_t)nc * t->H > 15360) return false;
     int64_t g = (m + 3) / 4;
@@ -254,7 +257,7 @@ bool skinny_heads(ml_trainer* t, hipStream_t st, const float* x, int64_t m, cons
     else if (nc == 8) hipLaunchKernelGGL(mlt::skinny_heads_kernel<8>, grid, block, 0, st, x, m, t->H, w, b, out, ldo);
     else if (nc == 9) hipLaunchKernelGGL(mlt::skinny_heads_kernel<9>, grid, block, 0, st, x, m, t->H, w, b, out, ldo);
     else return false;
-    return true;
+    return hipGetLastError() == hipSuccess;   // (a failed launch sends the caller to the generic GEMM, which reports its own errors)
 }
 
 struct Block {  // Linear + BatchNorm + ReLU + Dropout
@@ -544,8 +547,7 @@ int upload_task_weights(ml_trainer* t, hipStream_t st, bool task_weights) {
 void finish_step_host(ml_trainer* t, const double* lv, bool task_weights, int update, float lr, float bc1, float bc2,
                       double* losses_host) {
     const int nt = (t->C == 10) ? 8 : 7;
-    t->last_vals[0] = lv[8];
-    t->last_vals[1] = lv[9];
+    for (int i = 0; i < mlt::LOSS_NV; ++i) t->last_vals[i] = lv[i];
     if (losses_host) {
         double tot = 0;
         for (int i = 0; i < 8; ++i) {
@@ -599,6 +601,83 @@ void launch_bwd_apply(const ml_trainer* t, hipStream_t st, const P& p) {
     else hipLaunchKernelGGL(mlt::bwd_apply_kernel<16>, dim3(t->H / 16), blk, 0, st, p);
 }
 
+void sum_loss_parts(const ml_trainer* t, int parts, double* lv) {   // the per-workgroup partial sums, in order
+    for (int q = 0; q < mlt::LOSS_NV; ++q) {
+        double a = 0.0;
+        for (int b = 0; b < parts; ++b) a += t->h_loss[b * mlt::LOSS_NV + q];
+        lv[q] = a;
+    }
+}
+
+// The mid route's forward + heads + loss values (+ loss gradient when training) on the trainer's buffers.  eval: BatchNorm with the
+// running statistics, no dropout, no gradient (the reference's model.eval() forward, trainer.py:167-178).
+int mid_forward(ml_trainer* t, hipStream_t st, const float* x_dev, const float* labels_dev, int label_cols, int64_t m, uint32_t seed,
+                bool eval, bool task_weights, int* hl_grid_out) {
+    const int H = t->H, S = t->S, C = t->C;
+    int rc;
+    int bi = 0;
+    auto nb = [&]() { return t->bufs[bi++]; };
+    std::vector<float*> a(S + 1), tt(S), za(S), zb(S);
+    for (auto& p : a) p = nb();
+    for (auto& p : tt) p = nb();
+    float* z0 = nb();
+    for (int s = 0; s < S; ++s) { za[s] = nb(); zb[s] = nb(); }
+    float* z3 = nb();
+    float* y2 = nb();
+    float* y3 = nb();
+    auto mean_of = [&](int bn_idx) { return t->bn_mean + (size_t)bn_idx * H; };
+    auto inv_of = [&](int bn_idx) { return t->bn_invstd + (size_t)bn_idx * H; };
+    auto fwd_apply = [&](float* z, const std::string& bn, int bn_idx, uint32_t site, const float* residual, float* y, bool input_layer) {
+        mlt::FwdApplyParams p;
+        p.z = input_layer ? nullptr : z;
+        p.x_in = input_layer ? x_dev : nullptr;
+        p.w_in = input_layer ? P(t, "w1.weight") : nullptr;
+        p.b_in = input_layer ? P(t, "w1.bias") : nullptr;
+        p.z_out = input_layer ? z : nullptr;
+        p.in_dim = t->in_f;
+        p.m = (long)m; p.H = H;
+        p.gamma = P(t, bn + ".weight"); p.beta = P(t, bn + ".bias");
+        p.run_mean = ST(t, bn + ".running_mean"); p.run_var = ST(t, bn + ".running_var");
+        p.mean_out = mean_of(bn_idx); p.invstd_out = inv_of(bn_idx);
+        p.p_drop = t->p_drop; p.seed = seed; p.site = site;
+        p.residual = residual; p.y = y;
+        p.eval = eval ? 1 : 0;
+        launch_fwd_apply(t, st, p);
+    };
+    // z (m x H) = x . W^T + b: both operands k-contiguous
+    auto lin_fwd = [&](const float* x, const std::string& lin, float* z) {
+        return launch_xgemm(st, x, H, 0, P(t, lin + ".weight"), H, 0, z, H, (int)m, H, H, P(t, lin + ".bias"), nullptr, nullptr);
+    };
+    fwd_apply(z0, "batch_norm1", 0, 0, nullptr, a[0], true);
+    for (int s = 0; s < S; ++s) {
+        const std::string p = "linear_stages." + std::to_string(s) + ".";
+        if ((rc = lin_fwd(a[s], p + "w1", za[s]))) return rc;
+        fwd_apply(za[s], p + "batch_norm1", 1 + 2 * s, 1 + 2 * s, nullptr, tt[s], false);
+        if ((rc = lin_fwd(tt[s], p + "w2", zb[s]))) return rc;
+        fwd_apply(zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, a[s], a[s + 1], false);   // a_{s+1} = a_s + block(t_s)
+    }
+    if ((rc = lin_fwd(a[S], "w2", y2))) return rc;
+    if ((rc = lin_fwd(y2, "w3", z3))) return rc;
+    fwd_apply(z3, "batch_norm3", 2 * S + 1, 2 * S + 1, nullptr, y3, false);
+    // ---------------- both heads, the loss (and its gradient): one launch, per-workgroup partial sums the host adds
+    int hl_grid = (int)((m + 3) / 4);
+    if (hl_grid > HL_GRID) hl_grid = HL_GRID;
+    {
+        mlt::HeadsLossParams p;
+        p.y3 = y3; p.y2 = y2;
+        p.w_fin = P(t, "w_fin.weight"); p.b_fin = P(t, "w_fin.bias");
+        p.w_aux = P(t, "w_aux.weight"); p.b_aux = P(t, "w_aux.bias");
+        p.lab = labels_dev; p.L = label_cols; p.m = (long)m; p.H = H;
+        p.out = t->d_out; p.dout = eval ? nullptr : t->d_dout;
+        p.tw = task_weights ? t->d_tw : nullptr;
+        p.part = t->d_lpart;
+        if (C == 10) hipLaunchKernelGGL(mlt::heads_loss_kernel<10>, dim3(hl_grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(mlt::heads_loss_kernel<9>, dim3(hl_grid), dim3(256), 0, st, p);
+    }
+    *hl_grid_out = hl_grid;
+    return 0;
+}
+
 int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m, int update,
              double* losses_host, float* raw_out_dev, hipStream_t st) {
     const int H = t->H, S = t->S, C = t->C;
@@ -625,55 +704,11 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     auto mean_of = [&](int bn_idx) { return t->bn_mean + (size_t)bn_idx * H; };
     auto inv_of = [&](int bn_idx) { return t->bn_invstd + (size_t)bn_idx * H; };
 
-    // ---------------- forward (train mode)
-    auto fwd_apply = [&](float* z, const std::string& bn, int bn_idx, uint32_t site, const float* residual, float* y, bool input_layer) {
-        mlt::FwdApplyParams p;
-        p.z = input_layer ? nullptr : z;
-        p.x_in = input_layer ? x_dev : nullptr;
-        p.w_in = input_layer ? P(t, "w1.weight") : nullptr;
-        p.b_in = input_layer ? P(t, "w1.bias") : nullptr;
-        p.z_out = input_layer ? z : nullptr;
-        p.in_dim = t->in_f;
-        p.m = (long)m; p.H = H;
-        p.gamma = P(t, bn + ".weight"); p.beta = P(t, bn + ".bias");
-        p.run_mean = ST(t, bn + ".running_mean"); p.run_var = ST(t, bn + ".running_var");
-        p.mean_out = mean_of(bn_idx); p.invstd_out = inv_of(bn_idx);
-        p.p_drop = t->p_drop; p.seed = seed; p.site = site;
-        p.residual = residual; p.y = y;
-        launch_fwd_apply(t, st, p);
-    };
-    // z (m x H) = x . W^T + b: both operands k-contiguous
-    auto lin_fwd = [&](const float* x, const std::string& lin, float* z) {
-        return launch_xgemm(st, x, H, 0, P(t, lin + ".weight"), H, 0, z, H, (int)m, H, H, P(t, lin + ".bias"), nullptr, nullptr);
-    };
-    fwd_apply(z0, "batch_norm1", 0, 0, nullptr, a[0], true);
-    for (int s = 0; s < S; ++s) {
-        const std::string p = "linear_stages." + std::to_string(s) + ".";
-        if ((rc = lin_fwd(a[s], p + "w1", za[s]))) return rc;
-        fwd_apply(za[s], p + "batch_norm1", 1 + 2 * s, 1 + 2 * s, nullptr, tt[s], false);
-        if ((rc = lin_fwd(tt[s], p + "w2", zb[s]))) return rc;
-        fwd_apply(zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, a[s], a[s + 1], false);   // a_{s+1} = a_s + block(t_s)
-    }
-    if ((rc = lin_fwd(a[S], "w2", y2))) return rc;
-    if ((rc = lin_fwd(y2, "w3", z3))) return rc;
-    fwd_apply(z3, "batch_norm3", 2 * S + 1, 2 * S + 1, nullptr, y3, false);
-    // ---------------- both heads, the loss and its gradient: one launch, per-workgroup partial sums the host adds
+    // ---------------- forward (train mode), both heads, the loss and its gradient
     const bool task_weights = t->auto_tune || t->weighted;
     if ((rc = upload_task_weights(t, st, task_weights))) return rc;
-    int hl_grid = (int)((m + 3) / 4);
-    if (hl_grid > HL_GRID) hl_grid = HL_GRID;
-    {
-        mlt::HeadsLossParams p;
-        p.y3 = y3; p.y2 = y2;
-        p.w_fin = P(t, "w_fin.weight"); p.b_fin = P(t, "w_fin.bias");
-        p.w_aux = P(t, "w_aux.weight"); p.b_aux = P(t, "w_aux.bias");
-        p.lab = labels_dev; p.L = label_cols; p.m = (long)m; p.H = H;
-        p.out = t->d_out; p.dout = t->d_dout;
-        p.tw = task_weights ? t->d_tw : nullptr;
-        p.part = t->d_lpart;
-        if (C == 10) hipLaunchKernelGGL(mlt::heads_loss_kernel<10>, dim3(hl_grid), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(mlt::heads_loss_kernel<9>, dim3(hl_grid), dim3(256), 0, st, p);
-    }
+    int hl_grid = 0;
+    if ((rc = mid_forward(t, st, x_dev, labels_dev, label_cols, m, seed, false, task_weights, &hl_grid))) return rc;
     if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
     T_TRY(hipMemcpyAsync(t->h_loss, t->d_lpart, (size_t)hl_grid * mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));   // pinned
     // ---------------- backward (every gradient tensor is written in full: no memset of g).  The narrow gradients (head weights
@@ -781,11 +816,7 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     }
     T_TRY(hipStreamSynchronize(st));
     double lv[mlt::LOSS_NV];
-    for (int q = 0; q < mlt::LOSS_NV; ++q) {
-        double a = 0.0;
-        for (int b = 0; b < hl_grid; ++b) a += t->h_loss[b * mlt::LOSS_NV + q];
-        lv[q] = a;
-    }
+    sum_loss_parts(t, hl_grid, lv);
     finish_step_host(t, lv, task_weights, update, lr, bc1, bc2, losses_host);
     return ML_OK;
 }
@@ -897,7 +928,7 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (hipEvent_t e : t->ev_dz) (void)hipEventDestroy(e);
     for (hipEvent_t e : t->ev_w) (void)hipEventDestroy(e);
     if (t->st2) (void)hipStreamDestroy(t->st2);
-    void* ptrs[] = {t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    void* ptrs[] = {t->w_snap, t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -969,10 +1000,42 @@ int ml_trainer_set_route(ml_trainer* t, int route, int64_t fast_rows) {
 
 int ml_trainer_last_route(const ml_trainer* t) { return t ? t->last_route : -1; }
 
-int ml_trainer_last_val_values(const ml_trainer* t, double* host2) {
-    if (!t || !host2) return tfail(ML_ERR_ARG, "null argument");
-    host2[0] = t->last_vals[0];
-    host2[1] = t->last_vals[1];
+int ml_trainer_eval(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m, double* vals_host,
+                    float* raw_out_dev, void* stream) {
+    if (!t || !x_dev || !labels_dev || m < 1 || label_cols < 10 || !vals_host) return tfail(ML_ERR_ARG, "bad argument");
+    if (t->C == 10 && label_cols < 11) return tfail(ML_ERR_ARG, "stereo labels need 11 columns");
+    if (!mid_possible(t)) return tfail(ML_ERR_SHAPE, "ml_trainer_eval needs hidden % 64 == 0 (and out_features * hidden <= 15360)");
+    int rc = ensure_cap(t, m);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    int parts = 0;
+    if ((rc = mid_forward(t, st, x_dev, labels_dev, label_cols, m, 0u, true, false, &parts))) return rc;
+    if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * t->C * 4, hipMemcpyDeviceToDevice, st));
+    T_TRY(hipMemcpyAsync(t->h_loss, t->d_lpart, (size_t)parts * mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));
+    T_TRY(hipStreamSynchronize(st));
+    sum_loss_parts(t, parts, vals_host);
+    return ML_OK;
+}
+
+int ml_trainer_snapshot(ml_trainer* t, void* stream) {
+    if (!t) return tfail(ML_ERR_ARG, "null trainer");
+    if (!t->w_snap) T_TRY(hipMalloc((void**)&t->w_snap, (size_t)(t->n_param + t->n_stat) * 4));
+    T_TRY(hipMemcpyAsync(t->w_snap, t->w, (size_t)t->n_param * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    T_TRY(hipMemcpyAsync(t->w_snap + t->n_param, t->stat, (size_t)t->n_stat * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ML_OK;
+}
+
+int ml_trainer_restore(ml_trainer* t, void* stream) {
+    if (!t || !t->w_snap) return tfail(ML_ERR_ARG, "no snapshot");
+    T_TRY(hipMemcpyAsync(t->w, t->w_snap, (size_t)t->n_param * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    T_TRY(hipMemcpyAsync(t->stat, t->w_snap + t->n_param, (size_t)t->n_stat * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    T_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return ML_OK;
+}
+
+int ml_trainer_last_val_values(const ml_trainer* t, double* host10) {
+    if (!t || !host10) return tfail(ML_ERR_ARG, "null argument");
+    for (int i = 0; i < mlt::LOSS_NV; ++i) host10[i] = t->last_vals[i];
     return ML_OK;
 }
 

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restr
     dst[transpose ? (int64_t)j * nc + c : id] = a;
 }
 
-// out[i][c] = x[i] . w[c] + b[c] for c < NC (the output heads, x: m x n, n % 256 == 0, out row stride ldo): a wave per
+// out[i][c] = x[i] . w[c] + b[c] for c < NC (the output heads, x: m x n, n % 4 == 0, NC * n <= 15360, out row stride ldo): a wave per
 // row, the head weights in LDS (NC * n <= 15360 floats), butterfly reduction.
 template <int NC>
 __global__ __launch_bounds__(256) void skinny_heads_kernel(const float* __restrict__ x, int64_t m, int n, const float* __restrict__ w,

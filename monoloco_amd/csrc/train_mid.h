@@ -278,6 +278,7 @@ struct FwdApplyParams {
     uint32_t seed, site;
     const float* residual;
     float* y;
+    int eval;            // 1: evaluation mode -- the running statistics instead of the batch's (nothing is updated), no dropout
 };
 
 // rows a workgroup of the column-owner kernels holds in registers at once (512: the reference's default batch); per thread
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void fwd_apply_kernel(FwdApplyParams p) {
     }
     f32x4 zr[AP_PMAX];
     double s[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    for (long base = 0; base < p.m; base += chunk) {
+    for (long base = 0; base < p.m && !(p.eval && !inl && !single); base += chunk) {   // (evaluation of a large batch: pass 2 reads z)
 #pragma unroll
         for (int q = 0; q < AP_PMAX; ++q) {
             const long i = base + q * RPP + r;
@@ -373,9 +374,14 @@ __global__ __launch_bounds__(256) void fwd_apply_kernel(FwdApplyParams p) {
             }
         }
     }
-    column_reduce<NC, 2>(s, red, tid);
+    if (!p.eval) column_reduce<NC, 2>(s, red, tid);
     __syncthreads();
-    if (tid < NC) {
+    if (p.eval) {   // (uniform) nn.BatchNorm1d in eval mode: (z - running_mean) / sqrt(running_var + eps), fp32
+        if (tid < NC) {
+            stat[0][tid] = rmean;
+            stat[1][tid] = 1.0f / sqrtf(rvar + 1e-5f);
+        }
+    } else if (tid < NC) {
         const double sa = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);
         const double sb = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);
         // bn_finalize_kernel's arithmetic (train_kernels.h)
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(256) void fwd_apply_kernel(FwdApplyParams p) {
                 for (int e = 0; e < 4; ++e) {   // bn_relu_drop_kernel's arithmetic
                     float t = ga[e] * ((v[e] - mu[e]) * is[e]) + be[e];
                     t = t > 0.f ? t : 0.f;
-                    if (p.p_drop > 0.f)
+                    if (p.p_drop > 0.f && !p.eval)
                         t = (mlk::u01(p.seed, (uint32_t)i * 4099u + p.site, (uint32_t)(j + e)) >= p.p_drop) ? t / (1.f - p.p_drop) : 0.f;
                     v[e] = t;
                 }

@@ -183,20 +183,9 @@ def laplace_sampling_device(mu_b, n_samples, seed=1):
     return out
 
 
-def set_tuning(small_rows=-1, small32_rows=-1, chunk_rows=-1):
-    """Path-selection thresholds of the library (test hook, process-global; negative = unchanged)."""
-    check(_lib.load().ml_debug_set_tuning(int(small_rows), int(small32_rows), int(chunk_rows)))
-
-
-def set_tile_kernel(which, everywhere=False):
-    """Which kernel runs the tile path (test hook, process-global): 4 = dense_kernel_w4 for the long-K layers and
-    dense_kernel_pp for the input / fused-head layers (default); 2 = dense_kernel_pp everywhere; everywhere=True with 4 =
-    dense_kernel_w4 for every layer it supports."""
-    check(_lib.load().ml_debug_set_tile_kernel(int(which) | (256 if everywhere else 0)))
-
-
-def debug_linear(x, w, b, relu=False, res=None, precision='f16x2', small_path=False):
-    """Single dense layer through the MFMA kernel (test hook): the tile kernel, or the small-row kernels."""
+def debug_linear(x, w, b, relu=False, res=None, precision='f16x2', small_path=False, tile_kernel=None):
+    """Single dense layer through the MFMA kernel (test hook): the tile kernel (tile_kernel: None = the default choice, 'pp' =
+    dense_kernel_pp, 'w4' = dense_kernel_w4 wherever it runs), or the small-row kernels."""
     lib = _lib.load()
     dev = _require_cuda(x.device)
     x = _dev_f32(x, dev)
@@ -207,7 +196,8 @@ def debug_linear(x, w, b, relu=False, res=None, precision='f16x2', small_path=Fa
     res = _dev_f32(res, dev) if res is not None else None
     with torch.cuda.device(dev):
         check(lib.ml_debug_linear(_ptr(x), x.shape[0], k, fptr(w), fptr(b), n, int(bool(relu)), _ptr(res), _ptr(y),
-                                  PRECISIONS[precision] | (_lib.ML_DEBUG_SMALL_PATH if small_path else 0), _stream(dev)))
+                                  PRECISIONS[precision] | (_lib.ML_DEBUG_SMALL_PATH if small_path else 0)
+                                  | {None: 0, 'pp': _lib.ML_DEBUG_TILE_PP, 'w4': _lib.ML_DEBUG_TILE_W4}[tile_kernel], _stream(dev)))
     return y
 
 
@@ -263,6 +253,14 @@ class LocoEngine:
             self.close()
         except Exception:  # interpreter shutdown
             pass
+
+    def set_tuning(self, small_rows=-1, small32_rows=-1, chunk_rows=-1, tile_kernel=-1, everywhere=False):
+        """Path selection of THIS engine (ml_loco_set_tuning; negative = unchanged): rows <= small_rows run the small-row dense
+        kernels, above small32_rows with 32x32 tiles; chunk_rows > 0 walks the batch in row chunks; tile_kernel 4 (default) =
+        dense_kernel_w4 for the long-K layers + dense_kernel_pp for the input / fused-head layers, 2 = dense_kernel_pp
+        everywhere; everywhere=True with 4 = dense_kernel_w4 for every layer it supports."""
+        tk = int(tile_kernel) | (256 if everywhere else 0) if tile_kernel >= 0 else -1
+        check(_lib.load().ml_loco_set_tuning(self._h, int(small_rows), int(small32_rows), int(chunk_rows), tk))
 
     def reserve(self, rows):
         with torch.cuda.device(self.device):

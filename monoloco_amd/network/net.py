@@ -69,6 +69,7 @@ class Loco:
         self.engine = engine.LocoEngine(sd, device=self.device,
                                         precision=getattr(self.model, 'precision', 'f16x2'),
                                         merge_w2w3=getattr(self.model, 'merge_w2w3', True))
+        self._stage = {}   # per person count: pinned staging arrays + device buffers of the single-image path
 
     def forward(self, keypoints, kk, keypoints_r=None):
         """Pre-process, network forward and output extraction for one image (reference net.py:83-133).
@@ -76,7 +77,11 @@ class Loco:
         if keypoints is None or len(keypoints) == 0:
             return None
         dev = self.device
-        kps = engine._dev_f32(keypoints, dev)
+        if self.net == 'monoloco_pp' and not (isinstance(keypoints, torch.Tensor) and keypoints.is_cuda):
+            # one image from the host (the reference's call, predict.py:231-249): lists -> ONE float32 array, staged below
+            kps = np.asarray(keypoints, dtype=np.float32) if not isinstance(keypoints, torch.Tensor) else keypoints.float().numpy()
+        else:
+            kps = engine._dev_f32(keypoints, dev)
         kk_list = kk.tolist() if hasattr(kk, 'tolist') else kk
         kinv = engine.inverse_intrinsics(kk_list)
         geo_host = None
@@ -93,9 +98,7 @@ class Loco:
             dic_out = extract_outputs_mono(self.engine.forward_raw(x))
             n_out = kps.shape[0]
         elif self.net == 'monoloco_pp':
-            buf, out, geo = self._packed_buffers(kps.shape[0])
-            self.engine.forward_mono(kps, kinv, out=out)
-            dic_out, geo_host = self._fetch_with_geometry(buf, out, geo, kps, kinv, 9)
+            dic_out, geo_host = self._forward_pp_staged(kps, kinv)
             n_out = kps.shape[0]
         else:
             if keypoints_r is not None and len(keypoints_r) > 0:
@@ -123,10 +126,63 @@ class Loco:
             dic_out['epi'] = [0.] * n_out
         if geo_host is not None:
             # the geometry block post_process needs, computed behind the network from the keypoints that were on the device
-            # anyway and fetched in the same copy; post_process uses it when it is handed these very objects again
+            # anyway and fetched in the same copy; post_process uses it when it is handed these very objects again (identity +
+            # length checks only: a caller that edits the keypoints list or dic['d'] IN PLACE between forward and post_process
+            # must drop the cache -- `dic_out._geo = None` -- or pass copies; the reference's call sites do neither)
             dic_out = _LocoOut(dic_out)
             dic_out._geo = (keypoints, kk_list, dic_out['d'], geo_host)
         return dic_out
+
+    def _forward_pp_staged(self, kps, kinv):
+        """MonoLoco++ forward of one image with every buffer cached per person count: the keypoints go through a pinned staging
+        array (one asynchronous H2D), the network result (m,16) + the post-process geometry (m,12) come back in one
+        asynchronous D2H into a pinned array behind the launches; the host only waits once, for that copy.  Returns
+        (dictionary of fresh CPU tensors, fresh (m,12) geometry tensor)."""
+        lib = engine._lib.load()
+        dev = self.device
+        m = int(kps.shape[0])
+        stride = engine._lib.ML_OUT_STRIDE
+        st = self._stage.get(m)
+        if st is None:
+            if len(self._stage) >= 16:
+                self._stage.clear()
+            pin_in = torch.empty((m, 3, 17), dtype=torch.float32).pin_memory()
+            pin_out = torch.empty((m * (stride + 12),), dtype=torch.float32).pin_memory()
+            st = dict(pin_in=pin_in, np_in=pin_in.numpy(), dev_in=torch.empty((m, 3, 17), dtype=torch.float32, device=dev),
+                      buf=torch.empty((m * (stride + 12),), dtype=torch.float32, device=dev),
+                      xyzds=torch.empty((m, engine._lib.ML_XYZDS_STRIDE), dtype=torch.float32, device=dev),
+                      pin_out=pin_out, np_out=pin_out.numpy())
+            st['p_in'] = ctypes.c_void_p(st['dev_in'].data_ptr())
+            st['p_out'] = ctypes.c_void_p(st['buf'].data_ptr())
+            st['p_d'] = ctypes.c_void_p(st['buf'].data_ptr() + 3 * 4)
+            st['p_geo'] = ctypes.c_void_p(st['buf'].data_ptr() + m * stride * 4)
+            st['p_xyzds'] = ctypes.c_void_p(st['xyzds'].data_ptr())
+            self._stage[m] = st
+        if isinstance(kps, torch.Tensor):     # already on the device: no staging
+            assert tuple(kps.shape[1:]) == (3, 17), "keypoints must be (m, 3, 17)"
+            p_in = ctypes.c_void_p(kps.data_ptr())
+        else:
+            assert kps.shape[1:] == (3, 17), "keypoints must be (m, 3, 17)"
+            np.copyto(st['np_in'], kps)
+            st['dev_in'].copy_(st['pin_in'], non_blocking=True)
+            p_in = st['p_in']
+        stream = engine._stream(dev)
+        kinv_p = engine.fptr(kinv)
+        with torch.cuda.device(dev):
+            engine.check(lib.ml_loco_forward_mono(self.engine._h, p_in, m, kinv_p, None, None, st['p_out'], st['p_xyzds'], stream))
+            engine.check(lib.ml_post_geometry_strided(p_in, m, kinv_p, st['p_d'], stride, st['p_geo'], stream))
+            st['pin_out'].copy_(st['buf'], non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+        host = st['np_out']
+        n = m * stride
+        packed = host[:n].reshape(m, stride)
+        # the reference's dictionary (process.py:240-278) from ONE regrouping copy: every output a slice of its own row block
+        t = torch.from_numpy(np.ascontiguousarray(packed[:, [8, 9, 10, 4, 5, 6, 3]].T))   # rows h w l bi yaw yaw_ego d: fresh memory
+        col = lambda a: t[a:a + 1].t()
+        dic = {'h': col(0), 'w': col(1), 'l': col(2), 'ori': torch.from_numpy(np.ascontiguousarray(packed[:, 12:14])),
+               'bi': col(3), 'xyzd': torch.from_numpy(np.ascontiguousarray(packed[:, 0:4])), 'd': col(6), 'yaw': (col(4), col(5))}
+        geo = torch.from_numpy(host[n:].reshape(m, 12).copy())
+        return dic, geo
 
     def _packed_buffers(self, m):
         """One device allocation for the packed (m,16) network result and the (m,12) post-process geometry."""

@@ -35,6 +35,7 @@ class HipTrainer:
             self._h = h
             self.load_state_dict(state_dict)
         self.set_route(route, fast_rows)
+        self.last_plain = None
         self.auto_tune_mtl = bool(auto_tune_mtl)
         if self.auto_tune_mtl:   # AutoTuneMultiTaskLoss (reference train/losses.py:17-43)
             check(lib.ml_trainer_set_auto_tune(self._h, 1), train=True)
@@ -84,6 +85,7 @@ class HipTrainer:
             pass
 
     def load_state_dict(self, state_dict):
+        self.version = getattr(self, 'version', 0) + 1   # weights / statistics changed: whoever caches derived state keys on this
         lib = _lib.load()
         with torch.cuda.device(self.device):
             for key, val in state_dict.items():
@@ -124,6 +126,49 @@ class HipTrainer:
         with torch.cuda.device(dev):
             check(_lib.load().ml_trainer_step(self._h, _ptr(x), _ptr(y), int(y.shape[1]), m, int(bool(update)), losses,
                                               _ptr(raw), _stream(dev)), train=True)
+            self.version += 1   # (a step without update still moves the BatchNorm running statistics)
+            vals = (ctypes.c_double * 10)()
+            check(_lib.load().ml_trainer_last_val_values(self._h, vals), train=True)
         out = {'loss': losses[0]}
         out.update({t: losses[1 + i] for i, t in enumerate(TASKS)})
+        self.last_plain = self._plain(vals)
         return (out, raw) if want_outputs else out
+
+    @staticmethod
+    def _plain(vals):
+        """The unweighted means of one batch: training-type task values d (Laplace), x, y, h, w, l, ori, aux and the two
+        validation-type ones that differ (reference losses.py:85-96): 'd_val' = L1 on d, 'ori_val' = angle error in degrees."""
+        out = {t: vals[i] for i, t in enumerate(TASKS)}
+        out['d_val'] = vals[8]
+        out['ori_val'] = vals[9] * 180 / 3.14
+        return out
+
+    def evaluate_batch(self, inputs, labels, want_outputs=False):
+        """Eval-mode forward (running statistics, no dropout) of the trainer's current weights on one batch, on the device
+        (ml_trainer_eval): dict of the training-type task means d (Laplace), x, y, h, w, l, ori, aux and the validation-type
+        'd_val' (L1), 'ori_val' (degrees) [and the raw outputs].  Needs hidden % 64 == 0 (MonolocoHipError otherwise)."""
+        dev = self.device
+        x = _dev_f32(inputs, dev)
+        y = _dev_f32(labels, dev)
+        m = x.shape[0]
+        vals = (ctypes.c_double * 10)()
+        raw = torch.empty((m, self.out_features), dtype=torch.float32, device=dev) if want_outputs else None
+        with torch.cuda.device(dev):
+            check(_lib.load().ml_trainer_eval(self._h, _ptr(x), _ptr(y), int(y.shape[1]), m, vals, _ptr(raw), _stream(dev)), train=True)
+        out = self._plain(vals)
+        return (out, raw) if want_outputs else out
+
+    @property
+    def can_evaluate(self):
+        """evaluate_batch runs for this shape (the mid route's kernels: hidden % 64 == 0)."""
+        return self.hidden % 64 == 0 and self.out_features * self.hidden <= 15360 and self.in_features <= 68
+
+    def snapshot(self):
+        """Keep the current parameters + running statistics aside on the device (the loop's best-epoch copy)."""
+        with torch.cuda.device(self.device):
+            check(_lib.load().ml_trainer_snapshot(self._h, _stream(self.device)), train=True)
+
+    def restore(self):
+        self.version += 1
+        with torch.cuda.device(self.device):
+            check(_lib.load().ml_trainer_restore(self._h, _stream(self.device)), train=True)

@@ -51,6 +51,21 @@ class KeypointsDataset(Dataset):
         return self.version
 
 
+class _IndexDataset(Dataset):
+    """Row numbers only: a DataLoader over it draws exactly the random numbers the reference's DataLoader over its
+    KeypointsDataset draws (same sampler, same batching), so the batches are the reference's -- while the rows themselves stay
+    on the device and are gathered there."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        return idx
+
+
 class Trainer:
     VAL_BS = 10000
     tasks = ('d', 'x', 'y', 'h', 'w', 'l', 'ori', 'aux')
@@ -77,9 +92,14 @@ class Trainer:
         torch.manual_seed(args.r_seed)
         if self.mode == 'mono':
             self.tasks = self.tasks[:-1]
-        self.dataloaders = {phase: DataLoader(KeypointsDataset(self.joints, phase=phase), batch_size=args.bs, shuffle=True)
+        datasets = {phase: KeypointsDataset(self.joints, phase=phase) for phase in ['train', 'val']}
+        self.dataset_sizes = {phase: len(datasets[phase]) for phase in ['train', 'val']}
+        # the reference's loaders (trainer.py:104-106: batch_size=bs, shuffle=True for BOTH phases) over row numbers; the rows
+        # live on the device for the whole training
+        self.dataloaders = {phase: DataLoader(_IndexDataset(self.dataset_sizes[phase]), batch_size=args.bs, shuffle=True)
                             for phase in ['train', 'val']}
-        self.dataset_sizes = {phase: len(KeypointsDataset(self.joints, phase=phase)) for phase in ['train', 'val']}
+        self._rows = {phase: (datasets[phase].inputs_all.to(self.device, torch.float32).contiguous(),
+                              datasets[phase].outputs_all.to(self.device, torch.float32).contiguous()) for phase in ['train', 'val']}
         # same construction order as the reference (trainer.py:115-123), hence the same default initialisation
         self.model = LocoModel(input_size=self.input_size[self.mode], output_size=self.output_size[self.mode],
                                linear_size=args.hidden_size, p_dropout=args.dropout, num_stage=args.n_stage)
@@ -93,10 +113,11 @@ class Trainer:
 
     # ---- validation: eval-mode forward (running statistics) on the inference engine, built ONCE per weight version
     def _eval_engine(self):
-        """LocoEngine of the trainer's current weights; rebuilt only when a training step changed them.  w2/w3 are
-        kept as two layers (merge_w2w3=False): no host fp64 H x H x H product per rebuild."""
+        """LocoEngine of the trainer's current weights (only for shapes the trainer's own evaluation does not take: hidden % 64
+        != 0); keyed on HipTrainer.version, which every step / load_state_dict / restore bumps.  w2/w3 are kept as two layers
+        (merge_w2w3=False): no host fp64 H x H x H product per rebuild."""
         from ..engine import LocoEngine
-        version = self.hip.num_steps
+        version = self.hip.version
         if self._eval_eng is None or self._eval_version != version:
             self._close_eval_engine()
             self._eval_eng = LocoEngine(self.hip.state_dict(), device=self.device, merge_w2w3=False)
@@ -115,18 +136,30 @@ class Trainer:
         """Validation values of the reference for raw outputs `out` and labels `lab` (CPU tensors): per task the
         `losses_val` entries of CompositeLoss (losses.py:85-96: L1 from Laplace for d, angle error for ori, BCE for
         aux, L1 otherwise) and 'all' = the training-type multi-task loss on these outputs (losses.py:59-73 with unit
-        lambdas; trainer.py:195)."""
-        vals = {'d': (out[:, 2:3] - lab[:, 3:4]).abs().mean().item()}
+        lambdas; trainer.py:195).  Host fallback of `_vals` for shapes the device evaluation does not take."""
+        plain = {'d_val': (out[:, 2:3] - lab[:, 3:4]).abs().mean().item()}
         for t, c in (('x', 0), ('y', 1), ('h', 4), ('w', 5), ('l', 6)):
-            vals[t] = (out[:, c] - lab[:, c]).abs().mean().item()
+            plain[t] = (out[:, c] - lab[:, c]).abs().mean().item()
         ang = torch.atan2(out[:, 7], out[:, 8]) - torch.atan2(lab[:, 7], lab[:, 8])
-        vals['ori'] = ang.abs().mean().item() * 180 / 3.14
+        plain['ori_val'] = ang.abs().mean().item() * 180 / 3.14
         norm = 1 - out[:, 2:3] / lab[:, 3:4]
-        laplace = (norm.abs() * torch.exp(-out[:, 3:4]) + 0.01 + out[:, 3:4] + 2).mean().item()   # losses.py:112-131
-        train_type = [laplace] + [vals[t] for t in ('x', 'y', 'h', 'w', 'l')] + [(out[:, 7:9] - lab[:, 7:9]).abs().mean().item()]
+        plain['d'] = (norm.abs() * torch.exp(-out[:, 3:4]) + 0.01 + out[:, 3:4] + 2).mean().item()   # losses.py:112-131
+        plain['ori'] = (out[:, 7:9] - lab[:, 7:9]).abs().mean().item()
+        plain['aux'] = (torch.nn.functional.binary_cross_entropy_with_logits(out[:, 9:10], lab[:, 10:11]).item()
+                        if 'aux' in self.tasks else 0.0)
+        return self._vals(plain)
+
+    def _vals(self, plain):
+        """The reference's validation-type record of one batch from its unweighted means (HipTrainer.last_plain /
+        evaluate_batch: computed by the loss kernel on the device): per task the validation value, and 'all' = the training-type
+        multi-task loss."""
+        vals = {'d': plain['d_val'], 'ori': plain['ori_val']}
+        for t in ('x', 'y', 'h', 'w', 'l'):
+            vals[t] = plain[t]
+        train_type = [plain[t] for t in ('d', 'x', 'y', 'h', 'w', 'l', 'ori')]
         if 'aux' in self.tasks:
-            vals['aux'] = torch.nn.functional.binary_cross_entropy_with_logits(out[:, 9:10], lab[:, 10:11]).item()
-            train_type.append(vals['aux'])
+            vals['aux'] = plain['aux']
+            train_type.append(plain['aux'])
         lam = self.lambdas[:len(train_type)]
         if self.auto_tune_mtl:   # losses.py:34-39: every task * lambda / (2 sigma^2), plus the log_sigmas
             ls = self.hip.log_sigmas.tolist()
@@ -135,22 +168,45 @@ class Trainer:
             vals['all'] = sum(la * v for la, v in zip(lam, train_type))
         return vals
 
+    def _batch(self, phase, idx):
+        x_all, y_all = self._rows[phase]
+        idx = idx.to(self.device)
+        return x_all.index_select(0, idx), y_all.index_select(0, idx)
+
+    def _eval_batch(self, x, y, want_outputs=False):
+        """Validation values (and raw outputs) of the CURRENT weights on one device batch: on the trainer's own kernels where
+        the shape allows (no engine rebuild, nothing leaves the device but ten numbers), else through the inference engine."""
+        if self.hip.can_evaluate:
+            if want_outputs:
+                plain, raw = self.hip.evaluate_batch(x, y, want_outputs=True)
+                return self._vals(plain), raw.cpu()
+            return self._vals(self.hip.evaluate_batch(x, y)), None
+        out = self._forward_eval(x)
+        return self._val_losses(out, y.cpu()), out
+
     def train(self):
         since = time.time()
-        best_wts = copy.deepcopy(self.hip.state_dict())
+        self.hip.snapshot()
         best_acc, best_epoch = 1e6, 0
+        self.step_seconds = 0.0          # time inside the device calls (each synchronises): bench.py's device-busy fraction
         for epoch in range(self.num_epochs):
             running = defaultdict(lambda: defaultdict(float))
-            for inputs, labels, _, _ in self.dataloaders['train']:
-                # the reference logs, for the training phase as well, the validation-type values of the train-mode outputs
-                # it has just back-propagated (trainer.py:163-165, epoch_logs :193-197); 'loss' (the optimised total of the
-                # step) is kept beside them
-                losses, raw = self.hip.step(inputs, labels, update=True, want_outputs=True)
+            for idx in self.dataloaders['train']:
+                inputs, labels = self._batch('train', idx)
+                # the reference logs, for the training phase as well, the validation-type values of the train-mode outputs it
+                # has just back-propagated (trainer.py:163-165, epoch_logs :193-197): the loss kernel reduces them on the way;
+                # 'loss' (the optimised total of the step) is kept beside them
+                t0 = time.perf_counter()
+                losses = self.hip.step(inputs, labels, update=True)
+                self.step_seconds += time.perf_counter() - t0
                 running['train']['loss'] += losses['loss'] * inputs.size(0)
-                for k, v in self._val_losses(raw.cpu(), labels).items():
+                for k, v in self._vals(self.hip.last_plain).items():
                     running['train'][k] += v * inputs.size(0)
-            for inputs, labels, _, _ in self.dataloaders['val']:
-                vals = self._val_losses(self._forward_eval(inputs), labels)
+            for idx in self.dataloaders['val']:
+                inputs, labels = self._batch('val', idx)
+                t0 = time.perf_counter()
+                vals, _ = self._eval_batch(inputs, labels)
+                self.step_seconds += time.perf_counter() - t0
                 for k, v in vals.items():
                     running['val'][k] += v * inputs.size(0)
             for phase in running:
@@ -159,9 +215,9 @@ class Trainer:
             val_d = self.epoch_losses['val'][self.val_task][-1]   # KeyError-free: every epoch appends every task
             if val_d < best_acc:
                 best_acc, best_epoch = val_d, epoch
-                best_wts = copy.deepcopy(self.hip.state_dict())
+                self.hip.snapshot()       # device-to-device: the weights of the best epoch never travel
         self.training_time = time.time() - since
-        self.hip.load_state_dict(best_wts)
+        self.hip.restore()
         self._close_eval_engine()   # the weights changed without a step: never reuse the engine of the last epoch
         return best_epoch
 
@@ -182,8 +238,9 @@ class Trainer:
         dic_err['val']['sigmas'] = [math.exp(v) for v in self.hip.log_sigmas.tolist()] if self.auto_tune_mtl else [0.] * len(self.tasks)
 
         def stats(inputs, labels, clst):
-            out = self._forward_eval(inputs)
-            vals = self._val_losses(out, labels)
+            vals, out = self._eval_batch(inputs.to(self.device, torch.float32), labels.to(self.device, torch.float32),
+                                         want_outputs=True)
+            labels = labels.float()
             entry = dic_err['val'][clst]
             for t in self.tasks:
                 if t != 'aux':

@@ -201,7 +201,7 @@ def test_empty_and_errors(hip_lib, cuda_device):
 @pytest.mark.parametrize("mode", ["mono", "stereo"])
 @pytest.mark.parametrize("m", [1, 16, 17, 100, 129, 300, 1000, 2048])
 def test_small_row_path_matches_tile_path(hip_lib, cuda_device, monkeypatch, m, mode):
-    """rows <= the small-row threshold (2048, engine.set_tuning) run dense_small_kernel (16x16 tiles up to 128 rows, 32x32 tiles above; K split over 4
+    """rows <= the small-row threshold (2048, LocoEngine.set_tuning) run dense_small_kernel (16x16 tiles up to 128 rows, 32x32 tiles above; K split over 4
     waves), larger batches the 256x256-tile persistent kernel: same operands and epilogue, only the fp32
     accumulation order differs.
     Both must agree with each other far below the parity bar and each must meet the bar against fp64."""
@@ -211,9 +211,9 @@ def test_small_row_path_matches_tile_path(hip_lib, cuda_device, monkeypatch, m, 
     rng = np.random.default_rng(m)
     x = torch.tensor((rng.standard_normal((m, in_f)) * 3).astype(np.float32), device=cuda_device)
     eng = engine.LocoEngine(_sd_t(sd), device=cuda_device)
-    engine.set_tuning(small_rows=0)
+    eng.set_tuning(small_rows=0)
     raw_tile = eng.forward_raw(x).cpu()
-    engine.set_tuning(small_rows=2048)
+    eng.set_tuning(small_rows=2048)
     raw_small = eng.forward_raw(x).cpu()
     ref64 = O.loco_forward(_sd_t(sd), x.cpu(), dtype=torch.float64)
     scale = ref64.abs().max().item()
@@ -224,7 +224,7 @@ def test_small_row_path_matches_tile_path(hip_lib, cuda_device, monkeypatch, m, 
 
 
 def test_row_chunking_is_bit_identical(hip_lib, cuda_device, monkeypatch):
-    """Row chunking (engine.set_tuning(chunk_rows=...)) walks the batch in row chunks through all layers (Infinity-Cache residency experiment): rows
+    """Row chunking (LocoEngine.set_tuning(chunk_rows=...)) walks the batch in row chunks through all layers (Infinity-Cache residency experiment): rows
     are independent, so the result must not change by a bit -- including the fused-head partial sums."""
     from monoloco_amd import engine
     sd = synth.make_state_dict(6)
@@ -233,11 +233,9 @@ def test_row_chunking_is_bit_identical(hip_lib, cuda_device, monkeypatch):
     eng = engine.LocoEngine(_sd_t(sd), device=cuda_device)
     out0, xyzds0, raw0 = eng.forward_mono(kps, kinv, want_raw=True)
     out0, xyzds0, raw0 = out0.clone(), xyzds0.clone(), raw0.clone()
-    engine.set_tuning(chunk_rows=2048)
-    try:
-        out1, xyzds1, raw1 = eng.forward_mono(kps, kinv, want_raw=True)
-    finally:
-        engine.set_tuning(chunk_rows=0)
+    eng.set_tuning(chunk_rows=2048)
+    out1, xyzds1, raw1 = eng.forward_mono(kps, kinv, want_raw=True)
+    eng.set_tuning(chunk_rows=0)
     assert torch.equal(raw0, raw1) and torch.equal(xyzds0, xyzds1)
     assert torch.equal(out0.nan_to_num(), out1.nan_to_num())
     eng.close()
@@ -252,9 +250,9 @@ def test_small_row_path_single_fp16_mode(hip_lib, cuda_device, monkeypatch, m):
     rng = np.random.default_rng(m)
     x = torch.tensor((rng.standard_normal((m, 34)) * 3).astype(np.float32), device=cuda_device)
     eng = engine.LocoEngine(_sd_t(sd), device=cuda_device, precision='f16')
-    engine.set_tuning(small_rows=0)
+    eng.set_tuning(small_rows=0)
     raw_tile = eng.forward_raw(x).cpu()
-    engine.set_tuning(small_rows=2048)
+    eng.set_tuning(small_rows=2048)
     raw_small = eng.forward_raw(x).cpu()
     ref64 = O.loco_forward(_sd_t(sd), x.cpu(), dtype=torch.float64)
     scale = max(1.0, ref64.abs().max().item())

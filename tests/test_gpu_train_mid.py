@@ -225,3 +225,57 @@ def test_headline_width_steps_match_reference(hip_lib, cuda_device, tag, route):
         floor = 8e-4 if k.startswith(('w1.', 'batch_norm1.')) else 3e-4
         assert rel <= max(3.0 * noise, floor), (k, rel, noise)
     tr.close()
+
+
+@pytest.mark.parametrize("mode,hidden", [('stereo', 256), ('mono', 1024)])
+def test_trainer_evaluates_and_snapshots_on_the_device(hip_lib, cuda_device, mode, hidden):
+    """ml_trainer_eval = the validation pass of the reference's loop (model.eval(): running statistics, no dropout) on the
+    trainer's own weights: raw outputs against the inference engine built from the same state_dict, the ten values against
+    their formulas (losses.py:85-131) on those outputs; nothing is modified.  ml_trainer_snapshot / _restore = the loop's
+    best-epoch copy, device to device."""
+    from monoloco_amd.engine import LocoEngine
+    from monoloco_amd.train import HipTrainer
+    in_f, out_f = (34, 9) if mode == 'mono' else (68, 10)
+    x, y = _batch(mode)
+    xv, yv = _batch(mode, val=True)
+    sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(37, in_f, out_f, hidden).items()}
+    tr = HipTrainer(sd0, p_dropout=0.2, lr=0.001, device=cuda_device)
+    for _ in range(3):
+        tr.step(x, y)
+    before = tr.state_dict()
+    plain, raw = tr.evaluate_batch(xv, yv, want_outputs=True)
+    after = tr.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    eng = LocoEngine(before, device=cuda_device, merge_w2w3=False)
+    ref = eng.forward_raw(xv.to(cuda_device)).cpu()
+    eng.close()
+    out = raw.cpu()
+    assert (out - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    o, lab = out.double(), yv.double()
+    norm = 1 - o[:, 2] / lab[:, 3]
+    want = {'d': (norm.abs() * torch.exp(-o[:, 3]) + 0.01 + o[:, 3] + 2).mean().item(),
+            'ori': (o[:, 7:9] - lab[:, 7:9]).abs().mean().item(),
+            'd_val': (o[:, 2] - lab[:, 3]).abs().mean().item(),
+            'ori_val': (torch.atan2(o[:, 7], o[:, 8]) - torch.atan2(lab[:, 7], lab[:, 8])).abs().mean().item() * 180 / 3.14}
+    for t, c in (('x', 0), ('y', 1), ('h', 4), ('w', 5), ('l', 6)):
+        want[t] = (o[:, c] - lab[:, c]).abs().mean().item()
+    if mode == 'stereo':
+        want['aux'] = torch.nn.functional.binary_cross_entropy_with_logits(o[:, 9], lab[:, 10]).item()
+    for k, v in want.items():
+        assert abs(plain[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, plain[k], v)
+    # the training step reports the same unweighted values for its train-mode outputs
+    res, out_t = tr.step(x, y, update=False, want_outputs=True)
+    ot, labt = out_t.cpu().double(), y.double()
+    assert abs(tr.last_plain['d_val'] - (ot[:, 2] - labt[:, 3]).abs().mean().item()) <= 2e-5 * max(1.0, tr.last_plain['d_val'])
+    assert abs(tr.last_plain['d'] - res['d']) <= 1e-12
+    # snapshot / restore
+    tr.snapshot()
+    kept = tr.state_dict()
+    tr.step(x, y)
+    tr.step(x, y)
+    moved = tr.state_dict()
+    assert any(not torch.equal(kept[k], moved[k]) for k in kept)
+    tr.restore()
+    back = tr.state_dict()
+    assert all(torch.equal(kept[k], back[k]) for k in kept)
+    tr.close()

@@ -9,11 +9,7 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _restore_kernel():
-    from monoloco_amd import engine
-    yield
-    engine.set_tile_kernel(4)
+KERNELS = {4: 'w4', 2: 'pp'}   # debug_linear's tile_kernel argument; engines select per handle (LocoEngine.set_tuning)
 
 
 @pytest.mark.parametrize("m,k,n", [(256, 64, 256), (700, 96, 256), (1000, 1024, 1024), (3000, 256, 512), (70000, 128, 1024)])
@@ -36,8 +32,7 @@ def test_w4_single_layer(hip_lib, cuda_device, m, k, n, relu, res):
         ref = ref + r
     out = {}
     for kern in (4, 2):
-        engine.set_tile_kernel(kern, everywhere=True)
-        out[kern] = engine.debug_linear(xd, w, b, relu=relu, res=rd).cpu().numpy()
+        out[kern] = engine.debug_linear(xd, w, b, relu=relu, res=rd, tile_kernel=KERNELS[kern]).cpu().numpy()
         err = np.abs(out[kern] - ref).max()
         assert err <= 4e-6 * max(1.0, np.abs(ref).max()), (kern, err)
     assert np.abs(out[4] - out[2]).max() <= 2e-6 * max(1.0, np.abs(ref).max())
@@ -54,8 +49,7 @@ def test_w4_single_product_modes(hip_lib, cuda_device, precision):
     xd = torch.tensor(x).to(cuda_device)
     out = {}
     for kern in (4, 2):
-        engine.set_tile_kernel(kern, everywhere=True)
-        out[kern] = engine.debug_linear(xd, w, b, relu=True, precision=precision).cpu().numpy()
+        out[kern] = engine.debug_linear(xd, w, b, relu=True, precision=precision, tile_kernel=KERNELS[kern]).cpu().numpy()
     ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + b, 0)
     tol = 2e-2 if precision == 'f16' else 1.5e-1
     assert np.abs(out[4] - ref).max() <= tol
@@ -76,9 +70,9 @@ def test_w4_whole_model_vs_pp_and_oracle(hip_lib, cuda_device, mode):
     for merge in (True, False):
         eng = engine.LocoEngine(sd, device=cuda_device, merge_w2w3=merge)
         for kern in (4, 2):
-            engine.set_tile_kernel(kern, everywhere=True)   # incl. the input layer and the fused-head layer
+            eng.set_tuning(tile_kernel=kern, everywhere=True)   # incl. the input layer and the fused-head layer
             raw[(merge, kern)] = eng.forward_raw(x).cpu()
-        engine.set_tile_kernel(4)                           # the default mix of the two kernels
+        eng.set_tuning(tile_kernel=4)                           # the default mix of the two kernels
         raw[(merge, 'mix')] = eng.forward_raw(x).cpu()
         eng.close()
     idx = torch.arange(0, m, 41)
@@ -94,8 +88,8 @@ def test_w4_is_deterministic_and_row_independent(hip_lib, cuda_device):
     """Same bits run after run and under a row permutation (rows are independent; a race between the DMA ring and the
     fragment reads would show up as run-to-run differences in some tile)."""
     from monoloco_amd import engine
-    engine.set_tile_kernel(4, everywhere=True)
     eng = engine.LocoEngine({k: torch.tensor(v) for k, v in synth.make_state_dict(1).items()}, device=cuda_device)
+    eng.set_tuning(tile_kernel=4, everywhere=True)
     kinv = engine.inverse_intrinsics(synth.KITTI_K)
     m = 65536
     kps = torch.tensor(synth.make_keypoints(m, seed=21)).to(cuda_device)

@@ -17,7 +17,7 @@ variants = {'pp': (2, False), 'mix': (4, False), 'w4': (4, True)}
 res = {k: [] for k in variants}
 for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     for name, (k, allw) in variants.items():
-        engine.set_tile_kernel(k, everywhere=allw)
+        eng.set_tuning(tile_kernel=k, everywhere=allw)
         for _ in range(3):
             eng.forward_mono(kps, kinv, box_conf=conf, out=out, xyzds=xyzds)
         torch.cuda.synchronize()

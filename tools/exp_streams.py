@@ -10,11 +10,12 @@ sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(1).items()}
 kinv = engine.inverse_intrinsics(synth.KITTI_K)
 M = 65536
 kps = torch.tensor(synth.make_keypoints(M, seed=1)).to(dev)
-if len(sys.argv) > 1:
-    engine.set_tile_kernel(int(sys.argv[1]))
+TILE_KERNEL = int(sys.argv[1]) if len(sys.argv) > 1 else -1
 for n in (1, 2, 4):
     m = M // n
     engs = [engine.LocoEngine(sd, device=dev, reserve_rows=m) for _ in range(n)]
+    for e in engs:
+        e.set_tuning(tile_kernel=TILE_KERNEL)
     streams = [torch.cuda.Stream(dev) for _ in range(n)]
     outs = [(torch.empty((m, 16), device=dev), torch.empty((m, 5), device=dev)) for _ in range(n)]
     chunks = [kps[i * m:(i + 1) * m].contiguous() for i in range(n)]
