@@ -46,6 +46,7 @@ def _dev_f32(x, dev, shape=None):
 
 
 _KINV_CACHE = {}
+_KINV_PTR = {}   # id(cached inverse) -> its ctypes float pointer (numpy's ctypes.data_as costs ~10 us per call)
 
 
 def inverse_intrinsics(kk):
@@ -58,11 +59,19 @@ def inverse_intrinsics(kk):
     if hit is None:
         if len(_KINV_CACHE) >= 64:
             _KINV_CACHE.clear()
+            _KINV_PTR.clear()
         k = torch.as_tensor(k32.copy()).reshape(3, 3)
         hit = np.ascontiguousarray(torch.inverse(k).numpy().reshape(9).astype(np.float32))
         hit.setflags(write=False)
         _KINV_CACHE[key] = hit
+        _KINV_PTR[id(hit)] = fptr(hit)
     return hit
+
+
+def kinv_ptr(kinv):
+    """ctypes pointer to the 9 floats of an inverse_intrinsics() result (cached with the array), or of any fp32 array."""
+    p = _KINV_PTR.get(id(kinv))
+    return p if p is not None else fptr(kinv)
 
 
 # ------------------------------------------------------------------ stand-alone kernels

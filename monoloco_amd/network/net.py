@@ -167,7 +167,7 @@ class Loco:
             st['dev_in'].copy_(st['pin_in'], non_blocking=True)
             p_in = st['p_in']
         stream = engine._stream(dev)
-        kinv_p = engine.fptr(kinv)
+        kinv_p = engine.kinv_ptr(kinv)
         with torch.cuda.device(dev):
             engine.check(lib.ml_loco_forward_mono(self.engine._h, p_in, m, kinv_p, None, None, st['p_out'], st['p_xyzds'], stream))
             engine.check(lib.ml_post_geometry_strided(p_in, m, kinv_p, st['p_d'], stride, st['p_geo'], stream))
@@ -176,13 +176,18 @@ class Loco:
         host = st['np_out']
         n = m * stride
         packed = host[:n].reshape(m, stride)
-        # the reference's dictionary (process.py:240-278) from ONE regrouping copy: every output a slice of its own row block
-        t = torch.from_numpy(np.ascontiguousarray(packed[:, [8, 9, 10, 4, 5, 6, 3]].T))   # rows h w l bi yaw yaw_ego d: fresh memory
-        col = lambda a: t[a:a + 1].t()
-        dic = {'h': col(0), 'w': col(1), 'l': col(2), 'ori': torch.from_numpy(np.ascontiguousarray(packed[:, 12:14])),
-               'bi': col(3), 'xyzd': torch.from_numpy(np.ascontiguousarray(packed[:, 0:4])), 'd': col(6), 'yaw': (col(4), col(5))}
-        geo = torch.from_numpy(host[n:].reshape(m, 12).copy())
-        return dic, geo
+        # the reference's dictionary (process.py:240-278) out of ONE fresh buffer: 7 single columns (h w l bi yaw yaw_ego d), then
+        # ori (m,2), xyzd (m,4) and the (m,12) geometry block; one torch.from_numpy, every output a view of its own range
+        fresh = np.empty((25 * m,), dtype=np.float32)
+        fresh[:7 * m].reshape(7, m)[...] = packed[:, [8, 9, 10, 4, 5, 6, 3]].T
+        fresh[7 * m:9 * m].reshape(m, 2)[...] = packed[:, 12:14]
+        fresh[9 * m:13 * m].reshape(m, 4)[...] = packed[:, 0:4]
+        fresh[13 * m:] = host[n:]
+        t = torch.from_numpy(fresh)
+        h_, w_, l_, bi_, yaw_, yawe_, d_ = t[:7 * m].view(7, m, 1).unbind(0)
+        dic = {'h': h_, 'w': w_, 'l': l_, 'ori': t[7 * m:9 * m].view(m, 2), 'bi': bi_, 'xyzd': t[9 * m:13 * m].view(m, 4), 'd': d_,
+               'yaw': (yaw_, yawe_)}
+        return dic, t[13 * m:].view(m, 12)
 
     def _packed_buffers(self, m):
         """One device allocation for the packed (m,16) network result and the (m,12) post-process geometry."""
