@@ -312,6 +312,8 @@ int ml_loco_profile_end(ml_loco* h, int64_t* launches, double* total_ms, double*
 #define ML_DEBUG_SMALL_PATH 256
 #define ML_DEBUG_TILE_PP 512    /* ... the tile path on dense_kernel_pp */
 #define ML_DEBUG_TILE_W4 1024   /* ... the tile path on dense_kernel_w4 wherever it runs (default: w4 for K > 128) */
+#define ML_DEBUG_MID_64 2048    /* ... dense_mid_kernel with 128 x 64 tiles */
+#define ML_DEBUG_MID_128 4096   /* ... dense_mid_kernel with 128 x 128 tiles */
 int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, const float* b_host,
                     int n, int relu, const float* res_dev, float* y_dev, int precision, void* stream);
 /* Host fp32 -> fp16 hi/lo split used by the packer (round-to-nearest-even), for unit tests. */
@@ -325,8 +327,11 @@ int ml_debug_num_layers(const ml_loco* h);
  * 0 / 4): rows <= small_rows take the small-row dense kernels, above small32_rows those use 32x32 tiles; chunk_rows > 0 walks
  * the batch in row chunks of that size through all layers; tile_kernel: 4 = dense_kernel_w4 for the long-K layers,
  * dense_kernel_pp for the short input layer and the fused-head layer (default), 2 = dense_kernel_pp everywhere, 4 | 256 =
- * dense_kernel_w4 wherever it can run.  Nothing here is process-global: handles stay thread-compatible. */
-int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel);
+ * dense_kernel_w4 wherever it can run; small_rows < rows <= mid_rows (default 12288) take dense_mid_kernel, whose tile
+ * height mid_tile is 0 (chosen from the row count, default), 64 or 128.  Nothing here is process-global: handles stay
+ * thread-compatible. */
+int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel, int mid_rows,
+                       int mid_tile);
 /* Training, bring-up: copy an internal fp32 buffer of the trainer to the host (after a device sync).  which: 0 .. 4S+7 the
  * (rows x hidden) activation / gradient buffers in allocation order (a_0..a_S, t_0.., z0, (za, zb)_s, z3, y2, y3, scratch,
  * gA, gB), 200 / 201 the raw outputs / their gradient. */

@@ -24,6 +24,8 @@ ML_PREC_BF16 = 2
 ML_DEBUG_SMALL_PATH = 256
 ML_DEBUG_TILE_PP = 512
 ML_DEBUG_TILE_W4 = 1024
+ML_DEBUG_MID_64 = 2048
+ML_DEBUG_MID_128 = 4096
 ML_FLAG_MERGE_W2W3 = 1
 ML_FLAG_HOST_ONLY = 256
 ML_OUT_STRIDE = 16
@@ -100,7 +102,7 @@ SIGNATURES = {
     'ml_debug_get_layer': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
                                    POINTER(c_int)]),
     'ml_debug_num_layers': (c_int, [_P]),
-    'ml_loco_set_tuning': (c_int, [_P, c_int, c_int, c_int, c_int]),
+    'ml_loco_set_tuning': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int]),
     'ml_debug_get_packed': (c_int, [_P, c_int, POINTER(c_uint16), c_int64]),
     'ml_debug_get_head': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_int), POINTER(c_int)]),

@@ -1,0 +1,219 @@
+// dense_mid.h -- the dense layer for MID-SIZE batches (a few thousand to ~16k rows: a video batch, a handful of
+// camera streams; reference use: Loco.forward over the persons of several frames, monoloco/network/net.py:83-133).
+//
+// The 256x256-tile persistent kernels (dense_kernel_pp / _w4) have (rows/256) * (N/256) tiles: 64 at 4096 rows, 128 at
+// 8192 -- a quarter / half of the 256 CUs, whatever the kernel does inside a tile.  The small-row kernels
+// (dense_small.h) have tiles enough but re-read their operands from L2 once per 32x32 tile (1 GB per layer at 4096
+// rows).  This kernel sits between the two: workgroup tile 128 (n) x TM (m), TM = 64 or 128, 4 waves as 2 (n) x 2 (m),
+// wave tile 64 x TM/2 = 2 x NB MFMA 32x32x16 tiles, same arithmetic as the other dense kernels (k32 hi|lo lines,
+// hi*lo + lo*hi + hi*hi in fp32, A operand = weights so that a lane ends up with 4 consecutive n of one person).
+//
+//   grid    (N/128) * (M_pad/TM) workgroups, numbered so that the 8 column tiles of a row panel land on ONE XCD (its L2
+//           then serves the activation panel 8 times); >= 2 workgroups per CU from 4096 rows (TM = 64) / 8192 rows (128)
+//   stage   one k32 line per row: 128 W rows + TM X rows = 24 / 32 KiB; 2 stages in LDS, chunk ^= (row>>1)&7 as in
+//           dense_kernel.h (conflict-free ds_read_b128 fragment reads)
+//   loader  register-staged: every thread moves 4 (W) + TM/32 (X) 16-byte chunks per step, global -> VGPR two steps
+//           ahead (two register sets), VGPR -> LDS one step ahead; one workgroup barrier per step.  (LDS-DMA costs its
+//           wave ~100 cycles of issue per instruction -- dense_kernel_pp.h -- and the two or three resident workgroups
+//           per CU hide the latency a single wave per SIMD cannot.)
+//   LDS     reads per step: 4 waves * 2 half-steps * (2 + NB) blocks * 2 KiB; writes 16 + TM/8 KiB: 768 cycles at
+//           128 B/clk for TM = 128 (= the 768 MFMA cycles per SIMD), 576 vs 384 for TM = 64 -- the small tile is
+//           LDS-bound at 2/3 of the MFMA rate, the price of the tile count
+//   epilogue per 32x32 MFMA tile as in dense_kernel_pp: bias rides in the accumulators, * 2^-e, ReLU, + residual, split
+//           to fp16 hi|lo, transposed through a private 4 KiB LDS scratch, four 16-byte stores per lane (whole 128-byte
+//           lines); the residual comes straight from global memory in the accumulator layout (8-byte loads).
+// The heads run as their own launches behind the last layer (launch_heads), as on the small-row path.
+#pragma once
+#include "dense_kernel_pp.h"
+
+namespace mlk {
+
+constexpr int MID_TN = 128;
+constexpr int MID_THREADS = 256;
+
+template <int TM>
+struct MidCfg {
+    static constexpr int NB = TM / 64;                   // MFMA column (person) blocks per wave
+    static constexpr int XL = TM / 32;                   // 16-byte X chunks a thread moves per step
+    static constexpr int W_BYTES = MID_TN * LINE;        // 16 KiB
+    static constexpr int STAGE = W_BYTES + TM * LINE;    // W rows then X rows
+    static constexpr int LDS = 2 * STAGE;
+};
+
+template <int NSPLIT, bool RELU, bool RES, int TM>
+__global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p) {
+    typedef MidCfg<TM> C;
+    constexpr int NB = C::NB, XL = C::XL;
+    __shared__ __attribute__((aligned(16))) char smem[C::LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w & 1, wm = w >> 1;
+
+    // workgroup -> tile: blockIdx round-robins over the 8 XCDs; XCD x takes the tiles [x * per, (x+1) * per), walked
+    // column tile fastest, so that the workgroups resident on an XCD share a few row panels of X
+    const int tiles_n = p.N / MID_TN;
+    const int tiles = tiles_n * (p.M_pad / TM);
+    const int per = (tiles + 7) >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (tile >= tiles) return;
+    const int n0 = (tile % tiles_n) * MID_TN;
+    const int m0 = (tile / tiles_n) * TM;
+
+    const size_t rowb = (size_t)p.K * 4;
+    const int nk = p.K / 32;
+    const float descale = p.descale_ptr ? *p.descale_ptr : p.descale;
+
+    // loader: thread -> (row lrow + 32 j, chunk lch) of both operands
+    const int lrow = tid >> 3, lch = tid & 7;
+    const char* gw = p.w + (size_t)(n0 + lrow) * rowb + lch * 16;
+    const char* gx = p.x + (size_t)(m0 + lrow) * rowb + lch * 16;
+    const int lst = lrow * LINE + ((lch ^ ((lrow >> 1) & 7)) * 16);   // + 32 j rows (the swizzle term repeats every 16 rows)
+
+    struct Raw {
+        f32x4 w[4];
+        f32x4 x[XL];
+    };
+    auto gload = [&](Raw& r, int k) {
+        const int kk = k < nk ? k : nk - 1;   // past the end: a harmless repeat (unconditional loads keep vmcnt countable)
+        const size_t o = (size_t)kk * LINE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.w[j] = *(const f32x4*)(gw + (size_t)(32 * j) * rowb + o);
+#pragma unroll
+        for (int j = 0; j < XL; ++j) r.x[j] = *(const f32x4*)(gx + (size_t)(32 * j) * rowb + o);
+    };
+    auto lstore = [&](const Raw& r, int s) {
+        char* b = smem + s * C::STAGE + lst;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4*)(b + j * 32 * LINE) = r.w[j];
+#pragma unroll
+        for (int j = 0; j < XL; ++j) *(f32x4*)(b + C::W_BYTES + j * 32 * LINE) = r.x[j];
+    };
+
+    // fragments: lane (r, q) reads row r of a 32-row block, chunk 2s+q (hi) / 4+2s+q (lo) of the line
+    const int r = lane & 31, q = lane >> 5;
+    const int sw = (r >> 1) & 7;
+    const int fa_row = (wn * 64 + r) * LINE;                       // + a * 32 rows
+    const int fb_row = C::W_BYTES + (wm * (TM / 2) + r) * LINE;    // + b * 32 rows
+    struct Frag {
+        half8 whi[2], wlo[2], xhi[NB], xlo[NB];
+    };
+    auto fread = [&](Frag& f, int s, int hs) {
+        const char* b = smem + s * C::STAGE;
+        const int chi = ((2 * hs + q) ^ sw) * 16, clo = ((4 + 2 * hs + q) ^ sw) * 16;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f.whi[a] = *(const half8*)(b + fa_row + a * 32 * LINE + chi);
+            if (NSPLIT == 3) f.wlo[a] = *(const half8*)(b + fa_row + a * 32 * LINE + clo);
+        }
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            f.xhi[c] = *(const half8*)(b + fb_row + c * 32 * LINE + chi);
+            if (NSPLIT == 3) f.xlo[c] = *(const half8*)(b + fb_row + c * 32 * LINE + clo);
+        }
+    };
+
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *(const f32x4*)(p.bias_scaled + n0 + wn * 64 + a * 32 + 8 * g + 4 * q);
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[a][c][g * 4 + e] = b4[e];
+        }
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (NSPLIT == 3) {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.whi[a], f.xlo[c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wlo[a], f.xhi[c], acc[a][c], 0, 0, 0);
+                }
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.whi[a], f.xhi[c], acc[a][c], 0, 0, 0);
+            }
+    };
+
+    Raw R0, R1;
+    gload(R0, 0);
+    gload(R1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XL) : "memory");
+    lstore(R0, 0);
+    gload(R0, 2);
+    __syncthreads();
+
+    // step i: LDS stage i&1 holds k-step i; the set named `nxt` holds step i+1 (requested two steps ago), the other set
+    // step i+2 (requested one step ago, stays in flight across the wait)
+    auto step = [&](Raw& nxt, int i) {
+        const int s = i & 1;
+        Frag f0, f1;
+        fread(f0, s, 0);
+        fread(f1, s, 1);
+        mma(f0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XL) : "memory");
+        if (i + 1 < nk) lstore(nxt, s ^ 1);
+        gload(nxt, i + 3);
+        mma(f1);
+        __syncthreads();
+    };
+    for (int i = 0; i < nk; i += 2) {
+        step(R1, i);
+        if (i + 1 < nk) step(R0, i + 1);
+    }
+
+    // ---- epilogue: the stage buffers are free behind the last barrier; wave w takes 4 KiB of them as its scratch
+    char* scr = smem + w * 4096;
+    const size_t yrowb = (size_t)p.N * 4;
+    const float lim = 65504.0f / descale;
+    const int eml = r, eh = q;
+    const int scr_row = eml * LINE + eh * 8;
+    const int rd_off = (lane >> 3) * LINE + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);
+    const size_t st_off = (size_t)(lane >> 3) * yrowb + (size_t)((lane & 7) * 16);
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const size_t line0 = (size_t)(m0 + wm * (TM / 2) + c * 32) * yrowb + (size_t)(n0 + wn * 64 + a * 32) * 4;
+            u32x2 rh[4], rl[4];
+            if (RES) {
+                const char* rb = p.res + line0 + (size_t)eml * yrowb + eh * 8;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    rh[g] = *(const u32x2*)(rb + g * 16);
+                    rl[g] = *(const u32x2*)(rb + g * 16 + 64);
+                }
+            }
+            u32x2 oh[4], ol[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const float a0 = acc[a][c][g * 4 + 2 * e2], a1 = acc[a][c][g * 4 + 2 * e2 + 1];
+                    unsigned hh, ll;
+                    if (RES) split2_res<RELU>(a0, a1, descale, rh[g][e2], rl[g][e2], hh, ll);
+                    else split2_scaled<RELU>(a0, a1, descale, lim, hh, ll);
+                    if (NSPLIT != 3) ll = 0u;
+                    oh[g][e2] = hh;
+                    ol[g][e2] = ll;
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *(u32x2*)(scr + scr_row + ((g ^ (eml & 7)) * 16)) = oh[g];
+                *(u32x2*)(scr + scr_row + (((g + 4) ^ (eml & 7)) * 16)) = ol[g];
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x4 d[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) d[qq] = *(const f32x4*)(scr + rd_off + qq * 1024);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) *(f32x4*)(p.y + line0 + (size_t)(qq * 8) * yrowb + st_off) = d[qq];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+}  // namespace mlk

@@ -21,6 +21,7 @@
 #include "dense_kernel_pp.h"
 #include "dense_kernel_w4.h"
 #include "dense_small.h"
+#include "dense_mid.h"
 #include "geom_kernels.h"
 #include "geom_ops.h"
 #include "mc_kernels.h"
@@ -149,10 +150,13 @@ struct Head {
 //   rows <= small_rows take the small-row dense kernels (no LDS staging) instead of the 256x256-tile persistent kernel; above
 //   small32_rows those use 32x32 output tiles (16x16 below); chunk_rows > 0 walks the batch in row chunks through all layers
 //   (Infinity-Cache residency experiment, off by default); tile_kernel 4 = dense_kernel_w4 for the long-K layers +
-//   dense_kernel_pp for the input / fused-head layers, 2 = dense_kernel_pp everywhere; tile_all: dense_kernel_w4 wherever it runs.
+//   dense_kernel_pp for the input / fused-head layers, 2 = dense_kernel_pp everywhere; tile_all: dense_kernel_w4 wherever it runs;
+//   small_rows < rows <= mid_rows take dense_mid_kernel (128 x 64 / 128 x 128 tiles: the 256x256 tiles are fewer than the CUs
+//   there), mid_tile 64 | 128 forces its tile height (0 = 64 while that leaves < 2 of the 128-row tiles per CU).
 struct Tuning {
     int small_rows = 2048, small32_rows = 128, chunk_rows = 0;
     int tile_kernel = 4, tile_all = 0;
+    int mid_rows = 12288, mid_tile = 0;
 };
 
 struct ml_loco {
@@ -449,15 +453,49 @@ bool use_small_path(const Tuning& tu, int precision, int64_t rows) {
     return dense_variant() != 1 && !dense_debug_bits() && precision != ML_PREC_BF16 && rows <= tu.small_rows;
 }
 
+bool use_mid_path(const Tuning& tu, int precision, int64_t rows) {
+    return dense_variant() != 1 && !dense_debug_bits() && precision != ML_PREC_BF16 && rows > tu.small_rows && rows <= tu.mid_rows;
+}
+
 // does the tile path run dense_kernel_w4 for a layer with this K (and fused head width)?
 bool w4_runs(const Tuning& tu, int K, int head_nh) {
     return tu.tile_kernel == 4 && K % 64 == 0 && (tu.tile_all || (K > 128 && head_nh <= 0));
 }
 
-int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0, int64_t rows = -1) {
+int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0, int64_t rows = -1,
+                 bool mid = false) {
     mlk::DenseParams p = p_in;
     p.debug = dense_debug_bits();
     p.trace = nullptr;
+
+    if (mid) {  // the caller chose the mid-size path (no fused heads there)
+        if (head_nh != 0 || p.N % mlk::MID_TN != 0) return fail(ML_ERR_STATE, "dense_mid_kernel: no fused head, N %% 128 == 0");
+        const int tiles128 = (p.M_pad / 128) * (p.N / mlk::MID_TN);
+        const int tm = tu.mid_tile ? tu.mid_tile : (tiles128 >= 2 * num_cus() ? 128 : 64);
+        const int tiles = (p.M_pad / tm) * (p.N / mlk::MID_TN);
+        const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
+#define ML_MID(NS, RL, RS)                                                                                                  \
+    do {                                                                                                                    \
+        if (tm == 128) hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, 128>), grid, dim3(mlk::MID_THREADS), 0, st, p); \
+        else hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, 64>), grid, dim3(mlk::MID_THREADS), 0, st, p);           \
+    } while (0)
+#define ML_MID_NS(NS)                                  \
+    do {                                               \
+        if (p.relu) {                                  \
+            if (p.res) ML_MID(NS, true, true);         \
+            else ML_MID(NS, true, false);              \
+        } else {                                       \
+            if (p.res) ML_MID(NS, false, true);        \
+            else ML_MID(NS, false, false);             \
+        }                                              \
+    } while (0)
+        if (precision == ML_PREC_F16X2) ML_MID_NS(3);
+        else ML_MID_NS(1);
+#undef ML_MID_NS
+#undef ML_MID
+        HIP_TRY(hipGetLastError());
+        return ML_OK;
+    }
 
     if (rows >= 0 && head_nh == 0) {  // the caller chose the small-row path
         // 16x16 tiles while they are few (latency: more workgroups), 32x32 tiles (half the L2 traffic) once there
@@ -628,6 +666,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
     const int64_t chunk_rows = h->tune.chunk_rows / 256 * 256;
     const int64_t chunk = (chunk_rows > 0 && mc.p <= 0.f) ? chunk_rows : m_pad_all;
     const bool small = use_small_path(h->tune, h->precision, rows);  // decided on the whole call, not per chunk
+    const bool mid = use_mid_path(h->tune, h->precision, rows);      // (heads as their own launches, like the small path)
     const bool defer = tail && chunk == m_pad_all;   // head reductions wait for the end of the (single) chunk
     const Head *def_fin = nullptr, *def_aux = nullptr;
     const int nparts = 2 * h->hidden / 256;
@@ -666,7 +705,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             const Head* fused = nullptr;
             for (const Head& hd : h->heads)
                 if (hd.after_layer == (int)li && (hd.nh == 8 || hd.nh == 9) && dense_variant() != 1 && L.relu && L.res < 0 &&
-                    !dense_debug_bits() && mc.p <= 0.f && !small)
+                    !dense_debug_bits() && mc.p <= 0.f && !small && !mid)
                     fused = &hd;
             if (fused) {
                 p.head_w = fused->d_w;
@@ -676,7 +715,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             // residual+relu layer when w3*w2 are merged, the plain w2 layer otherwise); its partials have their own region
             // behind the w_fin head's
             const Head* fused_aux = nullptr;
-            if (!fused && !small && mc.p <= 0.f && !dense_debug_bits() && dense_variant() != 1 && w4_runs(h->tune, L.kpad, 0) &&
+            if (!fused && !small && !mid && mc.p <= 0.f && !dense_debug_bits() && dense_variant() != 1 && w4_runs(h->tune, L.kpad, 0) &&
                 ((L.relu && L.res >= 0) || (!L.relu && L.res < 0)))
                 for (const Head& hd : h->heads)
                     if (hd.after_layer == (int)li && hd.nh == 1 && hd.src == L.dst) fused_aux = &hd;
@@ -686,7 +725,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             }
             const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
             if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
-            int rc = launch_dense(h->tune, h->precision, p, st, fused ? fused->nh : (fused_aux ? -1 : 0), small ? rows_here : -1);
+            int rc = launch_dense(h->tune, h->precision, p, st, fused ? fused->nh : (fused_aux ? -1 : 0), small ? rows_here : -1, mid);
             if (rc) return rc;
             if (timed) {
                 HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));
@@ -1325,8 +1364,9 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
     return ML_OK;
 }
 
-int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel) {
-    // negative = keep; the defaults are 2048 / 128 / 0 / 4
+int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel, int mid_rows, int mid_tile) {
+    // negative = keep; the defaults are 2048 / 128 / 0 / 4 / 12288 / 0
+    if (mid_tile > 0 && mid_tile != 64 && mid_tile != 128) return fail(ML_ERR_ARG, "mid tile height must be 0 (auto), 64 or 128");
     if (!h) return fail(ML_ERR_ARG, "null handle");
     if (tile_kernel >= 0) {
         const int which = tile_kernel & 255;
@@ -1337,6 +1377,8 @@ int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_r
     if (small_rows >= 0) h->tune.small_rows = small_rows;
     if (small32_rows >= 0) h->tune.small32_rows = small32_rows;
     if (chunk_rows >= 0) h->tune.chunk_rows = chunk_rows;
+    if (mid_rows >= 0) h->tune.mid_rows = mid_rows;
+    if (mid_tile >= 0) h->tune.mid_tile = mid_tile;
     return ML_OK;
 }
 
@@ -1384,8 +1426,10 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
     Tuning tu;   // which tile kernel: ML_DEBUG_TILE_PP = dense_kernel_pp, ML_DEBUG_TILE_W4 = dense_kernel_w4 wherever it runs
     if (precision & ML_DEBUG_TILE_PP) tu.tile_kernel = 2;
     if (precision & ML_DEBUG_TILE_W4) tu.tile_all = 1;
-    precision &= ~(ML_DEBUG_SMALL_PATH | ML_DEBUG_TILE_PP | ML_DEBUG_TILE_W4);
-    if (small_path && precision == ML_PREC_BF16) return fail(ML_ERR_ARG, "the bf16 mode has no small-row kernels");
+    const bool mid_path = (precision & (ML_DEBUG_MID_64 | ML_DEBUG_MID_128)) != 0;   // dense_mid_kernel with that tile height
+    if (mid_path) tu.mid_tile = (precision & ML_DEBUG_MID_64) ? 64 : 128;
+    precision &= ~(ML_DEBUG_SMALL_PATH | ML_DEBUG_TILE_PP | ML_DEBUG_TILE_W4 | ML_DEBUG_MID_64 | ML_DEBUG_MID_128);
+    if ((small_path || mid_path) && precision == ML_PREC_BF16) return fail(ML_ERR_ARG, "the bf16 mode runs on the 256x256-tile kernels only");
     hipStream_t st = (hipStream_t)stream;
     ml_loco tmp;
     tmp.precision = precision;
@@ -1437,7 +1481,7 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
                 hipLaunchKernelGGL(mlk::lines_to_bf16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, rl, pairs);
             }
         }
-        rc = launch_dense(tu, precision, p, st, 0, small_path ? m : -1);
+        rc = launch_dense(tu, precision, p, st, 0, small_path ? m : -1, mid_path);
         if (!rc) {
             const int64_t groups = m * (n / 8);
             hipLaunchKernelGGL(mlk::lines_to_f32_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, p.y, m,

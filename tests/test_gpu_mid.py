@@ -1,0 +1,106 @@
+"""-m gpu: dense_mid_kernel (128 x 64 / 128 x 128 workgroup tiles for the batches whose 256x256 tiles are fewer than the CUs)
+against fp64 and against the 256x256-tile kernel, layer by layer and through whole models on both sides of its row window."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tile", ["mid64", "mid128"])
+@pytest.mark.parametrize("m,k,n", [(256, 64, 256), (700, 96, 256), (1000, 1024, 1024), (3000, 32, 512), (9000, 1024, 1024)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
+def test_mid_single_layer(hip_lib, cuda_device, tile, m, k, n, relu, res):
+    """One layer: fp32-class accuracy against fp64, and the same operands through the 256x256-tile kernel (only the fp32
+    summation order differs).  Row counts that are not multiples of the tile, K of one to 32 lines, in-place residual."""
+    from monoloco_amd import engine
+    rng = np.random.default_rng(m + k + n)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    x = (rng.standard_normal((m, k)) * 2).astype(np.float32)
+    r = (rng.standard_normal((m, n)) * 3).astype(np.float32) if res else None
+    xd = torch.tensor(x).to(cuda_device)
+    rd = torch.tensor(r).to(cuda_device) if res else None
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    if res:
+        ref = ref + r
+    scale = max(1.0, np.abs(ref).max())
+    y_mid = engine.debug_linear(xd, w, b, relu=relu, res=rd, tile_kernel=tile).cpu().numpy()
+    y_tile = engine.debug_linear(xd, w, b, relu=relu, res=rd).cpu().numpy()
+    assert np.abs(y_mid - ref).max() <= 4e-6 * scale
+    assert np.abs(y_mid - y_tile).max() <= 2e-6 * scale
+
+
+def test_mid_single_product_mode(hip_lib, cuda_device):
+    from monoloco_amd import engine
+    rng = np.random.default_rng(3)
+    m, k, n = 2500, 512, 512
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    xd = torch.tensor(x).to(cuda_device)
+    ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + b, 0)
+    y_tile = engine.debug_linear(xd, w, b, relu=True, precision='f16').cpu().numpy()
+    for tile in ('mid64', 'mid128'):
+        y = engine.debug_linear(xd, w, b, relu=True, precision='f16', tile_kernel=tile).cpu().numpy()
+        assert np.abs(y - ref).max() <= 2e-2
+        assert np.abs(y - y_tile).max() <= 1e-4          # same rounded operands, one product per term
+    with pytest.raises(Exception):
+        engine.debug_linear(xd, w, b, relu=True, precision='bf16', tile_kernel='mid64')
+
+
+@pytest.mark.parametrize("mode", ["mono", "stereo"])
+@pytest.mark.parametrize("m", [2049, 4096, 5000, 8192, 12288])
+def test_mid_path_matches_tile_path(hip_lib, cuda_device, m, mode):
+    """Whole model inside the window (small_rows, mid_rows]: the default route is dense_mid_kernel + separate head launches,
+    mid_rows = 0 sends the same rows through the 256x256-tile kernels with their fused heads.  Each meets the parity bar
+    against fp64, and they agree with each other far below it; both tile heights."""
+    from monoloco_amd import engine
+    from oracle import monoloco_oracle as O
+    in_f, out_f = (34, 9) if mode == "mono" else (68, 10)
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(4, in_features=in_f, out_features=out_f).items()}
+    rng = np.random.default_rng(m)
+    x = torch.tensor((rng.standard_normal((m, in_f)) * 3).astype(np.float32), device=cuda_device)
+    eng = engine.LocoEngine(sd, device=cuda_device)
+    eng.set_tuning(mid_rows=0)
+    raw_tile = eng.forward_raw(x).cpu()
+    raws = {}
+    for tile in (0, 64, 128):
+        eng.set_tuning(mid_rows=12288, mid_tile=tile)
+        raws[tile] = eng.forward_raw(x).cpu()
+    ref64 = O.loco_forward(sd, x.cpu(), dtype=torch.float64)
+    scale = max(1.0, ref64.abs().max().item())
+    assert (raw_tile.double() - ref64).abs().max().item() <= 1e-4
+    for tile, raw in raws.items():
+        assert (raw.double() - ref64).abs().max().item() <= 1e-4, tile
+        assert (raw - raw_tile).abs().max().item() <= 2e-6 * scale, tile
+    assert torch.equal(raws[0], raws[64 if m < 8192 else 128])      # the automatic choice: 128-row tiles from 2 per CU
+    eng.close()
+
+
+def test_mid_path_pipeline_and_mc_dropout(hip_lib, cuda_device):
+    """The fused mono pipeline (prep -> layers -> heads -> post) and the batched MC-dropout passes inside the window."""
+    from monoloco_amd import engine
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(6).items()}
+    kps = torch.tensor(synth.make_poses(5000, 3)).to(cuda_device)
+    kinv = engine.inverse_intrinsics(synth.KITTI_K)
+    eng = engine.LocoEngine(sd, device=cuda_device)
+    out_mid, xyzds_mid, raw_mid = [t.clone() for t in eng.forward_mono(kps, kinv, want_raw=True)]
+    eng.set_tuning(mid_rows=0)
+    out_tile, xyzds_tile, raw_tile = eng.forward_mono(kps, kinv, want_raw=True)
+    assert (raw_mid - raw_tile).abs().max().item() <= 2e-6 * max(1.0, raw_tile.abs().max().item())
+    assert (xyzds_mid - xyzds_tile).abs().max().item() <= 1e-4
+    assert (out_mid.nan_to_num() - out_tile.nan_to_num()).abs().max().item() <= 1e-4
+    # 20 stochastic passes over 256 persons = 5120 batched rows; the masks are counter-based (row, column, seed), so the two
+    # routes drop the same units and the passes agree like the deterministic forward does
+    _, p_tile = eng.epistemic_mono(kps[:256], kinv, 20, 0.2, want_passes=True)
+    p_tile = p_tile.clone()
+    eng.set_tuning(mid_rows=12288)
+    _, p_mid = eng.epistemic_mono(kps[:256], kinv, 20, 0.2, want_passes=True)
+    assert (p_mid - p_tile).abs().max().item() <= 4e-6 * max(1.0, p_tile.abs().max().item())
+    assert p_mid.std(0).min().item() > 0          # the passes do differ from each other
+    eng.close()
