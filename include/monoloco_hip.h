@@ -180,6 +180,12 @@ int ml_loco_forward_raw(ml_loco* h, const float* x_dev, int64_t m, float* raw_de
 int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host,
                          const float* box_conf_dev, float* raw_dev, float* out_dev,
                          float* xyzds_dev, void* stream);
+/* One image in one call (what the reference's Loco.forward + the geometry of post_process do per frame, net.py:83-133,
+ * 195-215): kps_host (m,3,17) PINNED host memory -> kps_dev (async copy), the pipeline above into buf_dev = [packed (m,16) |
+ * post-process geometry (m,12)] (one allocation of m * 28 floats), one copy of that into out_host (pinned), one stream
+ * synchronisation.  xyzds_dev (m,5) or NULL. */
+int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float* kinv_host, float* kps_dev, float* buf_dev,
+                       float* xyzds_dev, float* out_host, void* stream);
 /* stereo (net.py:112-122, process.py:307-327): all left x right pairs, per-left arg-max of the
  * aux logit.  best_dev (ml) int32 receives the first arg-max right index; ties_dev (1) int32
  * receives the number of left persons with more than one maximal pair (the reference keeps
@@ -308,7 +314,7 @@ int ml_loco_profile_end(ml_loco* h, int64_t* launches, double* total_ms, double*
 /* Dense layer on its own: y = [relu](x . W^T + b) [+ res]; x (m,k), w (n,k), b (n), res (m,n)
  * or NULL, y (m,n); all fp32 device pointers except w/b which are host.  k, n: n multiple of 256.
  * The 256x256-tile kernel runs it unless ML_DEBUG_SMALL_PATH is or-ed into `precision` (then the
- * small-row kernels the model path takes for <= 2048 rows). */
+ * small-row kernels the model path takes for <= 512 rows). */
 #define ML_DEBUG_SMALL_PATH 256
 #define ML_DEBUG_TILE_PP 512    /* ... the tile path on dense_kernel_pp */
 #define ML_DEBUG_TILE_W4 1024   /* ... the tile path on dense_kernel_w4 wherever it runs (default: w4 for K > 128) */
@@ -323,11 +329,11 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
 int ml_debug_get_layer(const ml_loco* h, int layer, float* w_host, float* b_host, int* n, int* k,
                        int* scale_pow2);
 int ml_debug_num_layers(const ml_loco* h);
-/* Path selection of ONE handle, for tests / A-B runs that compare the paths (negative = leave unchanged; defaults 2048 / 128 /
+/* Path selection of ONE handle, for tests / A-B runs that compare the paths (negative = leave unchanged; defaults 512 / 128 /
  * 0 / 4): rows <= small_rows take the small-row dense kernels, above small32_rows those use 32x32 tiles; chunk_rows > 0 walks
  * the batch in row chunks of that size through all layers; tile_kernel: 4 = dense_kernel_w4 for the long-K layers,
  * dense_kernel_pp for the short input layer and the fused-head layer (default), 2 = dense_kernel_pp everywhere, 4 | 256 =
- * dense_kernel_w4 wherever it can run; small_rows < rows <= mid_rows (default 12288) take dense_mid_kernel, whose tile
+ * dense_kernel_w4 wherever it can run; small_rows < rows <= mid_rows (default 9216) take dense_mid_kernel, whose tile
  * height mid_tile is 0 (chosen from the row count, default), 64 or 128.  Nothing here is process-global: handles stay
  * thread-compatible. */
 int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel, int mid_rows,

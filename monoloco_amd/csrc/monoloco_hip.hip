@@ -154,9 +154,9 @@ struct Head {
 //   small_rows < rows <= mid_rows take dense_mid_kernel (128 x 64 / 128 x 128 tiles: the 256x256 tiles are fewer than the CUs
 //   there), mid_tile 64 | 128 forces its tile height (0 = 64 while that leaves < 2 of the 128-row tiles per CU).
 struct Tuning {
-    int small_rows = 2048, small32_rows = 128, chunk_rows = 0;
+    int small_rows = 512, small32_rows = 128, chunk_rows = 0;
     int tile_kernel = 4, tile_all = 0;
-    int mid_rows = 12288, mid_tile = 0;
+    int mid_rows = 9216, mid_tile = 0;
 };
 
 struct ml_loco {
@@ -1365,7 +1365,7 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
 }
 
 int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel, int mid_rows, int mid_tile) {
-    // negative = keep; the defaults are 2048 / 128 / 0 / 4 / 12288 / 0
+    // negative = keep; the defaults are 512 / 128 / 0 / 4 / 9216 / 0 (measured crossovers, profiles/r03_mid_sweep.txt)
     if (mid_tile > 0 && mid_tile != 64 && mid_tile != 128) return fail(ML_ERR_ARG, "mid tile height must be 0 (auto), 64 or 128");
     if (!h) return fail(ML_ERR_ARG, "null handle");
     if (tile_kernel >= 0) {
@@ -1379,6 +1379,25 @@ int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_r
     if (chunk_rows >= 0) h->tune.chunk_rows = chunk_rows;
     if (mid_rows >= 0) h->tune.mid_rows = mid_rows;
     if (mid_tile >= 0) h->tune.mid_tile = mid_tile;
+    return ML_OK;
+}
+
+// One image through the mono pipeline in ONE call: pinned host keypoints -> device (async), ml_loco_forward_mono, the
+// post-process geometry block behind it, one copy of [packed (m, 16) | geometry (m, 12)] back into pinned host memory, one
+// stream synchronisation.  What Loco.forward does per frame (reference net.py:83-133 + the geometry of :195-215); as one entry
+// the host pays one foreign call instead of five.
+int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float* kinv_host, float* kps_dev, float* buf_dev,
+                       float* xyzds_dev, float* out_host, void* stream) {
+    if (m < 0 || !kinv_host || (m > 0 && (!kps_host || !kps_dev || !buf_dev || !out_host))) return fail(ML_ERR_ARG, "bad argument");
+    if (m == 0) return ML_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(kps_dev, kps_host, (size_t)m * 3 * mlk::NKP * 4, hipMemcpyHostToDevice, st));
+    int rc = ml_loco_forward_mono(h, kps_dev, m, kinv_host, nullptr, nullptr, buf_dev, xyzds_dev, stream);
+    if (rc) return rc;
+    float* geo = buf_dev + (size_t)m * ML_OUT_STRIDE;
+    if ((rc = ml_post_geometry_strided(kps_dev, m, kinv_host, buf_dev + 3, ML_OUT_STRIDE, geo, stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out_host, buf_dev, (size_t)m * (ML_OUT_STRIDE + ML_POSTGEO_STRIDE) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return ML_OK;
 }
 

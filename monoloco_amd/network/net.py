@@ -157,22 +157,25 @@ class Loco:
             st['p_d'] = ctypes.c_void_p(st['buf'].data_ptr() + 3 * 4)
             st['p_geo'] = ctypes.c_void_p(st['buf'].data_ptr() + m * stride * 4)
             st['p_xyzds'] = ctypes.c_void_p(st['xyzds'].data_ptr())
+            st['p_pin_in'] = ctypes.c_void_p(pin_in.data_ptr())
+            st['p_pin_out'] = ctypes.c_void_p(pin_out.data_ptr())
             self._stage[m] = st
+        stream = engine._stream(dev)
+        kinv_p = engine.kinv_ptr(kinv)
         if isinstance(kps, torch.Tensor):     # already on the device: no staging
             assert tuple(kps.shape[1:]) == (3, 17), "keypoints must be (m, 3, 17)"
             p_in = ctypes.c_void_p(kps.data_ptr())
-        else:
+            with torch.cuda.device(dev):
+                engine.check(lib.ml_loco_forward_mono(self.engine._h, p_in, m, kinv_p, None, None, st['p_out'], st['p_xyzds'], stream))
+                engine.check(lib.ml_post_geometry_strided(p_in, m, kinv_p, st['p_d'], stride, st['p_geo'], stream))
+                st['pin_out'].copy_(st['buf'], non_blocking=True)
+                torch.cuda.current_stream(dev).synchronize()
+        else:                                 # the frame in ONE foreign call: H2D, pipeline, geometry, D2H, stream sync
             assert kps.shape[1:] == (3, 17), "keypoints must be (m, 3, 17)"
             np.copyto(st['np_in'], kps)
-            st['dev_in'].copy_(st['pin_in'], non_blocking=True)
-            p_in = st['p_in']
-        stream = engine._stream(dev)
-        kinv_p = engine.kinv_ptr(kinv)
-        with torch.cuda.device(dev):
-            engine.check(lib.ml_loco_forward_mono(self.engine._h, p_in, m, kinv_p, None, None, st['p_out'], st['p_xyzds'], stream))
-            engine.check(lib.ml_post_geometry_strided(p_in, m, kinv_p, st['p_d'], stride, st['p_geo'], stream))
-            st['pin_out'].copy_(st['buf'], non_blocking=True)
-            torch.cuda.current_stream(dev).synchronize()
+            with torch.cuda.device(dev):
+                engine.check(lib.ml_loco_frame_mono(self.engine._h, st['p_pin_in'], m, kinv_p, st['p_in'], st['p_out'], st['p_xyzds'],
+                                                    st['p_pin_out'], stream))
         host = st['np_out']
         n = m * stride
         packed = host[:n].reshape(m, stride)

@@ -201,7 +201,7 @@ def test_empty_and_errors(hip_lib, cuda_device):
 @pytest.mark.parametrize("mode", ["mono", "stereo"])
 @pytest.mark.parametrize("m", [1, 16, 17, 100, 129, 300, 1000, 2048])
 def test_small_row_path_matches_tile_path(hip_lib, cuda_device, monkeypatch, m, mode):
-    """rows <= the small-row threshold (2048, LocoEngine.set_tuning) run dense_small_kernel (16x16 tiles up to 128 rows, 32x32 tiles above; K split over 4
+    """rows <= the small-row threshold (512 by default, 2048 here: LocoEngine.set_tuning) run dense_small_kernel (16x16 tiles up to 128 rows, 32x32 tiles above; K split over 4
     waves), larger batches the 256x256-tile persistent kernel: same operands and epilogue, only the fp32
     accumulation order differs.
     Both must agree with each other far below the parity bar and each must meet the bar against fp64."""
@@ -211,7 +211,7 @@ def test_small_row_path_matches_tile_path(hip_lib, cuda_device, monkeypatch, m, 
     rng = np.random.default_rng(m)
     x = torch.tensor((rng.standard_normal((m, in_f)) * 3).astype(np.float32), device=cuda_device)
     eng = engine.LocoEngine(_sd_t(sd), device=cuda_device)
-    eng.set_tuning(small_rows=0)
+    eng.set_tuning(small_rows=0, mid_rows=0)
     raw_tile = eng.forward_raw(x).cpu()
     eng.set_tuning(small_rows=2048)
     raw_small = eng.forward_raw(x).cpu()
@@ -250,7 +250,7 @@ def test_small_row_path_single_fp16_mode(hip_lib, cuda_device, monkeypatch, m):
     rng = np.random.default_rng(m)
     x = torch.tensor((rng.standard_normal((m, 34)) * 3).astype(np.float32), device=cuda_device)
     eng = engine.LocoEngine(_sd_t(sd), device=cuda_device, precision='f16')
-    eng.set_tuning(small_rows=0)
+    eng.set_tuning(small_rows=0, mid_rows=0)
     raw_tile = eng.forward_raw(x).cpu()
     eng.set_tuning(small_rows=2048)
     raw_small = eng.forward_raw(x).cpu()

@@ -35,6 +35,7 @@ def _xgemm(lib, dev, a, alay, b, blay, M, N, K, bias=None, res=None, want_sumsq=
 
 
 @pytest.mark.parametrize("M,N,K", [(331, 1024, 1024), (512, 1024, 1024), (1024, 1024, 331), (70, 128, 96), (1, 64, 32), (513, 256, 1056),
+                                   (2048, 1024, 1024), (4096, 256, 512), (3000, 64, 1024), (256, 256, 4096),
                                    (64, 192, 77)])
 def test_xgemm_layouts_against_fp64(hip_lib, cuda_device, M, N, K):
     """C = sum_k A(i, k) B(j, k) on the exact fp32 matrix instruction for the three operand layouts the step uses (forward:
@@ -89,7 +90,8 @@ def test_xgemm_epilogue(hip_lib, cuda_device):
 
 
 @pytest.mark.parametrize("mode,hidden,p_drop,rows", [('mono', 256, 0.0, None), ('stereo', 128, 0.2, None), ('mono', 1024, 0.2, None),
-                                                     ('mono', 1024, 0.0, 512), ('stereo', 320, 0.0, 1500)])
+                                                     ('mono', 1024, 0.0, 512), ('stereo', 320, 0.0, 1500), ('mono', 1024, 0.0, 2048),
+                                                     ('mono', 1024, 0.2, 3500)])
 def test_mid_route_matches_exact_route(hip_lib, cuda_device, mode, hidden, p_drop, rows):
     """Same step on the exact-fp32 route and on the mid route: losses, outputs, gradients, BatchNorm statistics; the device
     RNG is the same on both, so dropout masks agree.  (hidden 320: % 64 == 0 but not % 256 -- mid is the only fast route.)"""

@@ -1,0 +1,8 @@
+# round 3, GPU call S: xgemm -- the first barrier?
+O=$GRAFT_REPO_ROOT/gpurun_out/r03s; mkdir -p $O; cd $GRAFT_REPO_ROOT
+for v in 128 256; do
+  L=$GRAFT_REPO_ROOT/monoloco_amd/lib/libmonoloco_hip_xg$v.so
+  REPS=30 MONOLOCO_HIP_LIB=$L timeout 300 python tools/exp_xgemm_occ.py > $O/occ$v.txt 2>&1
+  echo "== variant $v: wrong tiles per run: $(grep '^run' $O/occ$v.txt | sed 's/run [0-9]*: \([0-9]*\) of.*/\1/' | tr '\n' ' ')"
+  grep "tile (" $O/occ$v.txt | head -3 | cut -c1-330
+done

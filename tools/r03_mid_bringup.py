@@ -32,6 +32,9 @@ def compare(hidden, m, p_drop, mode='mono'):
     for n in names + ['out', 'dout']:
         a, b = bufs['exact'][n], bufs['mid'][n]
         print('   %-5s max|exact| %.3e  max|diff| %.3e  nan %d' % (n, a.abs().max().item(), (a - b).abs().max().item(), int(torch.isnan(b).sum())))
+    d = (bufs['exact']['za0'] - bufs['mid']['za0']).abs()
+    print('   za0 max|diff| per 128-row block:', ' '.join('%.0e' % d[i:i + 128].max().item() for i in range(0, m, 128)))
+    print('   za0 max|diff| per 128-column block:', ' '.join('%.0e' % d[:, j:j + 128].max().item() for j in range(0, hidden, 128)))
     for k in res['exact'][1]:
         a, b = res['exact'][1][k], res['mid'][1][k]
         print('   grad %-40s max|exact| %.3e  rel diff %.3e' % (k, a.abs().max().item(), ((a - b).abs().max() / a.abs().max().clamp_min(1e-30)).item()))
@@ -64,5 +67,8 @@ if __name__ == '__main__':
         compare(128, 331, 0.0)
         compare(1024, 331, 0.2)
         compare(256, 700, 0.0, 'stereo')
+    if what == 'rows':   # where (if anywhere) the mid route drifts from the exact route as the batch grows
+        for m in [int(a) for a in sys.argv[2:]] or [1024, 2048, 4096]:
+            compare(1024, m, 0.0)
     if what in ('all', 'timing'):
         timing()
