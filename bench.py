@@ -457,7 +457,7 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
 
     def other_batches():
         # row counts between one image and the headline batch (a video batch, a handful of camera streams): the same pipeline, the
-        # dense layers on the kernel the engine picks for that row count (small-row <= 512 < dense_mid_kernel <= 9216 < 256x256 tiles)
+        # dense layers on the kernel the engine picks for that row count (small-row <= 512 < dense_mid_kernel <= 8192 < 256x256 tiles)
         res = {"config": "the same mono pipeline at other batch sizes, one GPU; route = the dense kernel family the engine chooses"}
         for rows in (1024, 2048, 4096, 8192, 16384):
             k = kps[:rows].contiguous()
@@ -466,7 +466,7 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
             x = torch.empty((rows, 5), dtype=torch.float32, device=dev)
             ms = _ms(lambda: eng.forward_mono(k, kinv, box_conf=c, out=o, xyzds=x), 60, 10, dev)
             res["rows_%d" % rows] = {"us_per_step": round(ms * 1e3, 1), "persons_per_s": round(rows / ms * 1e3, 1),
-                                     "route": "small" if rows <= 512 else ("mid" if rows <= 9216 else "tile")}
+                                     "route": "small" if rows <= 512 else ("mid" if rows <= 8192 else "tile")}
         return res
     guarded("other_batches", other_batches)
 

@@ -333,7 +333,7 @@ int ml_debug_num_layers(const ml_loco* h);
  * 0 / 4): rows <= small_rows take the small-row dense kernels, above small32_rows those use 32x32 tiles; chunk_rows > 0 walks
  * the batch in row chunks of that size through all layers; tile_kernel: 4 = dense_kernel_w4 for the long-K layers,
  * dense_kernel_pp for the short input layer and the fused-head layer (default), 2 = dense_kernel_pp everywhere, 4 | 256 =
- * dense_kernel_w4 wherever it can run; small_rows < rows <= mid_rows (default 9216) take dense_mid_kernel, whose tile
+ * dense_kernel_w4 wherever it can run; small_rows < rows <= mid_rows (default 8192) take dense_mid_kernel, whose tile
  * height mid_tile is 0 (chosen from the row count, default), 64 or 128.  Nothing here is process-global: handles stay
  * thread-compatible. */
 int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel, int mid_rows,

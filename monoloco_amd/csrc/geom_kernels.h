@@ -33,27 +33,29 @@ __device__ __forceinline__ float cam_row(float u, float v, const float* kr, floa
 }
 
 // ------------------------------------------------------------------------------------------
-// prep: one workgroup = 256 persons.  The (256 x 51) fp32 slab is contiguous in HBM, so it is
+// prep: one workgroup of 256 threads = PB persons (256 for the big batches; 32 below ~8k persons, where 256 per workgroup
+// leave most CUs without work: 15 -> 6 us at 4096 persons).  The (PB x 51) fp32 slab is contiguous in HBM, so it is
 // loaded fully coalesced into LDS, each thread then normalises its own person out of LDS (row
 // stride 51 dwords: odd, conflict free), and every output is written back coalesced:
 //   x_f32   (m,34) fp32 reference-format inputs            (optional)
 //   centre  (m,2)  box-centre pixel, (max-min)/2+min        (optional)
 //   x_lines (m_pad, kpad) line-format network input, zero padded in k and in rows >= m (optional)
+template <int PB>
 __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ kps, int64_t m, Kinv ki,
                                                    float z_met, float* __restrict__ x_f32,
                                                    float* __restrict__ centre, char* __restrict__ x_lines,
                                                    int kpad, int64_t m_pad, int zero_center) {
-    __shared__ float s_in[256 * KPS_ROW];
-    __shared__ float s_x[256 * NIN];
+    __shared__ float s_in[PB * KPS_ROW];
+    __shared__ float s_x[PB * NIN];
     const int t = threadIdx.x;
-    const int64_t p0 = (int64_t)blockIdx.x * 256;
-    const int64_t nvalid = (m - p0) < 256 ? (m - p0 > 0 ? m - p0 : 0) : 256;
+    const int64_t p0 = (int64_t)blockIdx.x * PB;
+    const int64_t nvalid = (m - p0) < PB ? (m - p0 > 0 ? m - p0 : 0) : PB;
     const float* src = kps + p0 * KPS_ROW;
     const int nfl = (int)nvalid * KPS_ROW;
     for (int i = t; i < nfl; i += 256) s_in[i] = src[i];
     __syncthreads();
     // (a) per person: box centre (and, for zero_center, its normalised image) -- only when somebody needs it
-    __shared__ float s_c[256][2];
+    __shared__ float s_c[PB][2];
     const bool need_centre = centre != nullptr || zero_center;
     if (need_centre && t < nvalid) {
         const float* u = s_in + t * KPS_ROW;
@@ -96,8 +98,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ kps
         // 16-byte chunks: person pi, chunk c of its row; chunk (b, sub): sub<4 hi, sub>=4 lo of
         // k = 32b + 8(sub&3) .. +7
         const int cpr = kpad / 4;  // 16-B chunks per row = kpad*4/16
-        const int total = 256 * cpr;
-        const int64_t rows_here = (m_pad - p0) < 256 ? (m_pad - p0) : 256;
+        const int total = PB * cpr;
+        const int64_t rows_here = (m_pad - p0) < PB ? (m_pad - p0) : PB;
         char* dst = x_lines + p0 * (int64_t)kpad * 4;
         for (int id = t; id < total; id += 256) {
             const int pi = id / cpr, c = id - pi * cpr;
@@ -479,6 +481,92 @@ __global__ __launch_bounds__(256) void heads_small_kernel(SmallHeads hp, int H, 
     }
 }
 
+
+// Both output heads of a LocoModel (w_fin: NH outputs from act_fin; w_aux: one output from act_aux) in ONE launch, for the
+// mid-size path, where two heads_kernel launches + post_kernel are ~10 % of a 4096-row forward: heads_kernel's loop and fma
+// order per head (same bits as the separate launches), then, when post_out is given, the mono post-process of the row by the
+// lane that holds it (post_person) -- raw may then be null.  Dynamic LDS: (NH + 1) * H floats.
+template <int NH>
+__global__ __launch_bounds__(256) void heads_pair_kernel(const char* __restrict__ act_fin, const char* __restrict__ act_aux, int H,
+                                                         const float* __restrict__ w_fin, const float* __restrict__ b_fin,
+                                                         const float* __restrict__ w_aux, const float* __restrict__ b_aux,
+                                                         float* __restrict__ raw, int64_t m,
+                                                         const float* __restrict__ centre, Kinv ki,
+                                                         const float* __restrict__ box_conf, float* __restrict__ post_out,
+                                                         float* __restrict__ xyzds) {
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    float* s_w = (float*)dyn_smem;  // [NH][H] then the aux head's [H]
+    for (int i = threadIdx.x; i < NH * H; i += 256) s_w[i] = w_fin[i];
+    for (int i = threadIdx.x; i < H; i += 256) s_w[NH * H + i] = w_aux[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int npairs = H / 8;
+    const int64_t nquads = (m + 3) / 4;
+    for (int64_t qd = (int64_t)blockIdx.x * 4 + wave; qd < nquads; qd += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = qd * 4;
+        float acc[4][NH + 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int o = 0; o <= NH; ++o) acc[r][o] = 0.0f;
+        for (int pr = lane; pr < npairs; pr += 64) {
+            const int b = pr >> 2, sub = pr & 3;
+            const int n = b * 32 + sub * 8;
+            float xv[4][8], xa[4][8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = (r0 + r < m) ? (r0 + r) : (m - 1);
+                const size_t off = (size_t)row * H * 4 + b * LINE + sub * 16;
+                const half8 hi = *(const half8*)(act_fin + off), lo = *(const half8*)(act_fin + off + 64);
+                const half8 hj = *(const half8*)(act_aux + off), lj = *(const half8*)(act_aux + off + 64);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xv[r][e] = (float)hi[e] + (float)lo[e];
+                    xa[r][e] = (float)hj[e] + (float)lj[e];
+                }
+            }
+#pragma unroll
+            for (int o = 0; o <= NH; ++o) {
+                const f32x4 wa = *(const f32x4*)(s_w + o * H + n);
+                const f32x4 wb = *(const f32x4*)(s_w + o * H + n + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = acc[r][o];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = __builtin_fmaf(o < NH ? xv[r][e] : xa[r][e], wa[e], a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a = __builtin_fmaf(o < NH ? xv[r][4 + e] : xa[r][4 + e], wb[e], a);
+                    acc[r][o] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int o = 0; o <= NH; ++o) {
+                float a = acc[r][o];
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) a += __shfl_xor(a, s, 64);
+                acc[r][o] = a;
+            }
+        // every lane holds all sums; lane r finishes row r0 + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (lane == r && r0 + r < m) {
+                float rowv[NH + 1];   // the raw row: w_fin's NH outputs, then the aux logit (the host checks that column order)
+#pragma unroll
+                for (int o = 0; o < NH; ++o) rowv[o] = acc[r][o] + b_fin[o];
+                rowv[NH] = acc[r][NH] + b_aux[0];
+                if (raw) {
+#pragma unroll
+                    for (int c = 0; c <= NH; ++c) raw[(r0 + r) * (NH + 1) + c] = rowv[c];
+                }
+                if (post_out) post_person(rowv, NH + 1, r0 + r, centre, ki, box_conf, post_out, xyzds);
+            }
+        }
+    }
+}
 
 // The tail of the mono tile path in ONE launch instead of three: both fused heads' partial sums are added exactly as
 // head_reduce_kernel / aux_reduce_kernel add them (bias first, slices in order), the raw row lives in registers (and is

@@ -156,7 +156,7 @@ struct Head {
 struct Tuning {
     int small_rows = 512, small32_rows = 128, chunk_rows = 0;
     int tile_kernel = 4, tile_all = 0;
-    int mid_rows = 9216, mid_tile = 0;
+    int mid_rows = 8192, mid_tile = 0;
 };
 
 struct ml_loco {
@@ -763,7 +763,42 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             // a single image's worth of rows: all heads in ONE launch after the last dense layer (their source
             // buffers are both still intact there), one workgroup per row
             const bool one_launch = small && rows <= 128 && mc.p <= 0.f && h->heads.size() <= 2;
-            if (one_launch) {
+            // the mid-size path: both heads (+ the mono post-process) in one launch behind the last layer, when the model has the
+            // LocoModel pair (w_fin: 8 | 9 outputs in columns 0.., w_aux: the last column)
+            const Head *pf = nullptr, *pa = nullptr;
+            if (mid && mc.p <= 0.f && h->heads.size() == 2 && h->precision != ML_PREC_BF16) {
+                for (const Head& hd : h->heads) {
+                    if ((hd.nh == 8 || hd.nh == 9) && hd.col0 == 0) pf = &hd;
+                    else if (hd.nh == 1) pa = &hd;
+                }
+                if (!pf || !pa || pa->col0 != pf->nh || h->out_f != pf->nh + 1) pf = pa = nullptr;
+            }
+            if (pf) {
+                if (li + 1 == h->layers.size() && rows_here > 0) {
+                    const size_t lds = (size_t)(pf->nh + 1) * h->hidden * 4;
+                    int grid = (int)((((rows_here + 3) / 4) + 3) / 4);
+                    if (grid > 2048) grid = 2048;
+                    const bool with_post = defer;
+                    float* raw_dst = with_post ? tail->raw : raw_out + r0 * h->out_f;
+#define ML_PAIR(NH)                                                                                                          \
+    do {                                                                                                                     \
+        if (lds > 65536)                                                                                                     \
+            HIP_TRY(hipFuncSetAttribute((const void*)mlk::heads_pair_kernel<NH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds));                                                                          \
+        hipLaunchKernelGGL(mlk::heads_pair_kernel<NH>, dim3(grid), dim3(256), lds, st, (const char*)at(pf->src),             \
+                           (const char*)at(pa->src), h->hidden, (const float*)pf->d_w, (const float*)pf->d_b,                \
+                           (const float*)pa->d_w, (const float*)pa->d_b, raw_dst, rows_here,                                 \
+                           with_post ? tail->centre : (const float*)nullptr, with_post ? tail->ki : mlk::Kinv{},             \
+                           with_post ? tail->box_conf : (const float*)nullptr, with_post ? tail->out : (float*)nullptr,      \
+                           with_post ? tail->xyzds : (float*)nullptr);                                                       \
+    } while (0)
+                    if (pf->nh == 8) ML_PAIR(8);
+                    else ML_PAIR(9);
+#undef ML_PAIR
+                    HIP_TRY(hipGetLastError());
+                    if (with_post) tail->done = true;
+                }
+            } else if (one_launch) {
                 if (li + 1 == h->layers.size() && rows_here > 0) {
                     mlk::SmallHeads hp = {};
                     int k = 0;
@@ -1061,16 +1096,28 @@ int ml_loco_destroy(ml_loco* h) {
 
 int64_t ml_loco_device_bytes(const ml_loco* h) { return h ? h->dev_bytes : 0; }
 
+// prep_kernel with the workgroup size in persons chosen from the rows it has to cover (the persons, or the zero-filled
+// line rows behind them): 32 per workgroup while that still leaves CUs idle, 256 for the big batches
+static int launch_prep(hipStream_t st, const float* kps, int64_t m, const mlk::Kinv& ki, float z_met, float* x_f32, float* centre,
+                char* lines, int kpad, int64_t fill_rows, int zero_center) {
+    const int64_t cover = (lines && fill_rows > m) ? fill_rows : m;
+    if (cover <= 0) return ML_OK;
+    if (cover <= 8192)
+        hipLaunchKernelGGL(mlk::prep_kernel<32>, dim3((unsigned)((cover + 31) / 32)), dim3(256), 0, st, kps, m, ki, z_met, x_f32, centre,
+                           lines, kpad, fill_rows, zero_center);
+    else
+        hipLaunchKernelGGL(mlk::prep_kernel<256>, dim3((unsigned)((cover + 255) / 256)), dim3(256), 0, st, kps, m, ki, z_met, x_f32,
+                           centre, lines, kpad, fill_rows, zero_center);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
 // ---------------------------------------------------------------- stand-alone geometry
 int ml_preprocess_mono(const float* kps_dev, int64_t m, const float* kinv_host, float z_met, int zero_center,
                        float* x_dev, float* centre_dev, void* stream) {
     if (m == 0) return ML_OK;
     if (m < 0 || !kinv_host || !kps_dev) return fail(ML_ERR_ARG, "bad argument");
-    const int grid = (int)((m + 255) / 256);
-    hipLaunchKernelGGL(mlk::prep_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, kps_dev, m,
-                       make_kinv(kinv_host), z_met, x_dev, centre_dev, (char*)nullptr, 0, m, zero_center);
-    HIP_TRY(hipGetLastError());
-    return ML_OK;
+    return launch_prep((hipStream_t)stream, kps_dev, m, make_kinv(kinv_host), z_met, x_dev, centre_dev, (char*)nullptr, 0, m, zero_center);
 }
 
 int ml_stereo_pairs(const float* xl_dev, int64_t ml, const float* xr_dev, int64_t mr, float* rows_dev,
@@ -1233,9 +1280,9 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
     const int64_t m_pad = round_up64(m, 256);
     const mlk::Kinv ki = make_kinv(kinv_host);
     // the small-row dense kernels read whole 32-row tiles only: no need to zero-fill up to the 256-row panel
-    hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(m_pad / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
-                       (float*)nullptr, h->d_centre, h->buf[0], h->k0pad, use_small_path(h->tune, h->precision, m) ? round_up64(m, 32) : m_pad, 0);
-    HIP_TRY(hipGetLastError());
+    if ((rc = launch_prep(st, kps_dev, m, ki, 10.0f, (float*)nullptr, h->d_centre, h->buf[0], h->k0pad,
+                          use_small_path(h->tune, h->precision, m) ? round_up64(m, 32) : m_pad, 0)))
+        return rc;
     float* raw = raw_dev ? raw_dev : h->d_raw;
     TailMono tail{h->d_centre, ki, box_conf_dev, out_dev, xyzds_dev, raw_dev};
     if ((rc = run_network(h, m, raw, st, McPass(), &tail))) return rc;
@@ -1261,11 +1308,8 @@ int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const
     if ((rc = ensure_side(h, ml > mr ? ml : mr))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const mlk::Kinv ki = make_kinv(kinv_host);
-    hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, st, kps_l_dev, ml, ki, 10.0f,
-                       h->d_xl, h->d_cl, (char*)nullptr, 0, ml, 0);
-    hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)((mr + 255) / 256)), dim3(256), 0, st, kps_r_dev, mr, ki, 10.0f,
-                       h->d_xr, (float*)nullptr, (char*)nullptr, 0, mr, 0);
-    HIP_TRY(hipGetLastError());
+    if ((rc = launch_prep(st, kps_l_dev, ml, ki, 10.0f, h->d_xl, h->d_cl, (char*)nullptr, 0, ml, 0))) return rc;
+    if ((rc = launch_prep(st, kps_r_dev, mr, ki, 10.0f, h->d_xr, (float*)nullptr, (char*)nullptr, 0, mr, 0))) return rc;
     const int64_t rows_pad = round_up64(rows, 256);
     const int64_t chunks = rows_pad * (h->k0pad / 4);
     hipLaunchKernelGGL(mlk::pairs_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, h->d_xl, ml, h->d_xr,
@@ -1318,9 +1362,9 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
         // the stochastic forward consumes the input lines afresh every time (buffer A is overwritten); rows beyond
         // the batched passes are zero-filled by the first prep launch only up to round_up(m), so clear the tail
         // legacy 'monoloco' (2 outputs = d, s) is fed zero-centred inputs (net.py:96)
-        hipLaunchKernelGGL(mlk::prep_kernel, dim3((unsigned)(round_up64(m, 256) / 256)), dim3(256), 0, st, kps_dev, m, ki, 10.0f,
-                           (float*)nullptr, (float*)nullptr, h->buf[0], h->k0pad, round_up64(m, 256),
-                           (h->legacy && h->out_f == 2) ? 1 : 0);
+        if ((rc = launch_prep(st, kps_dev, m, ki, 10.0f, (float*)nullptr, (float*)nullptr, h->buf[0], h->k0pad, round_up64(m, 256),
+                              (h->legacy && h->out_f == 2) ? 1 : 0)))
+            return rc;
         if (pc > 1) {
             const int64_t n16 = line_bytes / 16 * (pc - 1);
             hipLaunchKernelGGL(mlk::replicate_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, h->buf[0], line_bytes, pc);
@@ -1365,7 +1409,7 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
 }
 
 int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel, int mid_rows, int mid_tile) {
-    // negative = keep; the defaults are 512 / 128 / 0 / 4 / 9216 / 0 (measured crossovers, profiles/r03_mid_sweep.txt)
+    // negative = keep; the defaults are 512 / 128 / 0 / 4 / 8192 / 0 (measured crossovers, profiles/r03_mid_sweep.txt)
     if (mid_tile > 0 && mid_tile != 64 && mid_tile != 128) return fail(ML_ERR_ARG, "mid tile height must be 0 (auto), 64 or 128");
     if (!h) return fail(ML_ERR_ARG, "null handle");
     if (tile_kernel >= 0) {

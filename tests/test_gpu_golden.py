@@ -231,14 +231,16 @@ def test_full_batch_properties(hip_lib, cuda_device):
     out_p, xyzds_p, raw_p = eng.forward_mono(kps[perm].contiguous(), kinv, box_conf=conf[perm].contiguous(), want_raw=True)
     assert torch.equal(raw_p, raw[perm]) and torch.equal(xyzds_p, xyzds[perm])
     assert torch.equal(out_p.nan_to_num(), out[perm].nan_to_num())
-    sub = slice(12345, 12345 + 2777)   # > ML_SMALL_ROWS: same tile kernel, so the same bits
+    sub = slice(12345, 12345 + 9777)   # beyond the mid-size window (8192 rows): same tile kernels, so the same bits
     out_s, xyzds_s, raw_s = eng.forward_mono(kps[sub].contiguous(), kinv, box_conf=conf[sub].contiguous(), want_raw=True)
     assert torch.equal(raw_s, raw[sub]) and torch.equal(xyzds_s, xyzds[sub])
-    # a single image's worth of rows takes dense_small_kernel: same arithmetic, another fp32 summation order
-    sub = slice(4321, 4321 + 777)
-    out_s, xyzds_s, raw_s = eng.forward_mono(kps[sub].contiguous(), kinv, box_conf=conf[sub].contiguous(), want_raw=True)
-    assert (raw_s - raw[sub]).abs().max().item() <= 2e-6 * max(1.0, raw.abs().max().item())
-    assert (xyzds_s - xyzds[sub]).abs().max().item() <= 5e-5  # a few fp32 ulps at 20-60 m
+    # a video batch takes dense_mid_kernel, a single image's worth of rows dense_small_kernel: same arithmetic, another fp32
+    # summation order
+    for lo, n in ((20000, 2777), (4321, 777), (4321, 300)):
+        sub = slice(lo, lo + n)
+        out_s, xyzds_s, raw_s = eng.forward_mono(kps[sub].contiguous(), kinv, box_conf=conf[sub].contiguous(), want_raw=True)
+        assert (raw_s - raw[sub]).abs().max().item() <= 2e-6 * max(1.0, raw.abs().max().item()), n
+        assert (xyzds_s - xyzds[sub]).abs().max().item() <= 5e-5, n  # a few fp32 ulps at 20-60 m
     # idempotence: same input, same bits
     out2, xyzds2, _ = eng.forward_mono(kps, kinv, box_conf=conf)
     assert torch.equal(xyzds2, xyzds)
@@ -412,6 +414,7 @@ def test_million_rows_addressing(hip_lib, cuda_device):
     kps += (torch.arange(m, device=cuda_device).view(-1, 1, 1) % 97).float() * 0.01   # every row distinct
     out, xyzds, raw = eng.forward_mono(kps, kinv, want_raw=True)
     assert torch.isfinite(raw).all()
+    eng.set_tuning(mid_rows=0)      # the 2999-row reference batches on the tile kernels too
     for lo in (0, m // 2 + 12345, m - 3000):
         sub = slice(lo, lo + 2999)
         _, xyzds_s, raw_s = eng.forward_mono(kps[sub].contiguous(), kinv, want_raw=True)

@@ -70,7 +70,7 @@ def test_mid_path_matches_tile_path(hip_lib, cuda_device, m, mode):
     raw_tile = eng.forward_raw(x).cpu()
     raws = {}
     for tile in (0, 64, 128):
-        eng.set_tuning(mid_rows=12288, mid_tile=tile)      # (the default window ends at 9216 rows)
+        eng.set_tuning(mid_rows=12288, mid_tile=tile)      # (the default window ends at 8192 rows)
         raws[tile] = eng.forward_raw(x).cpu()
     ref64 = O.loco_forward(sd, x.cpu(), dtype=torch.float64)
     scale = max(1.0, ref64.abs().max().item())
@@ -88,7 +88,7 @@ def test_mid_path_pipeline_and_mc_dropout(hip_lib, cuda_device):
     sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(6).items()}
     kps = torch.tensor(synth.make_poses(5000, 3)).to(cuda_device)
     kinv = engine.inverse_intrinsics(synth.KITTI_K)
-    eng = engine.LocoEngine(sd, device=cuda_device)           # 5000 rows: inside the default window (512, 9216]
+    eng = engine.LocoEngine(sd, device=cuda_device)           # 5000 rows: inside the default window (512, 8192]
     out_mid, xyzds_mid, raw_mid = [t.clone() for t in eng.forward_mono(kps, kinv, want_raw=True)]
     eng.set_tuning(mid_rows=0)
     out_tile, xyzds_tile, raw_tile = eng.forward_mono(kps, kinv, want_raw=True)
