@@ -9,7 +9,7 @@
 // hi*lo + lo*hi + hi*hi in fp32, A operand = weights so that a lane ends up with 4 consecutive n of one person).
 //
 //   grid    (N/128) * (M_pad/TM) workgroups, numbered so that the 8 column tiles of a row panel land on ONE XCD (its L2
-//           then serves the activation panel 8 times); >= 2 workgroups per CU from 4096 rows (TM = 64) / 8192 rows (128)
+//           then serves the activation panel 8 times); TM = 64 while the 128-row tiles are fewer than the CUs (< 4096 rows at N = 1024)
 //   stage   one k32 line per row: 128 W rows + TM X rows = 24 / 32 KiB; 2 stages in LDS, chunk ^= (row>>1)&7 as in
 //           dense_kernel.h (conflict-free ds_read_b128 fragment reads)
 //   loader  register-staged: every thread moves 4 (W) + TM/32 (X) 16-byte chunks per step, global -> VGPR two steps
@@ -145,9 +145,16 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
     __syncthreads();
 
     // step i: LDS stage i&1 holds k-step i; the set named `nxt` holds step i+1 (requested two steps ago), the other set
-    // step i+2 (requested one step ago, stays in flight across the wait).  (Measured against a variant with the barrier in
-    // the middle of the step's MFMAs and the next step's first fragments requested right behind it: that one is 4 % slower
-    // -- 271 vs 259 us per 4096-row forward, 422 vs 406 at 8192 -- the resident workgroups already interleave.)
+    // step i+2 (requested one step ago, stays in flight across the wait).  Schedules measured against this one (us per forward
+    // at 4096 / 8192 rows, 128-row tiles; this one: 256-259 / 403-406):
+    //   * the barrier in the middle of the step's MFMAs, the next step's first fragments requested right behind it: 271 / 422;
+    //   * the loader without a branch (the `if (i + 1 < nk)` below makes hipcc's own waitcnt insertion drain ALL requests,
+    //     vmcnt(0), before every second LDS store; branch-free it waits for exactly the set it stores, vmcnt(8)): 256 / 428 --
+    //     no gain with one workgroup per CU, a loss with two;
+    //   * three register sets (requests three steps ahead), loader unconditional, MFMAs of padded steps skipped: 267 / 425.
+    // With two workgroups per CU the kernel is bound by the LDS pipe both of them feed through (reads + writes = the 768 MFMA
+    // cycles of a step at 128 B/clk; profiles/r03_mid_pmc_rows8192.txt: matrix pipe 39-44 % busy, 16 % of the wave cycles waiting on
+    // LDS, 3.5 % bank conflicts), not by request latency.
     auto step = [&](Raw& nxt, int i) {
         const int s = i & 1;
         Frag f0, f1;

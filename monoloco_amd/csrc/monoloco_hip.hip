@@ -152,7 +152,7 @@ struct Head {
 //   (Infinity-Cache residency experiment, off by default); tile_kernel 4 = dense_kernel_w4 for the long-K layers +
 //   dense_kernel_pp for the input / fused-head layers, 2 = dense_kernel_pp everywhere; tile_all: dense_kernel_w4 wherever it runs;
 //   small_rows < rows <= mid_rows take dense_mid_kernel (128 x 64 / 128 x 128 tiles: the 256x256 tiles are fewer than the CUs
-//   there), mid_tile 64 | 128 forces its tile height (0 = 64 while that leaves < 2 of the 128-row tiles per CU).
+//   there), mid_tile 64 | 128 forces its tile height (0 = 64 while the 128-row tiles are fewer than the CUs).
 struct Tuning {
     int small_rows = 512, small32_rows = 128, chunk_rows = 0;
     int tile_kernel = 4, tile_all = 0;
@@ -471,7 +471,7 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
     if (mid) {  // the caller chose the mid-size path (no fused heads there)
         if (head_nh != 0 || p.N % mlk::MID_TN != 0) return fail(ML_ERR_STATE, "dense_mid_kernel: no fused head, N %% 128 == 0");
         const int tiles128 = (p.M_pad / 128) * (p.N / mlk::MID_TN);
-        const int tm = tu.mid_tile ? tu.mid_tile : (tiles128 >= 2 * num_cus() ? 128 : 64);
+        const int tm = tu.mid_tile ? tu.mid_tile : (tiles128 >= num_cus() ? 128 : 64);   // (measured: 4096 rows 256 vs 266 us)
         const int tiles = (p.M_pad / tm) * (p.N / mlk::MID_TN);
         const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
 #define ML_MID(NS, RL, RS)                                                                                                  \

@@ -78,7 +78,7 @@ def test_mid_path_matches_tile_path(hip_lib, cuda_device, m, mode):
     for tile, raw in raws.items():
         assert (raw.double() - ref64).abs().max().item() <= 1e-4, tile
         assert (raw - raw_tile).abs().max().item() <= 2e-6 * scale, tile
-    assert torch.equal(raws[0], raws[64 if m < 8192 else 128])      # the automatic choice: 128-row tiles from 2 per CU
+    assert torch.equal(raws[0], raws[64 if m < 4096 else 128])      # the automatic choice: 128-row tiles from one per CU
     eng.close()
 
 
