@@ -41,7 +41,6 @@ struct XGemmParams {
 
 constexpr int XG_BM = 32, XG_BN = 64;
 constexpr int XG_A_BYTES = XG_BM * 128, XG_STAGE = XG_A_BYTES + XG_BN * 128;
-constexpr int XG_PAD = 40960;   // see xgemm_kernel: at most two workgroups per CU
 
 // One k32 step in LDS.  k-contiguous operand: a 128-byte row of 32 fp32 per tile row, its eight 16-byte chunks XOR-swizzled
 // by (row >> 1) & 7 (conflict-free ds_read_b128 for lane -> (row = lane & 31, chunk pair by lane >> 5), conflict-free
@@ -55,15 +54,7 @@ constexpr int XG_PAD = 40960;   // see xgemm_kernel: at most two workgroups per 
 // instruction; profiles/r03_train_kernel_stats_rows331_f16x3_in_registers.txt.)
 template <int ALAY, int BLAY>
 __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
-    // 2 stages + XG_PAD: the padding caps the kernel at TWO workgroups per CU (two waves per SIMD).  With the 24 KiB the stages
-    // need, 4 - 6 workgroups fit a CU, and from the third on MI355X returned wrong tiles: 1 - 8 of the 1024 tiles of a 2048 x
-    // 1024 x 1024 product per run, always among the workgroups dispatched third or fourth to a CU, each with 4 consecutive
-    // accumulator registers (8 rows x 32 columns) of one wave off by O(|A|) from the first k-steps on; 30 of 30 runs, whatever was
-    // added (vmcnt(0) before every LDS store, lgkmcnt(0), a second barrier, a full wait before s_endpgm, the partial tile through
-    // VGPRs), 0 of 30 runs at two workgroups per CU (profiles/r03_xgemm_occupancy.md).  Unexplained; this is the only kernel
-    // here that combines AGPR accumulators with more than two waves per SIMD.  The step's own shapes (<= 1024 rows) never had
-    // more than two workgroups per CU, so its timings do not change.
-    __shared__ __attribute__((aligned(16))) char smem[2 * XG_STAGE + XG_PAD];
+    __shared__ __attribute__((aligned(16))) char smem[2 * XG_STAGE];
     __shared__ double wsum[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,6 +208,11 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
     lstore(R1, 1);
     __syncthreads();
     fragread(F0, 0);
+    // Stage 0 is overwritten by the FIRST step (its LDS store of step 2) and, unlike every later stage hand-over, no step
+    // barrier lies between that store and these reads: without this barrier a wave that was slow to issue them multiplied 8 rows
+    // of step 2's A operand as step 0 -- never with one or two workgroups per CU (the store sits >= 4 MFMAs = 256 cycles behind
+    // the reads), 1 - 8 wrong tiles per 1024 with four (profiles/r03_xgemm_occupancy.md).
+    __syncthreads();
     for (int i = 0; i < nk; i += 4) {   // whole groups of 4 steps (one exit: no register shuffling between the sets)
         step(F0, F1, R1, R2, 0, i);
         step(F1, F0, R2, R3, 1, i + 1);
