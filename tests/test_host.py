@@ -231,3 +231,22 @@ def test_fold_merge_pack_emulated_forward(hip_lib, merge, hidden):
     assert np.abs(raw - ref64['raw'].numpy()).max() <= max(2 * noise, 1e-5)
     assert np.abs(raw - ref['raw'].numpy()).max() <= 5e-5
     hip_lib.ml_loco_destroy(h)
+
+
+def test_epoch_batches_are_the_dataloaders():
+    """Trainer's loader-free epoch sampler: the batches of DataLoader(n rows, batch_size, shuffle=True) -- the reference's loaders,
+    trainer.py:104-106 -- and the same state of torch's global generator afterwards, epoch after epoch; its self-check is what
+    decides at run time whether it is used."""
+    from torch.utils.data import DataLoader
+    from monoloco_amd.train.trainer import _EpochBatches, _IndexDataset
+    for n, bs in ((331, 512), (1056, 64), (169, 512), (7, 3), (1, 1)):
+        fast = _EpochBatches(n, bs)
+        assert fast.matches_dataloader(epochs=3)
+        torch.manual_seed(n)
+        mine = [[b.tolist() for b in fast] for _ in range(2)]
+        state_mine = torch.get_rng_state()
+        torch.manual_seed(n)
+        loader = DataLoader(_IndexDataset(n), batch_size=bs, shuffle=True)
+        ref = [[b.tolist() for b in loader] for _ in range(2)]
+        assert mine == ref and torch.equal(state_mine, torch.get_rng_state())
+        assert sorted(i for b in mine[0] for i in b) == list(range(n))
