@@ -435,7 +435,8 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
                    "trainer_setup_s": round(t_setup, 4), "route": tr2.hip.last_route,
                    "val_d_first_last": [round(tr2.epoch_losses['val']['d'][0], 4), round(tr2.epoch_losses['val']['d'][-1], 4)],
                    "note": "device_call = time inside ml_trainer_step / ml_trainer_eval (each synchronises the stream); the rest "
-                           "is the DataLoader over row numbers, two index_selects per batch and the epoch bookkeeping"}
+                           "is the epoch's row permutation (the draws of the reference's DataLoader, without the loader), one index upload and two "
+                           "index_selects per batch, and the epoch bookkeeping"}
             tr.hip.close()
             tr2.hip.close()
             return res
