@@ -496,14 +496,36 @@ __global__ __launch_bounds__(256) void heads_pair_kernel(const char* __restrict_
                                                          float* __restrict__ xyzds) {
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     float* s_w = (float*)dyn_smem;  // [NH][H] then the aux head's [H]
-    for (int i = threadIdx.x; i < NH * H; i += 256) s_w[i] = w_fin[i];
-    for (int i = threadIdx.x; i < H; i += 256) s_w[NH * H + i] = w_aux[i];
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int npairs = H / 8;
     const int64_t nquads = (m + 3) / 4;
-    for (int64_t qd = (int64_t)blockIdx.x * 4 + wave; qd < nquads; qd += (int64_t)gridDim.x * 4) {
+    // one 8-column group of 4 rows of both sources: 16 independent 16-byte loads per lane
+    struct Rows {
+        half8 hi[4], lo[4], hj[4], lj[4];
+    };
+    auto fetch = [&](Rows& x, int64_t r0, int pr) {
+        const int b = pr >> 2, sub = pr & 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = (r0 + r < m) ? (r0 + r) : (m - 1);
+            const size_t off = (size_t)row * H * 4 + b * LINE + sub * 16;
+            x.hi[r] = *(const half8*)(act_fin + off);
+            x.lo[r] = *(const half8*)(act_fin + off + 64);
+            x.hj[r] = *(const half8*)(act_aux + off);
+            x.lj[r] = *(const half8*)(act_aux + off + 64);
+        }
+    };
+    // the first rows of this wave are requested BEFORE the weights are staged: the two latencies overlap (a workgroup has only
+    // one to a few quads of rows at the mid-size batches, so the staging is not amortised over many)
+    Rows first;
+    const int64_t qd0 = (int64_t)blockIdx.x * 4 + wave;
+    const bool have = qd0 < nquads && lane < npairs;
+    if (have) fetch(first, qd0 * 4, lane);
+    for (int i = threadIdx.x * 4; i < NH * H; i += 1024) *(f32x4*)(s_w + i) = *(const f32x4*)(w_fin + i);
+    for (int i = threadIdx.x * 4; i < H; i += 1024) *(f32x4*)(s_w + NH * H + i) = *(const f32x4*)(w_aux + i);
+    __syncthreads();
+    for (int64_t qd = qd0; qd < nquads; qd += (int64_t)gridDim.x * 4) {
         const int64_t r0 = qd * 4;
         float acc[4][NH + 1];
 #pragma unroll
@@ -513,19 +535,17 @@ __global__ __launch_bounds__(256) void heads_pair_kernel(const char* __restrict_
         for (int pr = lane; pr < npairs; pr += 64) {
             const int b = pr >> 2, sub = pr & 3;
             const int n = b * 32 + sub * 8;
+            Rows x;
+            if (qd == qd0 && pr == lane) x = first;
+            else fetch(x, r0, pr);
             float xv[4][8], xa[4][8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = (r0 + r < m) ? (r0 + r) : (m - 1);
-                const size_t off = (size_t)row * H * 4 + b * LINE + sub * 16;
-                const half8 hi = *(const half8*)(act_fin + off), lo = *(const half8*)(act_fin + off + 64);
-                const half8 hj = *(const half8*)(act_aux + off), lj = *(const half8*)(act_aux + off + 64);
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    xv[r][e] = (float)hi[e] + (float)lo[e];
-                    xa[r][e] = (float)hj[e] + (float)lj[e];
+                    xv[r][e] = (float)x.hi[r][e] + (float)x.lo[r][e];
+                    xa[r][e] = (float)x.hj[r][e] + (float)x.lj[r][e];
                 }
-            }
 #pragma unroll
             for (int o = 0; o <= NH; ++o) {
                 const f32x4 wa = *(const f32x4*)(s_w + o * H + n);

@@ -422,7 +422,8 @@ int next_red_slot(ml_trainer* t, hipStream_t) {
 
 // slot >= 0: the Linear is an H x H one on the fast path: dz also goes to lbufs[0] / tl_dz as scaled lines, dW runs there;
 // slot == -2: the (narrow) input layer
-int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, float* xhat, int slot = -1) {
+// din: where the incoming gradient lies when it is not dout itself (fused chain only: dz is written to dout, din stays intact)
+int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, float* xhat, int slot = -1, const float* din = nullptr) {
     const int H = t->H;
     float* mean = t->bn_mean + (size_t)b.bn_idx * H;
     float* inv = t->bn_invstd + (size_t)b.bn_idx * H;
@@ -436,12 +437,13 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
         if (gy < 1) gy = 1;
         if ((rc = next_red_slot(t, st))) return rc;
         double* s_dy = t->d_red;
-        hipLaunchKernelGGL(mlt::bwd_stats_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, (const float*)dout, (const float*)b.z, m, H,
+        const float* src = din ? din : dout;
+        hipLaunchKernelGGL(mlt::bwd_stats_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, src, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
                            (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, s_dy, s_dy + H);
         if ((rc = next_red_slot(t, st))) return rc;
         double* s_dz = t->d_red;
-        hipLaunchKernelGGL(mlt::bn_bwd_fused_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, dout, (const float*)b.z, m, H,
+        hipLaunchKernelGGL(mlt::bn_bwd_fused_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, dout, src, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
                            (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, (const double*)s_dy,
                            (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz,
@@ -456,6 +458,7 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
             return skinny_dw(t, st, b.x, b.in_dim, b.in_dim, dout, m, G(t, b.lin + ".weight"), 1);
         return linear_bwd_weight(t, st, dout, H, b.x, b.in_dim, G(t, b.lin + ".weight"), (int)m, H, b.in_dim);
     }
+    if (din && din != dout) T_TRY(hipMemcpyAsync(dout, din, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));   // (unfused chain: in place)
     hipLaunchKernelGGL(mlt::relu_drop_bwd_kernel, dim3(nblk(m * H)), dim3(256), 0, st, dout, (const float*)b.z, m, H,
                        (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
                        (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, xhat);
@@ -1186,8 +1189,8 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     if (rc) return rc;
     // residual stages, last to first:  a_{s+1} = a_s + B(A(a_s))
     for (int s = S - 1; s >= 0; --s) {
-        T_TRY(hipMemcpyAsync(gB, gA, (size_t)m * H * 4, hipMemcpyDeviceToDevice, st));                          // gB = d r_s
-        if ((rc = block_bwd(t, st, sb[s], m, gB, xhat, fast ? 2 * s + 1 : -1))) return rc;                       // gB = dz_b
+        // gB = dz_b from gA = d a_{s+1} (which stays: the skip connection adds to it below)
+        if ((rc = block_bwd(t, st, sb[s], m, gB, xhat, fast ? 2 * s + 1 : -1, gA))) return rc;
         if (fast) {   // gB's fp32 dz_b has been consumed (dW) and its lines feed the GEMM: d t_s lands in gB directly
             if ((rc = fast_linear_bwd_data(t, st, dzl, sb[s].lin, gB, m, 2 * s + 1, false))) return rc;
         } else {

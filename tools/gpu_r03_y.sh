@@ -1,0 +1,6 @@
+# round 3, GPU call Y: heads_pair prefetch, out-of-place BN backward (no 268 MB copies), training tests, 65536-row step time
+O=$GRAFT_REPO_ROOT/gpurun_out/r03y; mkdir -p $O; cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_mid.py tests/test_gpu_train.py tests/test_gpu_train_mid.py tests/test_gpu_headline.py -q -m gpu --timeout 600 > $O/pytest.txt 2>&1; echo "pytest rc $?"
+tail -4 $O/pytest.txt | cut -c1-200
+timeout 300 python tools/mid_sweep.py 2048 4096 8192 > $O/sweep.txt 2>&1; cat $O/sweep.txt
+timeout 300 python tools/bench_train.py --steps 10 --cpu-seconds 0.1 2>/dev/null | cut -c1-400
