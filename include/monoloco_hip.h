@@ -268,9 +268,10 @@ int ml_trainer_eval(ml_trainer* t, const float* x_dev, const float* labels_dev, 
 int ml_trainer_snapshot(ml_trainer* t, void* stream);
 int ml_trainer_restore(ml_trainer* t, void* stream);
 /* Per-handle tuning of the mid route, same results: apply_cols = columns per workgroup of the column-owner kernels (4, 8 or 16;
- * default 8; 0 leaves it); side_stream = 1: the weight-gradient GEMMs, which only the optimizer needs, run on an internal side
- * stream beside the data-gradient chain (events both ways; measured to pay from ~2000 rows), 0 (default): everything on the
- * caller's stream; < 0 leaves it. */
+ * default 8; 0 leaves it); side_stream: 0 (default) = everything on the caller's stream, the data gradient and the weight
+ * gradient of a Linear in ONE launch (xgemm_pair_kernel); 1 = the weight-gradient GEMMs, which only the optimizer needs, on an
+ * internal side stream beside the data-gradient chain (events both ways; measured to pay from ~2000 rows); 2 = two launches per
+ * Linear on the caller's stream (the A/B reference of 0); < 0 leaves it. */
 int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream);
 int ml_trainer_destroy(ml_trainer* t);
 const char* ml_train_last_error(void);

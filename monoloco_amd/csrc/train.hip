@@ -110,6 +110,7 @@ struct ml_trainer {
     int side_stream = 0;             // ml_trainer_set_tuning: 1 = weight gradients on the side stream (measured: pays from ~2000 rows)
     int ssq_per_mat = 0;
     int apply_cols = 8;              // columns a workgroup of the column-owner kernels takes (4 | 8 | 16): ml_trainer_set_tuning
+    int pair_gemm = 1;               // both gradients of a Linear in one launch (xgemm_pair_kernel); side_stream = 2 turns it off
     double* h_loss = nullptr;        // pinned: up to HL_GRID x LOSS_NV partial sums
     double* d_lpart = nullptr;       // the same on the device (heads_loss_kernel)
     float* w_snap = nullptr;         // ml_trainer_snapshot: parameters + running statistics kept on the device (best epoch)
@@ -589,6 +590,21 @@ int launch_xgemm(hipStream_t st, const float* a, long lda, int alay, const float
     return 0;
 }
 
+// dx = dz . W (+ res) and dW = dz^T . x in one launch (xgemm_pair_kernel)
+int launch_xgemm_pair(hipStream_t st, const float* dz, const float* w, float* dx, const float* res, const float* x, float* dw,
+                      double* sumsq, int m, int H) {
+    mlt::XGemmParams pd, pw;
+    pd.a = dz; pd.b = w; pd.c = dx; pd.res = res; pd.bias = nullptr; pd.sumsq = nullptr;
+    pd.lda = H; pd.ldb = H; pd.ldc = H; pd.M = m; pd.N = H; pd.K = H;
+    pw.a = dz; pw.b = x; pw.c = dw; pw.res = nullptr; pw.bias = nullptr; pw.sumsq = sumsq;
+    pw.lda = H; pw.ldb = H; pw.ldc = H; pw.M = H; pw.N = H; pw.K = m;
+    const int ndx = H / mlt::XG_BN, nd = ndx * ((m + mlt::XG_BM - 1) / mlt::XG_BM);
+    const int nwx = H / mlt::XG_BN, nw = nwx * (H / mlt::XG_BM);
+    hipLaunchKernelGGL(mlt::xgemm_pair_kernel, dim3(nd + nw), dim3(256), 0, st, pd, pw, nd, ndx, nwx);
+    if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "xgemm pair launch failed");
+    return 0;
+}
+
 template <typename P>
 void launch_fwd_apply(const ml_trainer* t, hipStream_t st, const P& p) {
     const dim3 blk(256);
@@ -771,25 +787,32 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     auto dgrad = [&](const float* dz, const std::string& lin, float* dx, const float* res) {
         return launch_xgemm(st, dz, H, 0, P(t, lin + ".weight"), H, 1, dx, H, (int)m, H, H, nullptr, res, nullptr);
     };
+    // both gradients of one Linear: one launch on the main stream (xgemm_pair_kernel), or the two of them with the weight
+    // gradient on the side stream
+    auto grads = [&](const float* dz, const float* x, const std::string& lin, int slot, float* dx, const float* res) {
+        if (!side && t->pair_gemm) {
+            ++nlin;
+            return launch_xgemm_pair(st, dz, P(t, lin + ".weight"), dx, res, x, G(t, lin + ".weight"),
+                                     t->d_ssq + (size_t)slot * t->ssq_per_mat, (int)m, H);
+        }
+        const int r = wgrad(dz, x, lin, slot);
+        return r ? r : dgrad(dz, lin, dx, res);
+    };
     // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
     float* gB = next_dz();
     bwd_apply(nullptr, true, false, z3, "batch_norm3", 2 * S + 1, 2 * S + 1, "w3", gB, 1);                        // gB = dz3
-    if ((rc = wgrad(gB, y2, "w3", 2 * S + 1))) return rc;
-    if ((rc = dgrad(gB, "w3", gA, nullptr))) return rc;                                                          // gA = dy2 (w3 part)
+    if ((rc = grads(gB, y2, "w3", 2 * S + 1, gA, nullptr))) return rc;                                           // gA = dy2 (w3 part)
     gB = next_dz();
     bwd_apply(gA, false, true, nullptr, "", 0, 0, "w2", gB, 2);                                                  // gB = dz2 = dy2 + daux (x) w_aux
-    if ((rc = wgrad(gB, a[S], "w2", 2 * S))) return rc;
-    if ((rc = dgrad(gB, "w2", gA, nullptr))) return rc;                                                          // gA = da_S
+    if ((rc = grads(gB, a[S], "w2", 2 * S, gA, nullptr))) return rc;                                             // gA = da_S
     for (int s = S - 1; s >= 0; --s) {   // a_{s+1} = a_s + B(A(a_s))
         const std::string p = "linear_stages." + std::to_string(s) + ".";
         gB = next_dz();
         bwd_apply(gA, false, false, zb[s], p + "batch_norm2", 2 + 2 * s, 2 + 2 * s, p + "w2", gB, 0);              // gB = dz_b
-        if ((rc = wgrad(gB, tt[s], p + "w2", 2 * s + 1))) return rc;
-        if ((rc = dgrad(gB, p + "w2", gE, nullptr))) return rc;                                                   // gE = d t_s
+        if ((rc = grads(gB, tt[s], p + "w2", 2 * s + 1, gE, nullptr))) return rc;                                 // gE = d t_s
         gB = next_dz();
         bwd_apply(gE, false, false, za[s], p + "batch_norm1", 1 + 2 * s, 1 + 2 * s, p + "w1", gB, 0);              // gB = dz_a
-        if ((rc = wgrad(gB, a[s], p + "w1", 2 * s))) return rc;
-        if ((rc = dgrad(gB, p + "w1", gA, gA))) return rc;                                                        // gA = da_s = da_{s+1} + dz_a . W
+        if ((rc = grads(gB, a[s], p + "w1", 2 * s, gA, gA))) return rc;                                           // gA = da_s = da_{s+1} + dz_a . W
     }
     gB = next_dz();
     bwd_apply(gA, false, false, z0, "batch_norm1", 0, 0, "w1", gB, 0);                                            // gB = dz0
@@ -1046,7 +1069,10 @@ int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream) {
     if (!t || (apply_cols != 0 && apply_cols != 4 && apply_cols != 8 && apply_cols != 16))
         return tfail(ML_ERR_ARG, "apply_cols must be 4, 8 or 16 (0: unchanged)");
     if (apply_cols) t->apply_cols = apply_cols;
-    if (side_stream >= 0) t->side_stream = side_stream ? 1 : 0;
+    if (side_stream >= 0) {   // 0: both gradients of a Linear in one launch (default); 1: weight gradients on the side stream; 2: two launches
+        t->side_stream = side_stream == 1 ? 1 : 0;
+        t->pair_gemm = side_stream == 0 ? 1 : 0;
+    }
     return ML_OK;
 }
 

@@ -34,7 +34,7 @@ struct XGemmParams {
     float* c;            // C(i, j) = sum_k A(i, k) B(j, k), row stride ldc
     const float* res;    // optional [M][N] (stride ldc) added to the result; may alias c
     const float* bias;   // optional [N]
-    double* sumsq;       // optional: sum of squares of this workgroup's part of C -> sumsq[blockIdx.y * gridDim.x + blockIdx.x]
+    double* sumsq;       // optional: sum of squares of this workgroup's part of C -> sumsq[row tile * (N / 64) + column tile]
     long lda, ldb, ldc;
     int M, N, K;         // N % 64 == 0; rows beyond M are clamped on load and never stored
 };
@@ -52,14 +52,12 @@ constexpr int XG_A_BYTES = XG_BM * 128, XG_STAGE = XG_A_BYTES + XG_BN * 128;
 // lane holds per operand ARE the A / B register of v_mfma_f32_32x32x16_f16 for its k16 half -- at 20.0 us per 331 x 1024 x 1024
 // product against 15.7 us for this kernel: 40 conversion instructions per wave and k-step cost more than the 16 x slower matrix
 // instruction; profiles/r03_train_kernel_stats_rows331_f16x3_in_registers.txt.)
+// (the kernel body: tile (bx, by) of a problem with nbx column tiles; smem = 2 stages, wsum = 4 doubles of LDS)
 template <int ALAY, int BLAY>
-__global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * XG_STAGE];
-    __shared__ double wsum[4];
+__device__ __forceinline__ void xgemm_tile(const XGemmParams& p, int bx, int by, int nbx, char* smem, double* wsum) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tn = w & 1, wk = w >> 1;
-    const int bx = blockIdx.x, by = blockIdx.y;
     const int m0 = by * XG_BM, n0 = bx * XG_BN;
     const int nk = (p.K + 31) / 32, last = nk - 1;
     // position i of the k loop -> k-step (positions past the end repeat the final one)
@@ -253,8 +251,27 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
         for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
         if (lane == 0) wsum[w] = ss;
         __syncthreads();
-        if (tid == 0) p.sumsq[(size_t)by * gridDim.x + bx] = wsum[0] + wsum[1];
+        if (tid == 0) p.sumsq[(size_t)by * nbx + bx] = wsum[0] + wsum[1];
     }
+}
+
+template <int ALAY, int BLAY>
+__global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * XG_STAGE];
+    __shared__ double wsum[4];
+    xgemm_tile<ALAY, BLAY>(p, blockIdx.x, blockIdx.y, gridDim.x, smem, wsum);
+}
+
+// The two products that read the same dz -- the data gradient dx = dz . W (+ res) (k-contiguous x reduction-major) and the
+// weight gradient dW = dz^T . x (both reduction-major) -- in ONE launch: workgroups [0, nd) are the data gradient's tiles
+// (dispatched first: 64 k-steps each at hidden 1024 against 11 at 331 rows), the rest the weight gradient's.  One kernel floor
+// (~4.5 us) instead of two per Linear, and the chip sees 176 + 512 workgroups at once instead of 176, then 512.
+__global__ __launch_bounds__(256) void xgemm_pair_kernel(XGemmParams pd, XGemmParams pw, int nd, int ndx, int nwx) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * XG_STAGE];
+    __shared__ double wsum[4];
+    const int id = blockIdx.x;   // (uniform)
+    if (id < nd) xgemm_tile<0, 1>(pd, id % ndx, id / ndx, ndx, smem, wsum);
+    else xgemm_tile<1, 1>(pw, (id - nd) % nwx, (id - nd) / nwx, nwx, smem, wsum);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -154,6 +154,17 @@ def test_mid_route_after_reload_and_route_switches(hip_lib, cuda_device):
     for cols in (4, 8):
         assert abs(outs[cols][0] - outs[16][0]) <= 1e-6 * abs(outs[16][0])
         assert (outs[cols][1] - outs[16][1]).abs().max().item() <= 1e-5 * outs[16][1].abs().max().item()
+    # both gradients of a Linear in one launch (the default) / in two launches / with the side stream: the same tiles, the same bits
+    per_mode = {}
+    for mode in (0, 1, 2):
+        fresh = HipTrainer(sd1, p_dropout=0.2, lr=0.001, device=cuda_device, route='mid', seed=5)
+        check(hip_lib.ml_trainer_set_tuning(fresh._h, 0, mode), train=True)
+        r = fresh.step(x, y, update=False)
+        per_mode[mode] = (r['loss'], fresh.grads())
+        fresh.close()
+    for mode in (1, 2):
+        assert per_mode[mode][0] == per_mode[0][0]
+        assert all(torch.equal(per_mode[mode][1][k], per_mode[0][1][k]) for k in per_mode[0][1]), mode
     fresh = HipTrainer(sd1, p_dropout=0.0, lr=0.001, device=cuda_device, route='mid')
     b = fresh.step(x, y, update=False)
     gb = fresh.grads()

@@ -46,19 +46,21 @@ def timing():
         xb, yb = synth.big_train_batch(g['mono_x'], g['mono_y'], m, 3)
         x, y = torch.tensor(xb).to(dev), torch.tensor(yb).to(dev)
         out = {}
-        for name in ('exact', 'mid', 'mid1s', 'fast'):
+        for name in ('exact', 'mid', 'mid1s', 'mid2l', 'fast'):
             tr = HipTrainer(sd, p_dropout=0.2, lr=0.001, device=dev, route=name[:3] if name.startswith('mid') else name)
             from monoloco_amd import _lib
             if name == 'mid1s':
                 _lib.check(_lib.load().ml_trainer_set_tuning(tr._h, 0, 1), train=True)
+            if name == 'mid2l':
+                _lib.check(_lib.load().ml_trainer_set_tuning(tr._h, 0, 2), train=True)
             for _ in range(5): tr.step(x, y)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             n = 30
             for _ in range(n): tr.step(x, y)
             torch.cuda.synchronize(); out[name] = (time.perf_counter() - t0) / n * 1e3
             tr.close()
-        print('rows %5d: exact %.3f ms  mid %.3f ms (with the side stream %.3f)  fast %.3f ms' % (
-            m, out['exact'], out['mid'], out['mid1s'], out['fast']), flush=True)
+        print('rows %5d: exact %.3f ms  mid %.3f ms (two launches per Linear %.3f, with the side stream %.3f)  fast %.3f ms' % (
+            m, out['exact'], out['mid'], out['mid2l'], out['mid1s'], out['fast']), flush=True)
 
 
 if __name__ == '__main__':
