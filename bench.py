@@ -370,7 +370,7 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         g = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_train_inputs.npz'))
         res = {"config": "BASELINE configs[4]: LocoModel 34->1024->9 train-mode fwd + MultiTaskLoss + bwd + clip + Adam, "
                          "dropout 0.2; fp32 tensors.  Below 4096 rows the mid route (monoloco_amd/csrc/train_mid.h): every GEMM "
-                         "on the exact fp32 MFMA reading the row-major tensors as they lie, ~50 launches per step -> fraction of "
+                         "on the exact fp32 MFMA reading the row-major tensors as they lie, 42 launches per step -> fraction of "
                          "the 157 TF fp32-MFMA peak.  From 4096 rows the hidden-layer GEMMs run on the 3-product fp16 MFMA "
                          "kernel (fp32-class accuracy): fraction of the 833 TF (2500 / 3) a 3-product scheme can reach"}
         sd_t = {k: torch.tensor(v) for k, v in synth.make_state_dict(31, 34, 9, 1024).items()}
