@@ -181,9 +181,11 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
                          const float* box_conf_dev, float* raw_dev, float* out_dev,
                          float* xyzds_dev, void* stream);
 /* One image in one call (what the reference's Loco.forward + the geometry of post_process do per frame, net.py:83-133,
- * 195-215): kps_host (m,3,17) PINNED host memory -> kps_dev (async copy), the pipeline above into buf_dev = [packed (m,16) |
- * post-process geometry (m,12)] (one allocation of m * 28 floats), one copy of that into out_host (pinned), one stream
- * synchronisation.  xyzds_dev (m,5) or NULL. */
+ * 195-215): kps_host (m,3,17) and out_host (m * 28 floats = [packed (m,16) | post-process geometry (m,12)]) are PINNED,
+ * device-mapped host memory (hipHostMalloc / torch pin_memory: the pointers are dereferenced by kernels); one stream
+ * synchronisation inside.  Up to 128 persons no copy operation is issued at all (the first kernel reads the keypoints over the
+ * link, the last one writes both blocks into out_host); beyond that kps_dev (m,3,17) and buf_dev (m * 28 floats) stage the
+ * transfers.  xyzds_dev (m,5) or NULL. */
 int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float* kinv_host, float* kps_dev, float* buf_dev,
                        float* xyzds_dev, float* out_host, void* stream);
 /* stereo (net.py:112-122, process.py:307-327): all left x right pairs, per-left arg-max of the

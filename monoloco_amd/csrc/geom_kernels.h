@@ -436,12 +436,58 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ raw
     post_person(r, out_f, i, centre, ki, box_conf, out, xyzds);
 }
 
+// The per-person geometry block of Loco.post_process (net.py:195-215), out[i] = { uv_shoulder(2), uv_head(2), uv_center(2),
+// xy_center(3) = pixel_to_camera(uv_center, K, 1), xyz_pred(3) = xyz_from_distance(dd, xy_center) } (12 floats): same arithmetic,
+// in the same order, as keypoints_kernel / pix2cam_kernel / xyz_from_distance_kernel (geom_ops.h).
+constexpr int POSTGEO_STRIDE = 12;
+__device__ __forceinline__ void post_geometry_person(const float* __restrict__ kps, int64_t i, const Kinv& ki, float dd,
+                                                     float* __restrict__ out) {
+    const float* u = kps + i * KPS_ROW;
+    const float* v = u + NKP;
+    float* o = out + i * POSTGEO_STRIDE;
+    float su = 0.f, sv = 0.f;
+    for (int j = 5; j < 7; ++j) {
+        su = __fadd_rn(su, u[j]);
+        sv = __fadd_rn(sv, v[j]);
+    }
+    o[0] = su / 2.0f;
+    o[1] = sv / 2.0f;
+    su = 0.f;
+    sv = 0.f;
+    for (int j = 0; j < 5; ++j) {
+        su = __fadd_rn(su, u[j]);
+        sv = __fadd_rn(sv, v[j]);
+    }
+    o[2] = su / 5.0f;
+    o[3] = sv / 5.0f;
+    float umin = u[0], umax = u[0], vmin = v[0], vmax = v[0];
+    for (int j = 1; j < NKP; ++j) {
+        umin = __builtin_fminf(umin, u[j]);
+        umax = __builtin_fmaxf(umax, u[j]);
+        vmin = __builtin_fminf(vmin, v[j]);
+        vmax = __builtin_fmaxf(vmax, v[j]);
+    }
+    const float uc = __fadd_rn(__fmul_rn(__fsub_rn(umax, umin), 0.5f), umin);
+    const float vc = __fadd_rn(__fmul_rn(__fsub_rn(vmax, vmin), 0.5f), vmin);
+    o[4] = uc;
+    o[5] = vc;
+    const float cx = cam_row(uc, vc, ki.k + 0, 1.0f), cy = cam_row(uc, vc, ki.k + 3, 1.0f), cz = cam_row(uc, vc, ki.k + 6, 1.0f);
+    o[6] = cx;
+    o[7] = cy;
+    o[8] = cz;
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(1.0f, __fmul_rn(cx, cx)), __fmul_rn(cy, cy)));
+    o[9] = __fmul_rn(cx, dd) / nrm;
+    o[10] = __fmul_rn(cy, dd) / nrm;
+    o[11] = __fmul_rn(cz, dd) / nrm;
+}
+
 // post_out != null: the row is post-processed here as well (post_person by thread 0: a single image's forward ends in this
-// launch); raw may then be null.
+// launch); raw may then be null.  geo_out != null (with post_out): + the post_process geometry of the row (thread 64).
 __global__ __launch_bounds__(256) void heads_small_kernel(SmallHeads hp, int H, float* __restrict__ raw, int raw_stride,
                                                           int64_t m, const float* __restrict__ centre, Kinv ki,
                                                           const float* __restrict__ box_conf, float* __restrict__ post_out,
-                                                          float* __restrict__ xyzds) {
+                                                          float* __restrict__ xyzds, const float* __restrict__ geo_kps,
+                                                          float* __restrict__ geo_out) {
     __shared__ float srow[16];
     const int64_t row = blockIdx.x;
     if (row >= m) return;
@@ -478,6 +524,9 @@ __global__ __launch_bounds__(256) void heads_small_kernel(SmallHeads hp, int H, 
     if (post_out) {
         __syncthreads();
         if (threadIdx.x == 0) post_person((const float*)srow, raw_stride, row, centre, ki, box_conf, post_out, xyzds);
+        // geo_out != null: the geometry block post_process needs (distance = raw column 2, what post_person calls d) as well:
+        // a frame then ends in this launch, and both blocks may lie in pinned host memory (ml_loco_frame_mono)
+        if (geo_out && threadIdx.x == 64) post_geometry_person(geo_kps, row, ki, srow[2], geo_out);
     }
 }
 

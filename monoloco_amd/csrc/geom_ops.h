@@ -106,50 +106,12 @@ __global__ __launch_bounds__(256) void back_correct_kernel(const float* __restri
 //   out[i] = { uv_shoulder(2), uv_head(2), uv_center(2), xy_center(3) = pixel_to_camera(uv_center, K, 1),
 //              xyz_pred(3) = xyz_from_distance(d[i], xy_center) }      (12 floats)
 // Same arithmetic, in the same order, as keypoints_kernel / pix2cam_kernel / xyz_from_distance_kernel.
-constexpr int POSTGEO_STRIDE = 12;
 __global__ __launch_bounds__(256) void post_geometry_kernel(const float* __restrict__ kps, int64_t m, Kinv ki,
                                                             const float* __restrict__ d, int64_t d_stride,
                                                             float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
-    const float* u = kps + i * KPS_ROW;
-    const float* v = u + NKP;
-    float* o = out + i * POSTGEO_STRIDE;
-    float su = 0.f, sv = 0.f;
-    for (int j = 5; j < 7; ++j) {
-        su = __fadd_rn(su, u[j]);
-        sv = __fadd_rn(sv, v[j]);
-    }
-    o[0] = su / 2.0f;
-    o[1] = sv / 2.0f;
-    su = 0.f;
-    sv = 0.f;
-    for (int j = 0; j < 5; ++j) {
-        su = __fadd_rn(su, u[j]);
-        sv = __fadd_rn(sv, v[j]);
-    }
-    o[2] = su / 5.0f;
-    o[3] = sv / 5.0f;
-    float umin = u[0], umax = u[0], vmin = v[0], vmax = v[0];
-    for (int j = 1; j < NKP; ++j) {
-        umin = __builtin_fminf(umin, u[j]);
-        umax = __builtin_fmaxf(umax, u[j]);
-        vmin = __builtin_fminf(vmin, v[j]);
-        vmax = __builtin_fmaxf(vmax, v[j]);
-    }
-    const float uc = __fadd_rn(__fmul_rn(__fsub_rn(umax, umin), 0.5f), umin);
-    const float vc = __fadd_rn(__fmul_rn(__fsub_rn(vmax, vmin), 0.5f), vmin);
-    o[4] = uc;
-    o[5] = vc;
-    const float cx = cam_row(uc, vc, ki.k + 0, 1.0f), cy = cam_row(uc, vc, ki.k + 3, 1.0f), cz = cam_row(uc, vc, ki.k + 6, 1.0f);
-    o[6] = cx;
-    o[7] = cy;
-    o[8] = cz;
-    const float dd = d ? d[i * d_stride] : 0.0f;
-    const float nrm = sqrtf(__fadd_rn(__fadd_rn(1.0f, __fmul_rn(cx, cx)), __fmul_rn(cy, cy)));
-    o[9] = __fmul_rn(cx, dd) / nrm;
-    o[10] = __fmul_rn(cy, dd) / nrm;
-    o[11] = __fmul_rn(cz, dd) / nrm;
+    post_geometry_person(kps, i, ki, d ? d[i * d_stride] : 0.0f, out);
 }
 
 }  // namespace mlk

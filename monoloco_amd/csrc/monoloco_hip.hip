@@ -658,6 +658,11 @@ struct TailMono {
     float* xyzds;
     float* raw;   // the caller's raw buffer, or null (then the raw rows never leave the registers)
     bool done = false;
+    // optional: the post_process geometry block (ml_post_geometry) of every row from these keypoints into geo_out, in the same
+    // launch as the post-process when a single image's forward ends in one (geo_done says whether that happened)
+    const float* geo_kps = nullptr;
+    float* geo_out = nullptr;
+    bool geo_done = false;
 };
 
 int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass mc = McPass(), TailMono* tail = nullptr) {
@@ -814,12 +819,15 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                     const bool with_post = defer && h->out_f <= 16 && hp.col0[0] + hp.nh[0] <= 16 && hp.col0[1] + hp.nh[1] <= 16;
                     if (with_post) {
                         hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden, tail->raw,
-                                           h->out_f, rows_here, tail->centre, tail->ki, tail->box_conf, tail->out, tail->xyzds);
+                                           h->out_f, rows_here, tail->centre, tail->ki, tail->box_conf, tail->out, tail->xyzds,
+                                           tail->geo_kps, tail->geo_out);
                         tail->done = true;
+                        tail->geo_done = tail->geo_out != nullptr;
                     } else {
                         hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden,
                                            raw_out + r0 * h->out_f, h->out_f, rows_here, (const float*)nullptr, mlk::Kinv{},
-                                           (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                                           (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr,
+                                           (float*)nullptr);
                     }
                     HIP_TRY(hipGetLastError());
                 }
@@ -1264,9 +1272,10 @@ int ml_loco_forward_raw(ml_loco* h, const float* x_dev, int64_t m, float* raw_de
 }
 
 // ---------------------------------------------------------------- fused pipelines
-int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host,
-                         const float* box_conf_dev, float* raw_dev, float* out_dev, float* xyzds_dev,
-                         void* stream) {
+// geo_out != null: also the post_process geometry block (from the same keypoints); *geo_done = it was written by the launch that
+// ended the forward (a single image), otherwise the caller runs ml_post_geometry_strided
+static int forward_mono_impl(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host, const float* box_conf_dev,
+                             float* raw_dev, float* out_dev, float* xyzds_dev, void* stream, float* geo_out, bool* geo_done) {
     int rc = check_ready(h);
     if (rc) return rc;
     if (h->in_f != mlk::NIN) return fail(ML_ERR_SHAPE, "mono pipeline needs a 34-input model, this one has %d", h->in_f);
@@ -1285,12 +1294,21 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
         return rc;
     float* raw = raw_dev ? raw_dev : h->d_raw;
     TailMono tail{h->d_centre, ki, box_conf_dev, out_dev, xyzds_dev, raw_dev};
+    tail.geo_kps = kps_dev;
+    tail.geo_out = geo_out;
     if ((rc = run_network(h, m, raw, st, McPass(), &tail))) return rc;
+    if (geo_done) *geo_done = tail.geo_done;
     if (!tail.done)
         hipLaunchKernelGGL(mlk::post_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, raw, h->out_f,
                            (const int32_t*)nullptr, m, h->d_centre, ki, box_conf_dev, out_dev, xyzds_dev);
     HIP_TRY(hipGetLastError());
     return ML_OK;
+}
+
+int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host,
+                         const float* box_conf_dev, float* raw_dev, float* out_dev, float* xyzds_dev,
+                         void* stream) {
+    return forward_mono_impl(h, kps_dev, m, kinv_host, box_conf_dev, raw_dev, out_dev, xyzds_dev, stream, nullptr, nullptr);
 }
 
 int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const float* kps_r_dev, int64_t mr,
@@ -1426,18 +1444,32 @@ int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_r
     return ML_OK;
 }
 
-// One image through the mono pipeline in ONE call: pinned host keypoints -> device (async), ml_loco_forward_mono, the
-// post-process geometry block behind it, one copy of [packed (m, 16) | geometry (m, 12)] back into pinned host memory, one
-// stream synchronisation.  What Loco.forward does per frame (reference net.py:83-133 + the geometry of :195-215); as one entry
-// the host pays one foreign call instead of five.
+// One image through the mono pipeline in ONE call: pinned host keypoints in, [packed (m, 16) | post-process geometry (m, 12)] in
+// pinned host memory out, one stream synchronisation.  What Loco.forward does per frame (reference net.py:83-133 + the geometry
+// of :195-215); as one entry the host pays one foreign call instead of five.
+//   * up to 128 persons (one image; the forward ends in heads_small_kernel): NO copy operation at all -- prep_kernel reads the
+//     pinned keypoints over the link, the last launch writes both result blocks straight into the pinned output (device
+//     pointers of pinned host memory are valid kernel arguments): 10 launches and the synchronisation;
+//   * more: keypoints to the device (async copy), pipeline, ml_post_geometry_strided, one copy back.
 int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float* kinv_host, float* kps_dev, float* buf_dev,
                        float* xyzds_dev, float* out_host, void* stream) {
     if (m < 0 || !kinv_host || (m > 0 && (!kps_host || !kps_dev || !buf_dev || !out_host))) return fail(ML_ERR_ARG, "bad argument");
     if (m == 0) return ML_OK;
     hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (m <= 128 && h && use_small_path(h->tune, h->precision, m)) {
+        bool geo_done = false;
+        if ((rc = forward_mono_impl(h, kps_host, m, kinv_host, nullptr, nullptr, out_host, xyzds_dev, stream,
+                                    out_host + (size_t)m * ML_OUT_STRIDE, &geo_done)))
+            return rc;
+        if (!geo_done &&   // (a model whose heads do not end in the one launch: the geometry as its own launch, still into host memory)
+            (rc = ml_post_geometry_strided(kps_host, m, kinv_host, out_host + 3, ML_OUT_STRIDE, out_host + (size_t)m * ML_OUT_STRIDE, stream)))
+            return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+        return ML_OK;
+    }
     HIP_TRY(hipMemcpyAsync(kps_dev, kps_host, (size_t)m * 3 * mlk::NKP * 4, hipMemcpyHostToDevice, st));
-    int rc = ml_loco_forward_mono(h, kps_dev, m, kinv_host, nullptr, nullptr, buf_dev, xyzds_dev, stream);
-    if (rc) return rc;
+    if ((rc = ml_loco_forward_mono(h, kps_dev, m, kinv_host, nullptr, nullptr, buf_dev, xyzds_dev, stream))) return rc;
     float* geo = buf_dev + (size_t)m * ML_OUT_STRIDE;
     if ((rc = ml_post_geometry_strided(kps_dev, m, kinv_host, buf_dev + 3, ML_OUT_STRIDE, geo, stream))) return rc;
     HIP_TRY(hipMemcpyAsync(out_host, buf_dev, (size_t)m * (ML_OUT_STRIDE + ML_POSTGEO_STRIDE) * 4, hipMemcpyDeviceToHost, st));
