@@ -234,7 +234,7 @@ def test_fast_path_training_steps_match_reference(hip_lib, cuda_device, mode, in
             ref_out = g[mode + '_out0']
             assert np.abs(out.cpu().numpy() - ref_out).max() <= 2e-5 * max(1.0, np.abs(ref_out).max())
             grads = tr.grads()
-            checked = 0
+            checked, worst_rms = 0, 0.0
             for k, v in grads.items():
                 if mode + '_grad0/' + k not in g:
                     continue
@@ -245,8 +245,15 @@ def test_fast_path_training_steps_match_reference(hip_lib, cuda_device, mode, in
                 # the whole backward chain has accumulated (w1.weight 3.9e-4, batch_norm1.bias 6.3e-4); the exact-fp32 route
                 # sits at <= 2.5e-4 against the same reference run, torch fp32 itself at ~1e-4 of fp64.
                 assert err <= 2e-3 * max(np.abs(ref_g).max(), 1e-4 * gmax) + 2e-7 * gmax, (k, err, np.abs(ref_g).max())
+                # ... and, tight, the aggregate: rms error over rms of the tensor (the worst-element bar above has to leave room for
+                # the one or two entries a flipped ReLU mask moves; measured rms <= 1.3e-4 at hidden 1024, tools/exp_train_h1024.py)
+                if np.abs(ref_g).max() > 1e-4 * gmax:
+                    rms = float(np.sqrt(np.mean((v.numpy().astype(np.float64) - ref_g) ** 2)) / np.sqrt(np.mean(ref_g.astype(np.float64) ** 2)))
+                    worst_rms = max(worst_rms, rms)
+                    assert rms <= 3e-4, (k, rms)
                 checked += 1
             assert checked >= 9
+            print(mode, 'fast route vs the reference loop, hidden 256: worst rms-rel %.2e' % worst_rms)
         else:
             res = tr.step(x, y)
         ref = g['%s_loss%d' % (mode, step)]
