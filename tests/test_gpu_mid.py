@@ -104,3 +104,50 @@ def test_mid_path_pipeline_and_mc_dropout(hip_lib, cuda_device):
     assert (p_mid - p_tile).abs().max().item() <= 4e-6 * max(1.0, p_tile.abs().max().item())
     assert p_mid.std(0).min().item() > 0          # the passes do differ from each other
     eng.close()
+
+
+@pytest.mark.parametrize("m", [1, 16, 128, 129, 600, 3000])
+def test_loco_forward_frame_entry_all_routes(hip_lib, cuda_device, m):
+    """Loco.forward on Python lists (ml_loco_frame_mono: up to 128 persons without any copy operation -- the pinned keypoints are
+    read and both result blocks written by kernels --, staged copies beyond) against the engine's device-tensor pipeline and
+    ml_post_geometry on the same persons: the dictionary and the cached post_process geometry bit for bit, on the small-row
+    route (<= 512), the mid-size route and both sides of the 128-person switch."""
+    from monoloco_amd import engine
+    from monoloco_amd.network import Loco
+    from monoloco_amd.network.architectures import LocoModel
+    from monoloco_amd.network.process import packed_to_dict
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(6).items()}
+    model = LocoModel(34, 9, 1024)
+    model.load_state_dict(sd)
+    net = Loco(model=model, mode='mono', device=cuda_device)
+    kps = synth.make_poses(m, 11)
+    kk = synth.KITTI_K
+    for rep in range(2):                                          # the second call reuses the cached staging buffers
+        dic = net.forward(kps.tolist(), kk)
+        out, _, _ = net.engine.forward_mono(torch.tensor(kps).to(cuda_device), engine.inverse_intrinsics(kk))
+        ref = packed_to_dict(out, 9)
+        for k in ('h', 'w', 'l', 'ori', 'bi', 'xyzd', 'd'):
+            assert torch.equal(dic[k], ref[k]), (m, rep, k)
+        assert torch.equal(dic['yaw'][0], ref['yaw'][0]) and torch.equal(dic['yaw'][1], ref['yaw'][1])
+        geo = engine.post_geometry(torch.tensor(kps), kk, d=out[:, 3].contiguous(), device=cuda_device).cpu()
+        assert torch.equal(dic._geo[3], geo), (m, rep)
+
+
+def test_mid_path_ten_output_model_through_the_mono_pipeline(hip_lib, cuda_device):
+    """A 34 -> 10 LocoModel (w_fin with 9 outputs + the aux logit) through the fused mono pipeline inside the mid-size window:
+    heads_pair_kernel<9> with the post-process riding in it, against the tile path."""
+    from monoloco_amd import engine
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(7, in_features=34, out_features=10).items()}
+    kps = torch.tensor(synth.make_poses(3000, 5)).to(cuda_device)
+    kinv = engine.inverse_intrinsics(synth.KITTI_K)
+    eng = engine.LocoEngine(sd, device=cuda_device)
+    out_mid, xyzds_mid, raw_mid = [t.clone() for t in eng.forward_mono(kps, kinv, want_raw=True)]
+    out_nr, _, _ = eng.forward_mono(kps, kinv)                     # without the raw rows: they never leave the registers
+    assert torch.equal(out_nr.nan_to_num(), out_mid.nan_to_num())
+    eng.set_tuning(mid_rows=0)
+    out_tile, xyzds_tile, raw_tile = eng.forward_mono(kps, kinv, want_raw=True)
+    assert raw_mid.shape == (3000, 10)
+    assert (raw_mid - raw_tile).abs().max().item() <= 2e-6 * max(1.0, raw_tile.abs().max().item())
+    assert (xyzds_mid - xyzds_tile).abs().max().item() <= 1e-4
+    assert (out_mid.nan_to_num() - out_tile.nan_to_num()).abs().max().item() <= 1e-4
+    eng.close()
