@@ -91,6 +91,32 @@ int main(int argc, char** argv) {
     }
     printf("c-abi client: %lld persons, device bytes %lld, max |xyzds - expected| = %.3e (tolerance %.1e)\n", (long long)m,
            (long long)ml_loco_device_bytes(h), worst, tol);
+    /* one image in one call (ml_loco_frame_mono): pinned, device-mapped host memory in and out, no device buffer of the caller is
+     * touched for <= 128 persons; its (xyz_pred, d, bi) must be the rows the pipeline above produced */
+    {
+        const int64_t mf = m < 16 ? m : 16;
+        float *p_kps, *p_out, *d_stage, *d_buf;
+        HIP(hipHostMalloc((void**)&p_kps, (size_t)mf * 51 * 4, hipHostMallocDefault));
+        HIP(hipHostMalloc((void**)&p_out, (size_t)mf * (ML_OUT_STRIDE + ML_POSTGEO_STRIDE) * 4, hipHostMallocDefault));
+        HIP(hipMalloc((void**)&d_stage, (size_t)mf * 51 * 4));
+        HIP(hipMalloc((void**)&d_buf, (size_t)mf * (ML_OUT_STRIDE + ML_POSTGEO_STRIDE) * 4));
+        memcpy(p_kps, kps, (size_t)mf * 51 * 4);
+        ML(ml_loco_frame_mono(h, p_kps, mf, kinv, d_stage, d_buf, NULL, p_out, (void*)st));
+        double wf = 0.0;
+        for (int64_t i = 0; i < mf; ++i) {
+            const float* pk = p_out + i * ML_OUT_STRIDE;
+            const float* geo = p_out + mf * ML_OUT_STRIDE + i * ML_POSTGEO_STRIDE;
+            const float row[5] = {geo[9], geo[10], geo[11], pk[3], pk[4]};
+            for (int c = 0; c < 5; ++c) {
+                const double d = fabs((double)row[c] - (double)got[i * 5 + c]);
+                if (!(d <= wf)) wf = d;
+            }
+        }
+        printf("c-abi client: frame entry, %lld persons, max |frame - pipeline| = %.3e\n", (long long)mf, wf);
+        if (!(wf <= 5e-5)) worst = 1.0;   /* fails the run.  (16 persons take the small-row kernels, the batch above another dense
+                                             kernel family: same operands, another fp32 summation order -- a few ulps at 20-60 m) */
+        hipHostFree(p_kps); hipHostFree(p_out); hipFree(d_stage); hipFree(d_buf);
+    }
     /* error behaviour: a hot call with a bad argument reports, it does not crash */
     if (ml_loco_forward_mono(h, NULL, m, kinv, NULL, NULL, d_out, d_xyzds, (void*)st) == ML_OK) DIE("null input accepted");
     ML(ml_loco_destroy(h));
