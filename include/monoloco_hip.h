@@ -332,6 +332,8 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
 int ml_debug_get_layer(const ml_loco* h, int layer, float* w_host, float* b_host, int* n, int* k,
                        int* scale_pow2);
 int ml_debug_num_layers(const ml_loco* h);
+/* How many ml_loco_frame_mono calls of this process ran without any copy operation (pinned buffers, <= 128 persons). */
+long long ml_debug_frames_without_copies(void);
 /* Path selection of ONE handle, for tests / A-B runs that compare the paths (negative = leave unchanged; defaults 512 / 128 /
  * 0 / 4): rows <= small_rows take the small-row dense kernels, above small32_rows those use 32x32 tiles; chunk_rows > 0 walks
  * the batch in row chunks of that size through all layers; tile_kernel: 4 = dense_kernel_w4 for the long-K layers,

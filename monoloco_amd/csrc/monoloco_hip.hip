@@ -1444,6 +1444,8 @@ int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_r
     return ML_OK;
 }
 
+static long long g_frames_without_copies = 0;   // (test hook: ml_debug_frames_without_copies)
+
 // One image through the mono pipeline in ONE call: pinned host keypoints in, [packed (m, 16) | post-process geometry (m, 12)] in
 // pinned host memory out, one stream synchronisation.  What Loco.forward does per frame (reference net.py:83-133 + the geometry
 // of :195-215); as one entry the host pays one foreign call instead of five.
@@ -1457,8 +1459,19 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
     if (m == 0) return ML_OK;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (m <= 128 && h && use_small_path(h->tune, h->precision, m)) {
+    // kernels may only dereference PINNED (device-mapped) host memory: anything else takes the staged route, where the runtime's
+    // copies accept pageable memory as well (a wrong guess here would be a GPU page fault, not an error code)
+    auto pinned = [](const void* p) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return a.type == hipMemoryTypeHost;
+    };
+    if (m <= 128 && h && use_small_path(h->tune, h->precision, m) && pinned(kps_host) && pinned(out_host)) {
         bool geo_done = false;
+        ++g_frames_without_copies;
         if ((rc = forward_mono_impl(h, kps_host, m, kinv_host, nullptr, nullptr, out_host, xyzds_dev, stream,
                                     out_host + (size_t)m * ML_OUT_STRIDE, &geo_done)))
             return rc;
@@ -1476,6 +1489,8 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
     HIP_TRY(hipStreamSynchronize(st));
     return ML_OK;
 }
+
+long long ml_debug_frames_without_copies(void) { return g_frames_without_copies; }
 
 int ml_debug_num_layers(const ml_loco* h) { return h ? (int)h->layers.size() : 0; }
 

@@ -112,6 +112,17 @@ int main(int argc, char** argv) {
                 if (!(d <= wf)) wf = d;
             }
         }
+        /* the same call with ordinary (pageable) host memory: the library notices and stages the transfers instead of letting
+         * kernels dereference the pointers */
+        float* q_kps = (float*)malloc((size_t)mf * 51 * 4);
+        float* q_out = (float*)malloc((size_t)mf * (ML_OUT_STRIDE + ML_POSTGEO_STRIDE) * 4);
+        memcpy(q_kps, kps, (size_t)mf * 51 * 4);
+        ML(ml_loco_frame_mono(h, q_kps, mf, kinv, d_stage, d_buf, NULL, q_out, (void*)st));
+        if (memcmp(q_out, p_out, (size_t)mf * (ML_OUT_STRIDE + ML_POSTGEO_STRIDE) * 4) != 0) {
+            wf = 1.0;
+            fprintf(stderr, "frame entry: pageable and pinned buffers disagree\n");
+        }
+        free(q_kps); free(q_out);
         printf("c-abi client: frame entry, %lld persons, max |frame - pipeline| = %.3e\n", (long long)mf, wf);
         if (!(wf <= 5e-5)) worst = 1.0;   /* fails the run.  (16 persons take the small-row kernels, the batch above another dense
                                              kernel family: same operands, another fp32 summation order -- a few ulps at 20-60 m) */

@@ -123,7 +123,9 @@ def test_loco_forward_frame_entry_all_routes(hip_lib, cuda_device, m):
     kps = synth.make_poses(m, 11)
     kk = synth.KITTI_K
     for rep in range(2):                                          # the second call reuses the cached staging buffers
+        before = hip_lib.ml_debug_frames_without_copies()
         dic = net.forward(kps.tolist(), kk)
+        assert hip_lib.ml_debug_frames_without_copies() - before == (1 if m <= 128 else 0)   # torch's pinned memory is recognised
         out, _, _ = net.engine.forward_mono(torch.tensor(kps).to(cuda_device), engine.inverse_intrinsics(kk))
         ref = packed_to_dict(out, 9)
         for k in ('h', 'w', 'l', 'ori', 'bi', 'xyzd', 'd'):
