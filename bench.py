@@ -10,8 +10,13 @@ final gather).  `--total-rows 1048576` is BASELINE configs[3] (a fixed total cut
 "strong").  Prints ONE JSON line on rank 0.
 
   python bench.py                                   # 1 GPU
+  python bench.py --gpus N                          # launches its own N ranks (torch.distributed.run, 127.0.0.1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W      # the driver's form: same ranks, same line
+
+N > 1 lines carry `ranks_seen` (distinct (rank, device UUID) pairs), `ranks` (per-rank device, rows and its own ms per
+step), `ms_per_step_{min,max}_rank`, `gather_ms` (the collective alone), `gather_check` (per-shard checksums of the gathered
+block against each rank's own) and `config4_strong` (BASELINE configs[3] in the same launch).
 
 The line proves itself: `parity` is the deviation of the very outputs the timed loop produced from the CPU oracle on a
 strided sample; `e2e_ms` adds the pinned host<->device copies; `extra` (N = 1) times the other BASELINE configs
@@ -117,10 +122,11 @@ def traffic_from_profiles(args):
     return None
 
 
-def timed_steps(step, steps, warmup, world, device, begin=None, end=None):
+def timed_steps(step, steps, warmup, world, device, begin=None, end=None, local_out=None):
     """The timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by barrier + device
     synchronisation on both sides; returns (seconds = MAX over ranks, whatever `end()` returned on this rank).
-    `device` is the rank's HIP device (a CPU device in the gloo tests of this very function)."""
+    `device` is the rank's HIP device (a CPU device in the gloo tests of this very function).  `local_out` (a dict)
+    receives this rank's own seconds under 'local_s' (the per-rank spread bench.py reports for N > 1)."""
     import torch
     import torch.distributed as dist
     on_gpu = device.type == 'cuda'
@@ -144,11 +150,29 @@ def timed_steps(step, steps, warmup, world, device, begin=None, end=None):
     fence()
     dt = time.perf_counter() - t0
     extra = end() if end is not None else None
+    if local_out is not None:
+        local_out['local_s'] = dt
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, extra
+
+
+def device_identity(dev):
+    """What tells two ranks' devices apart: the HIP device's UUID (or PCI bus id) -- 'cpu:<pid>' for the stub."""
+    import torch
+    if dev.type != 'cuda':
+        return "cpu:%d" % os.getpid()
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        uid = getattr(p, 'uuid', None)
+        if uid is not None:
+            return "%s uuid=%s" % (p.name, uid)
+        return "%s pci=%s:%s.%s" % (p.name, getattr(p, 'pci_domain_id', '?'), getattr(p, 'pci_bus_id', '?'),
+                                    getattr(p, 'pci_device_id', '?'))
+    except Exception as e:  # identity garnish
+        return "cuda:%s (%r)" % (dev.index, e)
 
 
 def power_probe(step, dev, seconds=1.5):
@@ -530,7 +554,46 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
     return out
 
 
-def main():
+def ensure_library(path, local_rank, build, timeout_s=900.0, settle_s=2.0):
+    """The library normally travels with the tree; on a box without it LOCAL rank 0 builds it and the other local ranks
+    wait for the file (then `settle_s` for the linker to finish writing).  Raises if it never appears."""
+    if os.path.exists(path):
+        return False
+    if local_rank == 0:
+        build()
+    else:
+        t_wait = time.time()
+        while not os.path.exists(path) and time.time() - t_wait < timeout_s:
+            time.sleep(0.2)
+        time.sleep(settle_s)
+    if not os.path.exists(path):
+        raise SystemExit("bench.py: %s was not built (local rank %d)" % (path, local_rank))
+    return True
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without torchrun's environment: re-execute this file as N ranks under
+    `python -m torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1, a free port), pass the ranks'
+    stdout / stderr through and return the launcher's exit code.  Rank 0 prints the JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL needs it on this pool's host driver
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
@@ -550,30 +613,39 @@ def main():
     ap.add_argument('--chunk-rows', type=int, default=-1,
                     help='walk the batch in row chunks of this size through all layers (-1 = library default)')
     ap.add_argument('--gather', default='gather', choices=['gather', 'all_gather'], help='N > 1: the final collective')
-    args = ap.parse_args()
+    ap.add_argument('--stub-engine', action='store_true',
+                    help='launch-contract test on a box without a GPU: tests/stub_engine.py on CPU over gloo; the line is '
+                         'marked "data": "stub" and measures nothing')
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) and relay their line
+        return self_launch(args.gpus, list(sys.argv[1:] if argv is None else argv))
 
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
     import synth
     from monoloco_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        # the library normally travels with the tree; on a box without it local rank 0 builds it, the others wait
-        if int(os.environ.get('LOCAL_RANK', '0')) == 0:
-            import __graft_entry__
-            __graft_entry__.build()
-        else:
-            t_wait = time.time()
-            while not os.path.exists(_lib.LIB_PATH) and time.time() - t_wait < 900:
-                time.sleep(1.0)
-            time.sleep(2.0)  # let the linker finish writing
+    stub = args.stub_engine
+    if not stub:
+        import __graft_entry__
+        ensure_library(_lib.LIB_PATH, int(os.environ.get('LOCAL_RANK', '0')), __graft_entry__.build)
     from monoloco_amd import engine, parallel
 
-    rank, world, local = parallel.init_from_env('nccl' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else None)
+    multi = int(os.environ.get('WORLD_SIZE', '1')) > 1
+    rank, world, local = parallel.init_from_env(('gloo' if stub else 'nccl') if multi else None)
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's --nproc-per-node and --gpus must agree)"
+                         % (args.gpus, world))
+    if stub:
+        import stub_engine
+        dev = torch.device('cpu')
+        make_engine = stub_engine.StubEngine
+    else:
+        dev = torch.device('cuda', local)
+        torch.cuda.set_device(dev)
+        make_engine = engine.LocoEngine
 
     strong = args.total_rows > 0
     if strong:
@@ -594,8 +666,8 @@ def main():
         kps_np = synth.make_keypoints(ml, seed=100 + rank)
         kps_r = torch.tensor(synth.make_keypoints(mr, seed=200 + rank)).to(dev)
         rows = ml * mr
-    eng = engine.LocoEngine({k: torch.tensor(v) for k, v in sd.items()}, device=dev, precision=args.precision,
-                            merge_w2w3=not args.no_merge, reserve_rows=rows)
+    eng = make_engine({k: torch.tensor(v) for k, v in sd.items()}, device=dev, precision=args.precision,
+                      merge_w2w3=not args.no_merge, reserve_rows=rows)
     if args.tile_kernel:
         eng.set_tuning(tile_kernel=args.tile_kernel & 255, everywhere=bool(args.tile_kernel & 256))
     if args.chunk_rows >= 0:
@@ -625,7 +697,31 @@ def main():
         hooks = (lambda: eng.profile_begin(args.steps * eng.num_layers * 16 + 8), eng.profile_end)
     else:
         hooks = (None, None)
-    dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, begin=hooks[0], end=hooks[1])
+    mine = {}
+    dt, prof = timed_steps(step, args.steps, args.warmup, world, dev, begin=hooks[0], end=hooks[1], local_out=mine)
+
+    # who took part: one record per rank (its device's identity and its own clock around the same K steps)
+    me = {"rank": rank, "local_rank": local, "device": device_identity(dev), "rows": rows,
+          "ms_per_step": round(mine['local_s'] / args.steps * 1e3, 4)}
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+    else:
+        seen = [me]
+
+    gather_check = None
+    if sharded is not None:
+        # the gathered block really holds every rank's rows, in rank order: per-shard checksums on rank 0 against each
+        # rank's own checksum of what it computed (NaN rows -- sqrt of a negative z^2 -- count as zero on both sides)
+        full = sharded.run(local_block)
+        own = float(torch.nan_to_num(xyzds.double(), nan=0.0, posinf=0.0, neginf=0.0).abs().sum().item())
+        sums = [None] * world
+        dist.all_gather_object(sums, own)
+        if rank == 0:
+            got = [float(torch.nan_to_num(full[lo_:hi_].double(), nan=0.0, posinf=0.0, neginf=0.0).abs().sum().item())
+                   for lo_, hi_ in sharded.gather.bounds]
+            gather_check = {"ok": bool(all(a == b for a, b in zip(got, sums))), "shards": len(got),
+                            "rows": int(full.shape[0]), "distinct_shards": len(set(got))}
 
     gather_ms = None
     if sharded is not None:   # the collective alone, same buffers, same barriers (not part of `value`'s clock)
@@ -679,8 +775,18 @@ def main():
                        "weights": "seeded synthetic (tests/synth.py)",
                        "parallelism": "rows sharded x%d, 1 %s" % (world, args.gather)},
         }
+        line["ranks_seen"] = len({(r["rank"], r["device"]) for r in seen})
+        line["ranks"] = seen
+        per = [r["ms_per_step"] for r in seen]
+        line["ms_per_step_min_rank"], line["ms_per_step_max_rank"] = min(per), max(per)
+        if stub:
+            line["data"] = "stub"
+            line["config"]["stub"] = ("tests/stub_engine.py on CPU over gloo: the launch contract only, no device work -- "
+                                      "`value` measures nothing")
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 4)
+        if gather_check is not None:
+            line["gather_check"] = gather_check
         if strong4 is not None:
             line["config4_strong"] = strong4
         if prof and prof['launches']:
@@ -702,13 +808,13 @@ def main():
             pw = power_probe(step, dev)
             if pw is not None:
                 line["roofline"]["power"] = pw
-        if args.workload == 'mono':
+        if args.workload == 'mono' and not stub:
             line["parity"] = parity_of_timed_run(sd, kps, conf, xyzds, raw, kk)
-        if world == 1 and args.workload == 'mono' and not args.no_extra:
+        if world == 1 and args.workload == 'mono' and not args.no_extra and not stub:
             line["extra"] = extras(args, dev, sd, eng, kps, conf, kinv, kk, ms_per_step)
             if "e2e" in line["extra"] and "e2e_ms" in line["extra"]["e2e"]:
                 line["e2e_ms"] = line["extra"]["e2e"]["e2e_ms"]
-        if world == 1 and args.cpu_seconds > 0 and args.workload == 'mono':
+        if world == 1 and args.cpu_seconds > 0 and args.workload == 'mono' and not stub:
             line["cpu_baseline"] = cpu_baseline(sd, kps_np, kk, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -718,4 +824,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

@@ -182,3 +182,105 @@ def test_row_all_gather_mode_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get() is True and q.get() is True
+
+
+# ---------------------------------------------------------------- bench.main() end to end at world size 2
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(cmd, extra_env=None):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable] + cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, "exactly ONE JSON line on stdout, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def _check_world2_line(d, rows_per_rank):
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['data'] == 'stub'
+    assert [r['rank'] for r in d['ranks']] == [0, 1] and d['ranks'][0]['device'] != d['ranks'][1]['device']
+    assert d['ms_per_step_min_rank'] <= d['ms_per_step_max_rank'] <= d['ms_per_step'] * 1.0001 + 1e-3
+    assert d['gather_ms'] > 0 and d['gather_check'] == {'ok': True, 'shards': 2, 'rows': 2 * rows_per_rank,
+                                                         'distinct_shards': 2}
+    assert d['scaling'] == 'weak' and d['config']['rows_per_gpu'] == rows_per_rank
+    assert abs(d['value'] - 2 * rows_per_rank / d['ms_per_step'] * 1e3) <= 2e-3 * d['value']   # whole-job aggregate
+    c4 = d['config4_strong']                                   # BASELINE configs[3] rides in the same launch
+    assert c4['scaling'] == 'strong' and c4['total_rows'] == 1048576 and c4['rows_per_gpu'] == 524288 and c4['value'] > 0
+
+
+def test_bench_main_self_launches_world2():
+    """`python bench.py --gpus 2` with no torchrun environment launches its own two ranks; the stub
+    engine stands in for the device so that argument handling, sharding, the gather, config4_strong and the JSON line of
+    main() are executed on CPU."""
+    d = _run_bench(['bench.py', '--gpus', '2', '--stub-engine', '--steps', '3', '--warmup', '1', '--batch', '384'])
+    _check_world2_line(d, 384)
+    assert d['steps'] == 3 and d['warmup'] == 1
+
+
+def test_bench_main_under_torchrun_world2():
+    """The driver's own form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2."""
+    d = _run_bench(['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                    '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--stub-engine', '--steps', '2',
+                    '--warmup', '1', '--batch', '256', '--gather', 'all_gather'])
+    _check_world2_line(d, 256)
+    assert 'all_gather' in d['config']['parallelism']
+
+
+def test_bench_main_strong_world2():
+    d = _run_bench(['bench.py', '--gpus', '2', '--stub-engine', '--steps', '2', '--warmup', '1', '--total-rows', '1001'])
+    assert d['scaling'] == 'strong' and d['ranks_seen'] == 2
+    assert [r['rows'] for r in d['ranks']] == [501, 500]                       # ragged shards: point-to-point gather
+    assert d['gather_check']['ok'] and d['gather_check']['rows'] == 1001
+    assert 'config4_strong' not in d
+
+
+def test_bench_gpus_mismatch_is_an_error():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--stub-engine'], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and '--gpus 2 but WORLD_SIZE=1' in r.stderr
+
+
+def _build_worker(local_rank, path, q):
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    built = []
+
+    def build():                 # local rank 0's job: takes a while, writes the file at the end
+        time.sleep(1.0)
+        with open(path, 'w') as f:
+            f.write('built')
+        built.append(1)
+    t0 = time.time()
+    did = bench.ensure_library(path, local_rank, build, timeout_s=30.0, settle_s=0.1)
+    q.put((local_rank, did, len(built), os.path.exists(path), time.time() - t0))
+
+
+def test_on_demand_build_handoff(tmp_path):
+    """bench.py on a box without the library: local rank 0 builds, the other local ranks wait for the file."""
+    path = str(tmp_path / 'libfake.so')
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_build_worker, args=(r, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get() for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, did0, n0, ok0, _), (r1, did1, n1, ok1, t1) = res
+    assert did0 and n0 == 1 and ok0                 # rank 0 built it
+    assert did1 and n1 == 0 and ok1 and t1 >= 0.9   # rank 1 did not build, and did wait for it
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.ensure_library(path, 1, lambda: 1 / 0) is False     # present: nobody builds
