@@ -208,6 +208,16 @@ int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const
 int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host, int n_dropout,
                            float p_dropout, int n_samples, uint32_t seed, float* epi_dev, float* raw_passes_dev,
                            void* stream);
+/* The same on PRE-PROCESSED network inputs x_dev (m, 34): the argument Loco.epistemic_uncertainty(inputs) takes (net.py:135);
+ * same passes, masks and draws as ml_loco_epistemic_mono on the keypoints those inputs came from. */
+int ml_loco_epistemic_inputs(ml_loco* h, const float* x_dev, int64_t m, int n_dropout, float p_dropout, int n_samples,
+                             uint32_t seed, float* epi_dev, float* raw_passes_dev, void* stream);
+/* filter_outputs' mask as a row list (process.py:319-327): raw_all_dev (ml*mr, out_features) pair rows, i-major; rows_dev
+ * (capacity ml*mr) receives, left person by left person, every pair row whose aux logit (last column) is >= the maximum over that
+ * person's right candidates -- exact ties keep several rows, a NaN among the candidates keeps none, as in the reference --;
+ * count_dev (1) the number of rows written.  ml_loco_forward_stereo reports whether any person is tied; this lists them. */
+int ml_stereo_tied_rows(const float* raw_all_dev, int out_features, int64_t ml, int64_t mr, int32_t* rows_dev, int32_t* count_dev,
+                        void* stream);
 
 /* ---- training step: stands in for one iteration of Trainer.train (monoloco/train/trainer.py:150-161) ---- */
 typedef struct ml_trainer ml_trainer;
@@ -264,6 +274,19 @@ int ml_trainer_last_val_values(const ml_trainer* t, double* host10);
  * raw_out_dev (m, out_features) optionally receives the outputs.  Synchronises the stream. */
 int ml_trainer_eval(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m, double* vals_host,
                     float* raw_out_dev, void* stream);
+/* 1 if ml_trainer_eval takes this trainer's shape (the predicate its ML_ERR_SHAPE is raised from), 0 otherwise. */
+int ml_trainer_can_eval(const ml_trainer* t);
+/* The statistics the reference's Trainer computes with torch from raw outputs and labels (trainer.py:163-165 epoch values,
+ * :213-232 evaluate; losses.py:85-96; process.py:125-133 unnormalize_bi; trainer.py:384-389 get_accuracy), in one launch on rows
+ * that are on the device anyway: raw_dev (m, 9|10), labels_dev (m, label_cols >= 10|11) -> vals_host (14):
+ * [0..7] means of the training-type task terms d (Laplace), x, y, h, w, l, ori, aux (BCE); [8] mean |mu - d|; [9] mean angle error
+ * (radians); [10] mean bi = exp(s) d; [11] share of rows with |mu - d| <= bi; [12] unbiased std of |mu - d| (torch .std());
+ * [13] aux accuracy 1 - mean |[sigmoid(a) >= 0.5] - label| (0 for 9 outputs).  fp64 sums, fixed order.  Synchronises the stream. */
+int ml_val_stats(const float* raw_dev, int out_features, const float* labels_dev, int label_cols, int64_t m, double* vals_host,
+                 void* stream);
+/* dst_dev (n, width) = rows idx_dev[0..n) (int64) of src_dev (*, width): the collation of one batch of the epoch's row
+ * permutation (the reference's DataLoader does it on the host, trainer.py:150-152). */
+int ml_gather_rows(const float* src_dev, int width, const int64_t* idx_dev, int64_t n, float* dst_dev, void* stream);
 /* The best-epoch bookkeeping of the reference's loop (trainer.py:173-177, 183: deepcopy of the state_dict / load_state_dict) without
  * leaving the device: snapshot = parameters + BatchNorm running statistics copied aside (device to device), restore = copied back
  * (optimizer state untouched, like load_state_dict). */

@@ -70,6 +70,11 @@ SIGNATURES = {
     'ml_loco_forward_stereo': (c_int, [_P, _P, c_int64, _P, c_int64, POINTER(c_float), _P, _P, _P, _P,
                                        _P, _P, _P]),
     'ml_loco_epistemic_mono': (c_int, [_P, _P, c_int64, POINTER(c_float), c_int, c_float, c_int, c_uint32, _P, _P, _P]),
+    'ml_loco_epistemic_inputs': (c_int, [_P, _P, c_int64, c_int, c_float, c_int, c_uint32, _P, _P, _P]),
+    'ml_stereo_tied_rows': (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P]),
+    'ml_trainer_can_eval': (c_int, [_P]),
+    'ml_val_stats': (c_int, [_P, c_int, _P, c_int, c_int64, POINTER(c_double), _P]),
+    'ml_gather_rows': (c_int, [_P, c_int, _P, c_int64, _P, _P]),
     'ml_trainer_create': (c_int, [c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_uint32, POINTER(_P)]),
     'ml_trainer_set_tensor': (c_int, [_P, c_char_p, POINTER(c_float), c_int64]),
     'ml_trainer_get_tensor': (c_int, [_P, c_char_p, POINTER(c_float), c_int64]),

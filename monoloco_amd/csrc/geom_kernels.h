@@ -364,6 +364,60 @@ __global__ __launch_bounds__(256) void stereo_best_kernel(const float* __restric
     if (cnt > 1 || has_nan) atomicAdd(ties, 1);
 }
 
+// filter_outputs' mask as a row list (process.py:319-327): every pair row whose aux logit (last column) is >= the maximum of its
+// left person, left persons in order, rows in order.  ONE workgroup walks the left persons 256 at a time: per person the maximum and
+// the number of kept rows, an exclusive scan of the counts through LDS, then every thread writes its person's rows behind the
+// running base.  A NaN among a person's candidates keeps none of its rows (`val >= nan` is false everywhere).  Exact ties are
+// rare: this runs only when stereo_best_kernel has counted one.
+__global__ __launch_bounds__(256) void stereo_tied_rows_kernel(const float* __restrict__ raw_all, int out_f, int64_t ml, int64_t mr,
+                                                               int32_t* __restrict__ rows, int32_t* __restrict__ count) {
+    __shared__ int32_t scan[256];
+    __shared__ int32_t base_s;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < ml; i0 += 256) {
+        const int64_t i = i0 + threadIdx.x;
+        float bv = 0.f;
+        int cnt = 0;
+        if (i < ml) {
+            const float* p = raw_all + i * mr * out_f + (out_f - 1);
+            bv = p[0];
+            bool has_nan = (bv != bv);
+            cnt = 1;
+            for (int64_t j = 1; j < mr; ++j) {
+                const float v = p[j * out_f];
+                has_nan |= (v != v);
+                if (v > bv) {
+                    bv = v;
+                    cnt = 1;
+                } else if (v == bv) {
+                    ++cnt;
+                }
+            }
+            if (has_nan) cnt = 0;
+        }
+        scan[threadIdx.x] = cnt;
+        __syncthreads();
+        for (int s = 1; s < 256; s <<= 1) {   // inclusive Hillis-Steele scan
+            const int32_t add = ((int)threadIdx.x >= s) ? scan[threadIdx.x - s] : 0;
+            __syncthreads();
+            scan[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int32_t base = base_s;
+        if (cnt > 0) {
+            int32_t w = base + scan[threadIdx.x] - cnt;
+            const float* p = raw_all + i * mr * out_f + (out_f - 1);
+            for (int64_t j = 0; j < mr; ++j)
+                if (p[j * out_f] >= bv) rows[w++] = (int32_t)(i * mr + j);
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) base_s = base + scan[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base_s;
+}
+
 // ------------------------------------------------------------------------------------------
 // heads for a single image's worth of rows: ONE launch for all heads (w_fin and w_aux read different activation
 // buffers), one workgroup per row, the outputs dealt round-robin to its 4 waves, weights read straight from L2

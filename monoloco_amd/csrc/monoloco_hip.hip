@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1345,16 +1346,16 @@ int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const
 }
 
 // ---------------------------------------------------------------- MC-dropout epistemic uncertainty
-int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host, int n_dropout,
-                           float p_dropout, int n_samples, uint32_t seed, float* epi_dev, float* raw_passes_dev,
-                           void* stream) {
+// kps_dev + kinv_host (pixel keypoints, pre-processed here) or x_dev (the (m, 34) network inputs the reference's method takes)
+static int epistemic_impl(ml_loco* h, const float* kps_dev, const float* kinv_host, const float* x_dev, int64_t m, int n_dropout,
+                          float p_dropout, int n_samples, uint32_t seed, float* epi_dev, float* raw_passes_dev, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
     if (h->in_f != mlk::NIN) return fail(ML_ERR_SHAPE, "epistemic uncertainty is defined for the mono nets (net.py:139)");
     if (m == 0) return ML_OK;
     // p_dropout == 0 is legal (reference net.py:135-161 with a p = 0 model): the passes are then identical and the
     // spread is the purely aleatoric one of the Laplace samples
-    if (m < 0 || !kps_dev || !kinv_host || !epi_dev || n_dropout <= 0 || n_samples <= 0 || !(p_dropout >= 0.f) ||
+    if (m < 0 || !(x_dev || (kps_dev && kinv_host)) || !epi_dev || n_dropout <= 0 || n_samples <= 0 || !(p_dropout >= 0.f) ||
         !(p_dropout < 1.f))
         return fail(ML_ERR_ARG, "bad argument");
     if ((rc = ensure_rows(h, m))) return rc;
@@ -1370,7 +1371,7 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
     HIP_TRY(hipMallocAsync((void**)&acc, (size_t)(m * 2 + per_chunk * m * 2) * sizeof(double), st));
     HIP_TRY(hipMemsetAsync(acc, 0, (size_t)m * 2 * sizeof(double), st));
     double* part = acc + m * 2;
-    const mlk::Kinv ki = make_kinv(kinv_host);
+    const mlk::Kinv ki = x_dev ? mlk::Kinv() : make_kinv(kinv_host);
     const unsigned grid_m = (unsigned)((m + 255) / 256);
     const int64_t line_bytes = (int64_t)m * h->k0pad * 4;  // the m input rows in line format
     for (int pass0 = 0; pass0 < n_dropout && !rc; pass0 += (int)per_chunk) {
@@ -1380,9 +1381,15 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
         // the stochastic forward consumes the input lines afresh every time (buffer A is overwritten); rows beyond
         // the batched passes are zero-filled by the first prep launch only up to round_up(m), so clear the tail
         // legacy 'monoloco' (2 outputs = d, s) is fed zero-centred inputs (net.py:96)
-        if ((rc = launch_prep(st, kps_dev, m, ki, 10.0f, (float*)nullptr, (float*)nullptr, h->buf[0], h->k0pad, round_up64(m, 256),
-                              (h->legacy && h->out_f == 2) ? 1 : 0)))
+        if (x_dev) {
+            const int64_t mp = round_up64(m, 256), chunks = mp * (h->k0pad / 4);
+            hipLaunchKernelGGL(mlk::f32_to_lines_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, x_dev, m, h->in_f,
+                               h->buf[0], h->k0pad, mp);
+        } else if ((rc = launch_prep(st, kps_dev, m, ki, 10.0f, (float*)nullptr, (float*)nullptr, h->buf[0], h->k0pad,
+                                     round_up64(m, 256), (h->legacy && h->out_f == 2) ? 1 : 0))) {
+            (void)hipFreeAsync(acc, st);
             return rc;
+        }
         if (pc > 1) {
             const int64_t n16 = line_bytes / 16 * (pc - 1);
             hipLaunchKernelGGL(mlk::replicate_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, h->buf[0], line_bytes, pc);
@@ -1419,6 +1426,31 @@ int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const fl
     return rc;
 }
 
+int ml_loco_epistemic_mono(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host, int n_dropout,
+                           float p_dropout, int n_samples, uint32_t seed, float* epi_dev, float* raw_passes_dev,
+                           void* stream) {
+    if (m > 0 && (!kps_dev || !kinv_host)) return fail(ML_ERR_ARG, "bad argument");
+    return epistemic_impl(h, kps_dev, kinv_host, nullptr, m, n_dropout, p_dropout, n_samples, seed, epi_dev, raw_passes_dev, stream);
+}
+
+int ml_loco_epistemic_inputs(ml_loco* h, const float* x_dev, int64_t m, int n_dropout, float p_dropout, int n_samples,
+                             uint32_t seed, float* epi_dev, float* raw_passes_dev, void* stream) {
+    if (m > 0 && !x_dev) return fail(ML_ERR_ARG, "bad argument");
+    return epistemic_impl(h, nullptr, nullptr, x_dev, m, n_dropout, p_dropout, n_samples, seed, epi_dev, raw_passes_dev, stream);
+}
+
+// filter_outputs' mask (process.py:319-327) as a row list: for every left person, in order, every pair row whose aux logit is >=
+// the maximum over its right candidates (a NaN among them empties the person, as `val >= nan` does).
+int ml_stereo_tied_rows(const float* raw_all_dev, int out_features, int64_t ml, int64_t mr, int32_t* rows_dev, int32_t* count_dev,
+                        void* stream) {
+    if (!raw_all_dev || !rows_dev || !count_dev || ml < 0 || mr <= 0 || out_features < 1 || ml * mr > 0x7fffffffLL)
+        return fail(ML_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(mlk::stereo_tied_rows_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, raw_all_dev, out_features, ml, mr,
+                       rows_dev, count_dev);
+    HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
 // ---------------------------------------------------------------- test hooks
 int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint16_t* host_lo) {
     if (!host_in || !host_hi || !host_lo || n < 0) return fail(ML_ERR_ARG, "bad argument");
@@ -1444,7 +1476,7 @@ int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_r
     return ML_OK;
 }
 
-static long long g_frames_without_copies = 0;   // (test hook: ml_debug_frames_without_copies)
+static std::atomic<long long> g_frames_without_copies{0};   // (test hook: ml_debug_frames_without_copies)
 
 // One image through the mono pipeline in ONE call: pinned host keypoints in, [packed (m, 16) | post-process geometry (m, 12)] in
 // pinned host memory out, one stream synchronisation.  What Loco.forward does per frame (reference net.py:83-133 + the geometry
@@ -1471,7 +1503,6 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
     };
     if (m <= 128 && h && use_small_path(h->tune, h->precision, m) && pinned(kps_host) && pinned(out_host)) {
         bool geo_done = false;
-        ++g_frames_without_copies;
         if ((rc = forward_mono_impl(h, kps_host, m, kinv_host, nullptr, nullptr, out_host, xyzds_dev, stream,
                                     out_host + (size_t)m * ML_OUT_STRIDE, &geo_done)))
             return rc;
@@ -1479,6 +1510,7 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
             (rc = ml_post_geometry_strided(kps_host, m, kinv_host, out_host + 3, ML_OUT_STRIDE, out_host + (size_t)m * ML_OUT_STRIDE, stream)))
             return rc;
         HIP_TRY(hipStreamSynchronize(st));
+        g_frames_without_copies.fetch_add(1, std::memory_order_relaxed);   // counted once the frame has gone through
         return ML_OK;
     }
     HIP_TRY(hipMemcpyAsync(kps_dev, kps_host, (size_t)m * 3 * mlk::NKP * 4, hipMemcpyHostToDevice, st));
@@ -1490,7 +1522,7 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
     return ML_OK;
 }
 
-long long ml_debug_frames_without_copies(void) { return g_frames_without_copies; }
+long long ml_debug_frames_without_copies(void) { return g_frames_without_copies.load(std::memory_order_relaxed); }
 
 int ml_debug_num_layers(const ml_loco* h) { return h ? (int)h->layers.size() : 0; }
 

@@ -367,6 +367,9 @@ int fast_linear_bwd_weight(ml_trainer* t, hipStream_t st, const float* x, const 
 }
 
 bool fast_possible(const ml_trainer* t) { return t->H % 256 == 0 && !t->lbufs.empty(); }
+constexpr int64_t MID_AUTO_MAX_ROWS = 16384;
+// xgemm_tile keeps its per-lane operand offsets in 32 bits (train_mid.h): an m x H fp32 operand must stay below 4 GiB
+bool mid_rows_ok(const ml_trainer* t, int64_t m) { return (m + 64) * (int64_t)t->H * 4 < (int64_t)1 << 32; }
 bool mid_possible(const ml_trainer* t) {
     return t->H % 64 == 0 && t->d_ssq != nullptr && t->in_f <= mlt::SK_NC && (int64_t)t->C * t->H <= mlt::HL_MAXW;
 }
@@ -379,7 +382,9 @@ int pick_route(const ml_trainer* t, int64_t m) {
         default: break;
     }
     if (t->fast_rows > 0 && m >= t->fast_rows && fast_possible(t)) return 1;
-    if (mid_possible(t)) return 2;
+    // mid: built for the reference's batch sizes (its column-owner kernels walk all rows in H / apply_cols workgroups); above
+    // MID_AUTO_MAX_ROWS a shape the fast route cannot take goes to the exact route's row-parallel kernels instead
+    if (mid_possible(t) && m <= MID_AUTO_MAX_ROWS) return 2;
     return 0;
 }
 
@@ -1031,15 +1036,75 @@ int ml_trainer_eval(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     if (!t || !x_dev || !labels_dev || m < 1 || label_cols < 10 || !vals_host) return tfail(ML_ERR_ARG, "bad argument");
     if (t->C == 10 && label_cols < 11) return tfail(ML_ERR_ARG, "stereo labels need 11 columns");
     if (!mid_possible(t)) return tfail(ML_ERR_SHAPE, "ml_trainer_eval needs hidden % 64 == 0 (and out_features * hidden <= 15360)");
-    int rc = ensure_cap(t, m);
-    if (rc) return rc;
+    // a whole validation set arrives in one call (Trainer.evaluate): walked in chunks so that the buffers stay at batch size and
+    // the column-owner kernels at the row counts they were built for; the chunk means are combined weighted by their rows
+    const int64_t CH = 8192;
     hipStream_t st = (hipStream_t)stream;
-    int parts = 0;
-    if ((rc = mid_forward(t, st, x_dev, labels_dev, label_cols, m, 0u, true, false, &parts))) return rc;
-    if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * t->C * 4, hipMemcpyDeviceToDevice, st));
-    T_TRY(hipMemcpyAsync(t->h_loss, t->d_lpart, (size_t)parts * mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));
-    T_TRY(hipStreamSynchronize(st));
-    sum_loss_parts(t, parts, vals_host);
+    double acc[mlt::LOSS_NV];
+    for (int q = 0; q < mlt::LOSS_NV; ++q) acc[q] = 0.0;
+    int rc;
+    for (int64_t off = 0; off < m; off += CH) {
+        const int64_t mc = m - off < CH ? m - off : CH;
+        if ((rc = ensure_cap(t, mc))) return rc;
+        int parts = 0;
+        if ((rc = mid_forward(t, st, x_dev + off * t->in_f, labels_dev + off * label_cols, label_cols, mc, 0u, true, false, &parts)))
+            return rc;
+        if (raw_out_dev)
+            T_TRY(hipMemcpyAsync(raw_out_dev + off * t->C, t->d_out, (size_t)mc * t->C * 4, hipMemcpyDeviceToDevice, st));
+        T_TRY(hipMemcpyAsync(t->h_loss, t->d_lpart, (size_t)parts * mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));
+        T_TRY(hipStreamSynchronize(st));
+        double v[mlt::LOSS_NV];
+        sum_loss_parts(t, parts, v);
+        if (mc == m) {
+            for (int q = 0; q < mlt::LOSS_NV; ++q) acc[q] = v[q];
+        } else {
+            for (int q = 0; q < mlt::LOSS_NV; ++q) acc[q] += v[q] * ((double)mc / (double)m);
+        }
+    }
+    for (int q = 0; q < mlt::LOSS_NV; ++q) vals_host[q] = acc[q];
+    return ML_OK;
+}
+
+int ml_trainer_can_eval(const ml_trainer* t) { return (t && mid_possible(t)) ? 1 : 0; }
+
+int ml_val_stats(const float* raw_dev, int out_features, const float* labels_dev, int label_cols, int64_t m, double* vals_host,
+                 void* stream) {
+    if (!raw_dev || !labels_dev || !vals_host || m < 1 || (out_features != 9 && out_features != 10) || label_cols < 10 ||
+        (out_features == 10 && label_cols < 11))
+        return tfail(ML_ERR_ARG, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = (int)((m + 255) / 256);
+    if (grid > 256) grid = 256;
+    double* part = nullptr;
+    T_TRY(hipMallocAsync((void**)&part, (size_t)grid * mlt::VAL_NV * sizeof(double), st));
+    hipLaunchKernelGGL(mlt::val_stats_kernel, dim3(grid), dim3(256), 0, st, raw_dev, out_features, labels_dev, label_cols, m, part);
+    std::vector<double> h((size_t)grid * mlt::VAL_NV);
+    hipError_t e = hipMemcpyAsync(h.data(), part, h.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFreeAsync(part, st);
+    if (e != hipSuccess) return tfail(ML_ERR_HIP, "ml_val_stats: %s", hipGetErrorString(e));
+    double s[mlt::VAL_NV];
+    for (int q = 0; q < mlt::VAL_NV; ++q) {
+        double a = 0.0;
+        for (int b = 0; b < grid; ++b) a += h[(size_t)b * mlt::VAL_NV + q];
+        s[q] = a;
+    }
+    const double dm = (double)m;
+    for (int q = 0; q < mlt::LOSS_NV; ++q) vals_host[q] = s[q] / dm;
+    vals_host[10] = s[10] / dm;                                                    // mean bi
+    vals_host[11] = s[11] / dm;                                                    // share of |mu - d| <= bi
+    vals_host[12] = m > 1 ? std::sqrt(std::max(0.0, (s[13] - s[12] * s[12] / dm) / (dm - 1.0))) : NAN;   // unbiased std of |mu - d|
+    vals_host[13] = out_features == 10 ? 1.0 - s[14] / dm : 0.0;                   // aux accuracy
+    return ML_OK;
+}
+
+int ml_gather_rows(const float* src_dev, int width, const int64_t* idx_dev, int64_t n, float* dst_dev, void* stream) {
+    if (n == 0) return ML_OK;
+    if (!src_dev || !idx_dev || !dst_dev || n < 0 || width < 1) return tfail(ML_ERR_ARG, "bad argument");
+    const int64_t e = n * width;
+    hipLaunchKernelGGL(mlt::gather_rows_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src_dev, width,
+                       idx_dev, n, dst_dev);
+    T_TRY(hipGetLastError());
     return ML_OK;
 }
 
@@ -1108,7 +1173,10 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     const int H = t->H, S = t->S, C = t->C;
     const int route = pick_route(t, m);
     t->last_route = route;
-    if (route == 2) return step_mid(t, x_dev, labels_dev, label_cols, m, update, losses_host, raw_out_dev, st);
+    if (route == 2) {
+        if (!mid_rows_ok(t, m)) return tfail(ML_ERR_SHAPE, "the mid route takes operands below 4 GiB (rows x hidden x 4)");
+        return step_mid(t, x_dev, labels_dev, label_cols, m, update, losses_host, raw_out_dev, st);
+    }
     T_TRY(hipMemsetAsync(t->d_red_base, 0, (size_t)t->red_slots * (2 * H + 32) * sizeof(double), st));
     t->red_slot = 0;
     t->d_red = t->d_red_base;

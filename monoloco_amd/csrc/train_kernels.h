@@ -900,6 +900,59 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ out
     if (threadIdx.x < LOSS_NV) atomicAdd(&losses[threadIdx.x], red[threadIdx.x][0] / (double)m);
 }
 
+// Validation statistics of raw outputs against labels, what the reference's Trainer computes with torch on the host
+// (trainer.py:163-165, 197-246; losses.py:85-96): per row the LOSS_NV terms of loss_row, then bi = exp(s) d (unnormalize_bi,
+// process.py:125-133), [|mu - d| <= bi], |mu - d| and its square (for the unbiased std), and for stereo |[sigmoid(a) >= 0.5] - label|
+// (get_accuracy, trainer.py:384-389).  Per-workgroup partial SUMS (not means) to part[blockIdx.x][VAL_NV]; the host adds them in order.
+constexpr int VAL_NV = LOSS_NV + 5;
+__global__ __launch_bounds__(256) void val_stats_kernel(const float* __restrict__ out, int C, const float* __restrict__ lab, int L,
+                                                       int64_t m, double* __restrict__ part) {
+    __shared__ double red[VAL_NV][4];
+    double t[VAL_NV];
+#pragma unroll
+    for (int q = 0; q < VAL_NV; ++q) t[q] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        const float* o = out + i * C;
+        const float* y = lab + i * L;
+        float w8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        double r[LOSS_NV];
+        loss_row(o, y, C, m, w8, nullptr, r);
+#pragma unroll
+        for (int q = 0; q < LOSS_NV; ++q) t[q] += r[q];
+        const float err = fabsf(o[2] - y[3]);
+        const float bi = expf(o[3]) * o[2];
+        t[LOSS_NV + 0] += (double)bi;
+        t[LOSS_NV + 1] += (err <= bi) ? 1.0 : 0.0;
+        t[LOSS_NV + 2] += (double)err;
+        t[LOSS_NV + 3] += (double)err * (double)err;
+        if (C == 10) {
+            const float sg = 1.f / (1.f + expf(-o[9]));
+            t[LOSS_NV + 4] += (double)fabsf((sg >= 0.5f ? 1.f : 0.f) - y[10]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < VAL_NV; ++q) {
+        double v = t[q];
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s, 64);
+        if (lane == 0) red[q][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < VAL_NV)
+        part[(size_t)blockIdx.x * VAL_NV + threadIdx.x] =
+            ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+}
+
+// dst[i, :] = src[idx[i], :] (the batch of an epoch's row permutation: what the reference's DataLoader collates on the host)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int width, const int64_t* __restrict__ idx,
+                                                         int64_t n, float* __restrict__ dst) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * width) return;
+    const int64_t i = e / width;
+    const int c = (int)(e - i * width);
+    dst[e] = src[idx[i] * width + c];
+}
+
 // sum of squares of a flat fp32 buffer (gradient norm), fp64
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
     __shared__ double red[256];

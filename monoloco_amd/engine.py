@@ -112,6 +112,48 @@ def preprocess_rows(kps, kks, k_index, kps_r=None, device=None, z_met=10.0):
     return x
 
 
+def stereo_tied_rows(raw_all, ml, mr):
+    """filter_outputs' mask (reference process.py:319-327) as the list of kept pair rows, computed on the device:
+    raw_all (ml*mr, C) -> int32 device tensor of row numbers (several per tied left person, none for a NaN one)."""
+    dev = _require_cuda(raw_all.device)
+    raw_all = _dev_f32(raw_all, dev)
+    rows = torch.empty((ml * mr,), dtype=torch.int32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ml_stereo_tied_rows(_ptr(raw_all), int(raw_all.shape[1]), int(ml), int(mr), _ptr(rows), _ptr(count),
+                                              _stream(dev)))
+    return rows[:int(count.item())]
+
+
+def val_stats(raw, labels):
+    """The reference Trainer's host statistics (trainer.py:163-165, 213-232) of raw outputs (m, 9|10) against labels, in one
+    launch on the device -> dict (see ml_val_stats in include/monoloco_hip.h)."""
+    dev = _require_cuda(raw.device)
+    raw = _dev_f32(raw, dev)
+    labels = _dev_f32(labels, dev)
+    assert raw.shape[0] == labels.shape[0]
+    vals = (ctypes.c_double * 14)()
+    with torch.cuda.device(dev):
+        check(_lib.load().ml_val_stats(_ptr(raw), int(raw.shape[1]), _ptr(labels), int(labels.shape[1]), int(raw.shape[0]), vals,
+                                       _stream(dev)), train=True)
+    names = ('d', 'x', 'y', 'h', 'w', 'l', 'ori', 'aux', 'd_val', 'ori_rad', 'bi', 'bi%', 'std', 'aux_acc')
+    out = {k: vals[i] for i, k in enumerate(names)}
+    out['ori_val'] = out.pop('ori_rad') * 180 / 3.14        # the reference's 3.14 (losses.py:93)
+    return out
+
+
+def gather_rows(src, idx):
+    """src[idx] for a 2-D device tensor and an int64 index tensor on the same device (ml_gather_rows)."""
+    dev = _require_cuda(src.device)
+    assert src.dim() == 2 and src.dtype == torch.float32 and src.is_contiguous()
+    idx = idx.to(device=dev, dtype=torch.int64).contiguous()
+    out = torch.empty((idx.shape[0], src.shape[1]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ml_gather_rows(_ptr(src), int(src.shape[1]), _ptr(idx), int(idx.shape[0]), _ptr(out), _stream(dev)),
+              train=True)
+    return out
+
+
 def stereo_pairs(xl, xr):
     lib = _lib.load()
     dev = _require_cuda(xl.device)
@@ -342,6 +384,19 @@ class LocoEngine:
             check(_lib.load().ml_loco_epistemic_mono(self._h, _ptr(kps), m, fptr(kinv), int(n_dropout), float(p_dropout),
                                                      int(n_samples), int(seed), _ptr(epi), _ptr(passes), _stream(dev)))
         return (epi, passes) if want_passes else epi
+
+    def epistemic_inputs(self, inputs, n_dropout, p_dropout=0.2, n_samples=100, seed=1):
+        """The same spread from PRE-PROCESSED (m, 34) network inputs: the argument of the reference's
+        Loco.epistemic_uncertainty(inputs) (net.py:135-161) -> (m,) device tensor."""
+        dev = self.device
+        x = _dev_f32(inputs, dev)
+        assert x.dim() == 2 and x.shape[1] == self.in_features, "inputs must be (m, %d)" % self.in_features
+        m = x.shape[0]
+        epi = torch.empty((m,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.load().ml_loco_epistemic_inputs(self._h, _ptr(x), m, int(n_dropout), float(p_dropout), int(n_samples),
+                                                       int(seed), _ptr(epi), None, _stream(dev)))
+        return epi
 
     # -- measurement
     def profile_begin(self, max_launches=65536):

@@ -19,6 +19,12 @@ from .architectures import LocoModel, MonolocoModel
 from .process import extract_outputs_mono, packed_to_dict, unnormalize_bi
 
 
+def _f64_list(t):
+    """A column of fp32 results as Python floats (each the exact double of its fp32 value: what float(tensor[i]) yields)."""
+    a = t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float32)
+    return a.reshape(-1).astype(np.float64).tolist()
+
+
 class _LocoOut(dict):
     """The dictionary Loco.forward returns: a plain dict of the reference's keys, plus (as an attribute, not a key) the
     geometry block of the same keypoints that post_process would otherwise recompute."""
@@ -111,9 +117,7 @@ class Loco:
                 dic_out, geo_host = self._fetch_with_geometry(buf, out, geo, kps, kinv, 10)
             else:
                 # exact ties of the aux logit: the reference keeps every tied pair row (process.py:325)
-                raw = res['raw_all'].view(kps.shape[0], kps_r.shape[0], 10)
-                val = raw[:, :, -1]
-                rows = (val >= val.max(dim=1, keepdim=True).values).reshape(-1).nonzero().flatten().int()
+                rows = engine.stereo_tied_rows(res['raw_all'], kps.shape[0], kps_r.shape[0])   # filter_outputs' mask, on the device
                 out, _ = engine.extract_outputs_device(res['raw_all'], row_index=rows)
                 dic_out = packed_to_dict(out, 10)
             n_out = kps.shape[0]
@@ -121,7 +125,7 @@ class Loco:
             # combined aleatoric + epistemic spread by MC-dropout (reference net.py:126-128,135-161): a tensor
             dic_out['epi'] = self.engine.epistemic_mono(kps, kinv, self.n_dropout,
                                                         p_dropout=getattr(self.model, 'p_dropout', 0.2),
-                                                        n_samples=self.N_SAMPLES).cpu()
+                                                        n_samples=self.N_SAMPLES).cpu()   # == self.epistemic_uncertainty(inputs)
         else:
             dic_out['epi'] = [0.] * n_out
         if geo_host is not None:
@@ -132,6 +136,15 @@ class Loco:
             dic_out = _LocoOut(dic_out)
             dic_out._geo = (keypoints, kk_list, dic_out['d'], geo_host)
         return dic_out
+
+    def epistemic_uncertainty(self, inputs):
+        """Apply dropout at test time to obtain combined aleatoric + epistemic uncertainty (reference net.py:135-161).
+        `inputs`: the PRE-PROCESSED (m, 34) network inputs (preprocess_monoloco's result); returns the (m,) standard deviation
+        over n_dropout stochastic passes x N_SAMPLES Laplace draws, on self.device like the reference's."""
+        assert self.net in ('monoloco', 'monoloco_p', 'monoloco_pp'), "Not supported for MonStereo"
+        assert self.n_dropout > 0, "n_dropout must be positive (the reference returns the std of an empty tensor: nan)"
+        return self.engine.epistemic_inputs(inputs, self.n_dropout, p_dropout=getattr(self.model, 'p_dropout', 0.2),
+                                            n_samples=self.N_SAMPLES)
 
     def _forward_pp_staged(self, kps, kinv):
         """MonoLoco++ forward of one image with every buffer cached per person count: the keypoints go through a pinned staging
@@ -253,7 +266,6 @@ class Loco:
         g64 = geo.numpy().astype(np.float64)
         xyz_all = g64[:n_pred, 9:12]
         dist_all = np.sqrt(xyz_all[:, 0] ** 2 + xyz_all[:, 1] ** 2 + xyz_all[:, 2] ** 2)
-        bi_all = torch.as_tensor(dic_in['bi'], dtype=torch.float32).reshape(-1).numpy().astype(np.float64)
         uv = np.rint(g64[:, 0:6]).astype(int)
         uv_s, uv_h, uv_c = uv[:, 0:2], uv[:, 2:4], uv[:, 4:6]
         has_yaw = 'yaw' in dic_in
@@ -263,25 +275,33 @@ class Loco:
         # assemble the output column by column (the reference appends person by person, net.py:206-240); key creation
         # order is kept because the dictionary is dumped to json as it is
         if all_idxs:
+            # every per-person scalar comes out of ONE tolist() per column (a Python float of an fp32 value is that value as a
+            # double, exactly what float(tensor[i]) gives the reference); no per-person tensor indexing
+            d_l = _f64_list(d_all)
+            bi_l = _f64_list(dic_in['bi'])
+            dist_l = dist_all.tolist()
             epi = dic_in['epi']
+            epi_l = _f64_list(epi) if isinstance(epi, torch.Tensor) else [float(e) for e in epi]
+            identity = all_idxs == list(range(len(all_idxs)))   # no ground truth: input order
+            pick = (lambda col: col[:len(all_idxs)]) if identity else (lambda col: [col[i] for i in all_idxs])
             columns = [
-                ('boxes', [boxes[i] for i in all_idxs]),
-                ('confs', [0.035 * (boxes[i][-1]) / (float(bi_all[i]) / float(dist_all[i])) for i in all_idxs]),
-                ('dds_pred', [float(d_all[i]) for i in all_idxs]),
-                ('stds_ale', [float(bi_all[i]) for i in all_idxs]),
-                ('stds_epi', [float(epi[i]) for i in all_idxs]),
-                ('xyz_pred', xyz_all[all_idxs].tolist()),
-                ('uv_kps', [keypoints[i] for i in all_idxs]),
-                ('uv_centers', uv_c[all_idxs].tolist()),
-                ('uv_shoulders', uv_s[all_idxs].tolist()),
-                ('uv_heads', uv_h[all_idxs].tolist()),
+                ('boxes', pick(list(boxes))),
+                ('confs', [0.035 * (boxes[i][-1]) / (bi_l[i] / dist_l[i]) for i in all_idxs]),
+                ('dds_pred', pick(d_l)),
+                ('stds_ale', pick(bi_l)),
+                ('stds_epi', pick(epi_l)),
+                ('xyz_pred', pick(xyz_all.tolist())),
+                ('uv_kps', pick(list(keypoints))),
+                ('uv_centers', pick(uv_c.tolist())),
+                ('uv_shoulders', pick(uv_s.tolist())),
+                ('uv_heads', pick(uv_h.tolist())),
             ]
             if has_yaw:
                 yaw_pred, yaw_ego = dic_in['yaw']
-                columns.append(('angles', [float(yaw_pred[i]) for i in all_idxs]))
-                columns.append(('angles_egocentric', [float(yaw_ego[i]) for i in all_idxs]))
+                columns.append(('angles', pick(_f64_list(yaw_pred))))
+                columns.append(('angles_egocentric', pick(_f64_list(yaw_ego))))
                 # mono: the 'aux' key exists and stays empty (reference net.py:237-240)
-                columns.append(('aux', [float(dic_in['aux'][i]) for i in all_idxs] if has_aux else []))
+                columns.append(('aux', pick(_f64_list(dic_in['aux'])) if has_aux else []))
             for key, values in columns:
                 dic_out[key] = values
         for idx, idx_gt in matches:

@@ -161,7 +161,7 @@ class HipTrainer:
     @property
     def can_evaluate(self):
         """evaluate_batch runs for this shape (the mid route's kernels: hidden % 64 == 0)."""
-        return self.hidden % 64 == 0 and self.out_features * self.hidden <= 15360 and self.in_features <= 68
+        return bool(_lib.load().ml_trainer_can_eval(self._h))   # the library's own predicate (mid_possible, csrc/train.hip)
 
     def snapshot(self):
         """Keep the current parameters + running statistics aside on the device (the loop's best-epoch copy)."""

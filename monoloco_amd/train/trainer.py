@@ -18,6 +18,7 @@ from collections import defaultdict
 import torch
 from torch.utils.data import DataLoader, Dataset
 
+from .. import engine
 from ..network.architectures import LocoModel
 from .hip_trainer import HipTrainer
 
@@ -168,23 +169,18 @@ class Trainer:
         self._eval_eng, self._eval_version = None, -1
 
     def _forward_eval(self, inputs):
-        return self._eval_engine().forward_raw(inputs.to(self.device)).cpu()
+        """Raw eval-mode outputs on the device (the engine fallback for shapes ml_trainer_eval does not take)."""
+        return self._eval_engine().forward_raw(inputs.to(self.device))
 
     def _val_losses(self, out, lab):
-        """Validation values of the reference for raw outputs `out` and labels `lab` (CPU tensors): per task the
+        """Validation values of the reference for raw outputs `out` and labels `lab` (device tensors): per task the
         `losses_val` entries of CompositeLoss (losses.py:85-96: L1 from Laplace for d, angle error for ori, BCE for
         aux, L1 otherwise) and 'all' = the training-type multi-task loss on these outputs (losses.py:59-73 with unit
-        lambdas; trainer.py:195).  Host fallback of `_vals` for shapes the device evaluation does not take."""
-        plain = {'d_val': (out[:, 2:3] - lab[:, 3:4]).abs().mean().item()}
-        for t, c in (('x', 0), ('y', 1), ('h', 4), ('w', 5), ('l', 6)):
-            plain[t] = (out[:, c] - lab[:, c]).abs().mean().item()
-        ang = torch.atan2(out[:, 7], out[:, 8]) - torch.atan2(lab[:, 7], lab[:, 8])
-        plain['ori_val'] = ang.abs().mean().item() * 180 / 3.14
-        norm = 1 - out[:, 2:3] / lab[:, 3:4]
-        plain['d'] = (norm.abs() * torch.exp(-out[:, 3:4]) + 0.01 + out[:, 3:4] + 2).mean().item()   # losses.py:112-131
-        plain['ori'] = (out[:, 7:9] - lab[:, 7:9]).abs().mean().item()
-        plain['aux'] = (torch.nn.functional.binary_cross_entropy_with_logits(out[:, 9:10], lab[:, 10:11]).item()
-                        if 'aux' in self.tasks else 0.0)
+        lambdas; trainer.py:195) -- one launch on the device (ml_val_stats), for shapes the trainer's own evaluation does
+        not take."""
+        plain = engine.val_stats(out, lab)
+        if 'aux' not in self.tasks:
+            plain['aux'] = 0.0
         return self._vals(plain)
 
     def _vals(self, plain):
@@ -209,7 +205,7 @@ class Trainer:
     def _batch(self, phase, idx):
         x_all, y_all = self._rows[phase]
         idx = idx.to(self.device)
-        return x_all.index_select(0, idx), y_all.index_select(0, idx)
+        return engine.gather_rows(x_all, idx), engine.gather_rows(y_all, idx)
 
     def _eval_batch(self, x, y, want_outputs=False):
         """Validation values (and raw outputs) of the CURRENT weights on one device batch: on the trainer's own kernels where
@@ -217,10 +213,10 @@ class Trainer:
         if self.hip.can_evaluate:
             if want_outputs:
                 plain, raw = self.hip.evaluate_batch(x, y, want_outputs=True)
-                return self._vals(plain), raw.cpu()
+                return self._vals(plain), raw
             return self._vals(self.hip.evaluate_batch(x, y)), None
         out = self._forward_eval(x)
-        return self._val_losses(out, y.cpu()), out
+        return self._val_losses(out, y), out
 
     def train(self):
         since = time.time()
@@ -276,24 +272,20 @@ class Trainer:
         dic_err['val']['sigmas'] = [math.exp(v) for v in self.hip.log_sigmas.tolist()] if self.auto_tune_mtl else [0.] * len(self.tasks)
 
         def stats(inputs, labels, clst):
-            vals, out = self._eval_batch(inputs.to(self.device, torch.float32), labels.to(self.device, torch.float32),
-                                         want_outputs=True)
-            labels = labels.float()
+            labels = labels.to(self.device, torch.float32)
+            vals, out = self._eval_batch(inputs.to(self.device, torch.float32), labels, want_outputs=True)
             entry = dic_err['val'][clst]
             for t in self.tasks:
                 if t != 'aux':
                     entry[t] = vals[t]
             entry['all'] = vals['all']
-            errs = (out[:, 2:3] - labels[:, 3:4]).abs()
-            bis = torch.exp(out[:, 3:4]) * out[:, 2:3]                           # unnormalize_bi, process.py:125-133
-            entry['bi'] = bis.mean().item()
-            entry['bi%'] = float((errs <= bis).sum()) / errs.shape[0]
-            entry['std'] = errs.std()
-            if self.mode == 'mono':
-                entry['aux'] = 0
-            else:                                                                 # get_accuracy, trainer.py:384-389
-                mask = (torch.sigmoid(out[:, 9:10]) >= 0.5).float()
-                entry['aux'] = 1. - (mask - labels[:, 10:11]).abs().mean().item()
+            # bi = exp(s) d (unnormalize_bi, process.py:125-133), the share of |mu - d| <= bi, torch's unbiased std of the errors and
+            # the aux accuracy (get_accuracy, trainer.py:384-389): reduced on the device from the rows that are there anyway
+            ext = engine.val_stats(out, labels)
+            entry['bi'] = ext['bi']
+            entry['bi%'] = ext['bi%']
+            entry['std'] = torch.tensor(ext['std'], dtype=torch.float32)         # the reference stores the 0-dim tensor of .std()
+            entry['aux'] = 0 if self.mode == 'mono' else ext['aux_acc']
 
         inputs, labels, _, _ = dataset[0:len(dataset)]
         stats(inputs, labels, 'all')

@@ -340,7 +340,8 @@ def golden_train_h1024():
     """The reference's training loop body (trainer.py:150-161) at the HEADLINE width (hidden 1024, run.py:101) on a 512-row
     batch (the reference's default --bs, run.py:95: the HIP step's "mid" route) and a 4096-row batch (its large-batch
     route), dropout 0, from seeded weights: first-step outputs, losses of two steps, first-step clipped gradients -- every
-    narrow tensor in full, of each 1024 x 1024 matrix every 64th row (16 x 1024 values) and the tensor's max |g|.  The same
+    narrow tensor in full, of each 1024 x 1024 matrix every 64th row (16 x 1024 values), the row and column sums of all 1024
+    rows / columns, one matrix in full, and the tensor's max |g|.  The same
     run in fp64 gives the reference's own fp32 rounding noise per tensor ('_noise/<key>' = max |g32 - g64| / max |g64|), the
     yardstick the GPU test's tolerances are set by."""
     import itertools
@@ -384,8 +385,22 @@ def golden_train_h1024():
             g[tag + '_noise/' + k] = np.array(((v.double() - v64).abs().max() / v64.abs().max().clamp_min(1e-300)).item())
             if v.dim() == 2 and v.shape[0] == hidden and v.shape[1] == hidden:
                 g[tag + '_grad0/' + k] = v[::64].numpy().copy()
+                g[tag + '_grad0_f64/' + k] = v64[::64].float().numpy().copy()
+                # full-matrix coverage that stays small (round 4): row and column sums of ALL 1024 rows / columns (fp64 sums of
+                # the fp32 gradient, and of the fp64 run's) -- a wrong 32 x 64 tile anywhere moves 32 row sums and 64 column sums
+                g[tag + '_rowsum/' + k] = v.double().sum(1).numpy().copy()
+                g[tag + '_colsum/' + k] = v.double().sum(0).numpy().copy()
+                g[tag + '_rowsum64/' + k] = v64.sum(1).numpy().copy()
+                g[tag + '_colsum64/' + k] = v64.sum(0).numpy().copy()
+                g[tag + '_rowabs64/' + k] = v64.abs().sum(1).numpy().copy()     # the scale a sum's error is judged against
+                g[tag + '_colabs64/' + k] = v64.abs().sum(0).numpy().copy()
+                if tag == 'r512' and k == 'linear_stages.1.w1.weight':           # ... and ONE matrix in full
+                    g[tag + '_full/' + k] = v.numpy().copy()
             else:
                 g[tag + '_grad0/' + k] = v.numpy().copy()
+                g[tag + '_grad0_f64/' + k] = v64.float().numpy().copy()
+            # the reference's own fp32 run against its fp64 run, as an rms ratio (the yardstick beside '_noise', which is the max)
+            g[tag + '_noise_rms/' + k] = np.array(((v.double() - v64).pow(2).mean().sqrt() / v64.pow(2).mean().sqrt().clamp_min(1e-300)).item())
         g[tag + '_rows_seed'] = np.array([m, seed])
         print(tag, 'loss', g[tag + '_loss0'][0], 'noise: max', max(float(v) for k, v in g.items() if k.startswith(tag + '_noise/')))
     np.savez_compressed(os.path.join(OUT, 'golden_train_h1024.npz'), **g)

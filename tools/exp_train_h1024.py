@@ -19,16 +19,19 @@ for tag, routes in (('r512', ('exact', 'mid')), ('r4096', ('exact', 'mid', 'fast
         tr.step(torch.tensor(xb), torch.tensor(yb), update=False)
         res[route] = {k: v.numpy() for k, v in tr.grads().items()}
         tr.close()
-    print('==', tag, ' columns per route: max-rel  rms-rel  #>3e-4 | reference fp32-vs-fp64 max-rel')
+    print('==', tag, ' per route: rms error / rms(ref) against the reference fp32 run | against its fp64 run ;  last columns: the reference\'s own fp32-vs-fp64 rms and max')
     for k in res[routes[0]]:
         ref = g[tag + '_grad0/' + k]
+        ref64 = g[tag + '_grad0_f64/' + k].astype(np.float64)
         gmax = float(g[tag + '_gmax/' + k])
+        if gmax < 1e-12:
+            continue
         line = '%-38s' % k
         for route in routes:
             mine = res[route][k]
             if mine.shape != ref.shape:
                 mine = mine[::64]
-            d = np.abs(mine - ref)
-            line += ' | %8.2e %8.2e %5d' % (d.max() / max(gmax, 1e-30), np.sqrt(np.mean(d.astype(np.float64) ** 2)) / max(np.sqrt(np.mean(ref.astype(np.float64) ** 2)), 1e-30),
-                                          int((d > 3e-4 * gmax).sum()))
-        print(line + ' | %8.2e  (n=%d, gmax %.1e)' % (float(g[tag + '_noise/' + k]), ref.size, gmax))
+            r32 = np.sqrt(np.mean((mine.astype(np.float64) - ref) ** 2)) / max(np.sqrt(np.mean(ref.astype(np.float64) ** 2)), 1e-30)
+            r64 = np.sqrt(np.mean((mine.astype(np.float64) - ref64) ** 2)) / max(np.sqrt(np.mean(ref64 ** 2)), 1e-30)
+            line += ' | %s %8.2e %8.2e' % (route[0], r32, r64)
+        print(line + ' | ref %8.2e %8.2e' % (float(g[tag + '_noise_rms/' + k]), float(g[tag + '_noise/' + k])))
