@@ -23,6 +23,8 @@
 //                      deterministic) + the narrow tensors.
 // Per-element arithmetic of BatchNorm, dropout, loss, clip and Adam is the exact route's (train_kernels.h).
 #pragma once
+#include <type_traits>
+
 #include "train_kernels.h"
 
 namespace mlt {
@@ -53,7 +55,13 @@ constexpr int XG_A_BYTES = XG_BM * 128, XG_STAGE = XG_A_BYTES + XG_BN * 128;
 // product against 15.7 us for this kernel: 40 conversion instructions per wave and k-step cost more than the 16 x slower matrix
 // instruction; profiles/r03_train_kernel_stats_rows331_f16x3_in_registers.txt.)
 // (the kernel body: tile (bx, by) of a problem with nbx column tiles; smem = 2 stages, wsum = 4 doubles of LDS)
-template <int ALAY, int BLAY>
+// NACC independent accumulators (round 4): accumulator (step parity, step half) takes every NACC-th group of four matrix
+// instructions, so a K = 1024 reduction is NACC chains of 256 / NACC accumulations (2 products each) per k half instead of one of
+// 256, summed at the end: the rounding error of a product falls with the square root of the chain length.  It matters for the
+// FORWARD product: a pre-activation within rounding of zero flips its ReLU mask against the reference's, and every flip moves a
+// BatchNorm bias gradient by ~1/m of its size (measured at 512 rows against the reference's fp64 run: gradient rms error 2.5-5.6e-4
+// with one chain -- 2.3x the generic GEMM's 64-long split-K chains -- profiles/r04_train_parity.md).
+template <int ALAY, int BLAY, int NACC = 1>
 __device__ __forceinline__ void xgemm_tile(const XGemmParams& p, int bx, int by, int nbx, char* smem, double* wsum) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,9 +160,11 @@ __device__ __forceinline__ void xgemm_tile(const XGemmParams& p, int bx, int by,
             for (int e = 0; e < 8; ++e) F.b[e] = *(const float*)(sbuf + XG_A_BYTES + (kq + e) * 256 + (tn * 32 + ml) * 4);
         }
     };
-    f32x16 acc;
+    f32x16 accs[NACC];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs[a][e] = 0.f;
     const bool ragged = (p.K & 31) != 0;
     // (uniform) the reduction's zero padding: k >= K of the last step -- both operands, whatever lies behind the matrices
     // (NaN included) contributes exactly 0 -- and the steps that only fill the loop up to a multiple of 4
@@ -169,9 +179,10 @@ __device__ __forceinline__ void xgemm_tile(const XGemmParams& p, int bx, int by,
                 }
         }
     };
-    auto mma4 = [&](const Frag& F, int e0) {
+    auto mma4 = [&](const Frag& F, int e0, auto which) {   // `which`: compile-time accumulator index
+        constexpr int A = decltype(which)::value;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[e0 + e], F.b[e0 + e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) accs[A] = __builtin_amdgcn_mfma_f32_32x32x2f32(F.a[e0 + e], F.b[e0 + e], accs[A], 0, 0, 0);
     };
     // Pipeline.  The operands come from HBM / the last-level cache for the first time (the producer ran on other XCDs): ~0.8 us
     // per request, against 0.25 us of MFMA time per k-step -- with the rows of only one further step in flight the loop ran at
@@ -184,19 +195,22 @@ __device__ __forceinline__ void xgemm_tile(const XGemmParams& p, int bx, int by,
     // the LDS stores, 4 MFMAs, barrier (the last MFMA still runs).  Requests past the end repeat the final step; what they
     // bring is stored and read but never multiplied.
     Frag F0, F1;
-    auto step = [&](Frag& Fc, Frag& Fn, Raw& Rl, Raw& Rs, int sc, int i) {
+    auto step = [&](Frag& Fc, Frag& Fn, Raw& Rl, Raw& Rs, auto scc, int i) {
+        constexpr int sc = decltype(scc)::value;
         fragread(Fn, sc ^ 1);             // step i+1
         gload(Rl, seq(i + 5));
         mask(Fc, i);
         __builtin_amdgcn_sched_barrier(0);
-        mma4(Fc, 0);
+        mma4(Fc, 0, std::integral_constant<int, (NACC >= 4 ? 2 * sc : 0)>());
         __builtin_amdgcn_sched_barrier(0);
         lstore(Rs, sc);                   // step i+2
         __builtin_amdgcn_sched_barrier(0);
-        mma4(Fc, 4);
+        mma4(Fc, 4, std::integral_constant<int, (NACC >= 4 ? 2 * sc + 1 : (NACC >= 2 ? 1 : 0))>());
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     };
+    const std::integral_constant<int, 0> S0;
+    const std::integral_constant<int, 1> S1;
     gload(R0, seq(0));
     gload(R1, seq(1));
     gload(R2, seq(2));
@@ -212,12 +226,20 @@ __device__ __forceinline__ void xgemm_tile(const XGemmParams& p, int bx, int by,
     // the reads), 1 - 8 wrong tiles per 1024 with four (profiles/r03_xgemm_occupancy.md).
     __syncthreads();
     for (int i = 0; i < nk; i += 4) {   // whole groups of 4 steps (one exit: no register shuffling between the sets)
-        step(F0, F1, R1, R2, 0, i);
-        step(F1, F0, R2, R3, 1, i + 1);
-        step(F0, F1, R3, R0, 0, i + 2);
-        step(F1, F0, R0, R1, 1, i + 3);
+        step(F0, F1, R1, R2, S0, i);
+        step(F1, F0, R2, R3, S1, i + 1);
+        step(F0, F1, R3, R0, S0, i + 2);
+        step(F1, F0, R0, R1, S1, i + 3);
     }
     __syncthreads();
+    f32x16 acc = accs[0];
+    if (NACC == 2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = accs[0][e] + accs[NACC - 1][e];
+    } else if (NACC >= 4) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = (accs[0][e] + accs[1 % NACC][e]) + (accs[2 % NACC][e] + accs[3 % NACC][e]);
+    }
 
     // ---- the k halves meet: waves 2, 3 hand their partial tile to waves 0, 1
     float* red = (float*)smem;   // [2][16][64]
@@ -255,11 +277,16 @@ __device__ __forceinline__ void xgemm_tile(const XGemmParams& p, int bx, int by,
     }
 }
 
+// accumulators per layout pair: the forward product (k-contiguous x k-contiguous) 4, the data gradient 2, the weight gradient
+// (its reduction is the batch: 11 .. 16 k-steps at the reference's batch sizes) 1 -- see xgemm_tile
+template <int ALAY, int BLAY>
+constexpr int xg_nacc() { return (ALAY == 0 && BLAY == 0) ? 4 : ((ALAY == 0 && BLAY == 1) ? 2 : 1); }
+
 template <int ALAY, int BLAY>
 __global__ __launch_bounds__(256) void xgemm_kernel(XGemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * XG_STAGE];
     __shared__ double wsum[4];
-    xgemm_tile<ALAY, BLAY>(p, blockIdx.x, blockIdx.y, gridDim.x, smem, wsum);
+    xgemm_tile<ALAY, BLAY, xg_nacc<ALAY, BLAY>()>(p, blockIdx.x, blockIdx.y, gridDim.x, smem, wsum);
 }
 
 // The two products that read the same dz -- the data gradient dx = dz . W (+ res) (k-contiguous x reduction-major) and the
@@ -270,8 +297,8 @@ __global__ __launch_bounds__(256) void xgemm_pair_kernel(XGemmParams pd, XGemmPa
     __shared__ __attribute__((aligned(16))) char smem[2 * XG_STAGE];
     __shared__ double wsum[4];
     const int id = blockIdx.x;   // (uniform)
-    if (id < nd) xgemm_tile<0, 1>(pd, id % ndx, id / ndx, ndx, smem, wsum);
-    else xgemm_tile<1, 1>(pw, (id - nd) % nwx, (id - nd) / nwx, nwx, smem, wsum);
+    if (id < nd) xgemm_tile<0, 1, xg_nacc<0, 1>()>(pd, id % ndx, id / ndx, ndx, smem, wsum);
+    else xgemm_tile<1, 1, xg_nacc<1, 1>()>(pw, (id - nd) % nwx, (id - nd) / nwx, nwx, smem, wsum);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -89,6 +89,19 @@ def test_xgemm_epilogue(hip_lib, cuda_device):
     assert torch.allclose(ssq, per_wg, rtol=1e-12, atol=0)
 
 
+def _unit_masks(tr, m, hidden, stages=3):
+    """Which units a step left switched on (ReLU and dropout), from its own activations.  Buffer plan of csrc/train.hip:
+    a[0..S] = 0..S, t[0..S-1] = S+1..2S, ..., y3 = 4S + 4."""
+    rd = lambda i: tr.debug_read(i, (m, hidden))
+    a = [rd(i) for i in range(stages + 1)]
+    masks = [a[0] > 0]
+    for s in range(stages):
+        masks.append(rd(stages + 1 + s) > 0)
+        masks.append(a[s + 1] != a[s])                   # a_{s+1} = a_s + relu(.): unchanged exactly where the unit is off
+    masks.append(rd(4 * stages + 4) > 0)
+    return masks
+
+
 @pytest.mark.parametrize("mode,hidden,p_drop,rows", [('mono', 256, 0.0, None), ('stereo', 128, 0.2, None), ('mono', 1024, 0.2, None),
                                                      ('mono', 1024, 0.0, 512), ('stereo', 320, 0.0, 1500), ('mono', 1024, 0.0, 2048),
                                                      ('mono', 1024, 0.2, 3500)])
@@ -109,22 +122,33 @@ def test_mid_route_matches_exact_route(hip_lib, cuda_device, mode, hidden, p_dro
         assert tr.last_route == name
         sd = tr.state_dict()
         got[name] = (res, out.cpu().numpy(), {k: v.numpy() for k, v in tr.grads().items()},
-                     {k: v.numpy() for k, v in sd.items() if 'running' in k})
+                     {k: v.numpy() for k, v in sd.items() if 'running' in k}, _unit_masks(tr, x.shape[0], hidden))
         res2 = tr.step(x, y)          # and a real update step runs
         assert np.isfinite(res2['loss'])
         tr.close()
-    (r0, o0, g0, s0), (r1, o1, g1, s1) = got['exact'], got['mid']
+    (r0, o0, g0, s0, m0), (r1, o1, g1, s1, m1) = got['exact'], got['mid']
     assert not np.array_equal(o0, o1), "the mid route did not run"
     assert np.abs(o0 - o1).max() <= 2e-5 * max(1.0, np.abs(o0).max()), np.abs(o0 - o1).max()
     for k in r0:
         assert abs(r0[k] - r1[k]) <= 1e-4 * max(1.0, abs(r0[k])), (k, r0[k], r1[k])
     for k in s0:
         assert np.abs(s0[k] - s1[k]).max() <= 1e-5 * max(1.0, np.abs(s0[k]).max()), k
+    # Gradients.  Units whose pre-activation lies within rounding of zero get different ReLU masks from two fp32 implementations
+    # (test_relu_flip_accounting_at_headline_width); one flipped unit (i, j) switches dy[i][j] on or off: row j of that layer's
+    # weight gradient moves by one of its `rows` random-sign terms (~1 / sqrt(rows) of an entry, 2 % at 2048 rows), its BatchNorm
+    # bias gradient by ~1 / rows, everything below by ~1e-4 rms.  So: with IDENTICAL masks the routes must agree to 1e-3 of each
+    # tensor's largest entry and 1e-3 rms; with f flipped units the worst entry may move by a flipped term's size and the rms by 1e-3 per flip
+    # (seeded synthetic weights: a flip in the last block reaches the first layer's gradient amplified, measured 4e-3 with 4 flips).
+    n_flip = sum(int((a != b).sum()) for a, b in zip(m0, m1))
+    rows_n = x.shape[0]
+    assert n_flip <= 32, n_flip
+    worst_bar = 1e-3 if n_flip == 0 else max(1e-2, 2.0 / rows_n ** 0.5)
     gmax = max(np.abs(v).max() for v in g0.values())
-    for k in g0:   # (ReLU masks of pre-activations within rounding of 0 flip between two fp32 implementations: one flip moves a
-        # column sum over a few hundred rows by ~1 / rows of its size -- measured 4.9e-3 on a BatchNorm bias at 331 rows)
+    for k in g0:
         scale = max(np.abs(g0[k]).max(), 1e-4 * gmax)
-        assert np.abs(g0[k] - g1[k]).max() / scale <= 1e-2, (k, np.abs(g0[k] - g1[k]).max() / scale)
+        assert np.abs(g0[k] - g1[k]).max() / scale <= worst_bar, (k, n_flip, np.abs(g0[k] - g1[k]).max() / scale)
+        rms = np.sqrt(np.mean((g0[k].astype(np.float64) - g1[k]) ** 2)) / max(np.sqrt(np.mean(g0[k].astype(np.float64) ** 2)), 1e-4 * gmax)
+        assert rms <= 1e-3 * (1 + n_flip), (k, n_flip, rms)
 
 
 def test_mid_route_after_reload_and_route_switches(hip_lib, cuda_device):
@@ -226,34 +250,52 @@ def test_headline_width_steps_match_reference(hip_lib, cuda_device, tag, route):
     worst = {}
     for k, v in grads.items():
         ref_g = g[tag + '_grad0/' + k]
+        ref_64 = g[tag + '_grad0_f64/' + k].astype(np.float64)
         gmax = float(g[tag + '_gmax/' + k])
-        mine = v.numpy()
+        full = v.numpy()
+        mine = full
         if mine.shape != ref_g.shape:
-            mine = mine[::64]                              # the 1024 x 1024 matrices are stored as every 64th row
+            mine = mine[::64]                              # element-wise: every 64th row of the 1024 x 1024 matrices ...
         if gmax <= 1e-9 * gmax_all:      # a Linear bias in front of a BatchNorm: mathematically zero gradient, pure rounding noise
             assert np.abs(mine).max() <= 2e-7 * gmax_all, (k, np.abs(mine).max(), gmax_all)
             continue
+        if (tag + '_rowsum/' + k) in g:
+            # ... and EVERY row and column through its sum (round 4): a wrong 32 x 64 output tile anywhere -- the failure shape of
+            # round 3's prologue race -- moves 32 row sums and 64 column sums by ~a tile's worth of entries.  Bar per sum: 2e-3 of
+            # the sum of |entries| of that row / column (rounding of 1024 entries at 1e-4 relative each stays below 1e-5 of it;
+            # a garbage tile moves it by >= 3e-2)
+            f64 = full.astype(np.float64)
+            for axis, nm in ((1, 'row'), (0, 'col')):
+                got_s, ref_s, scale = f64.sum(axis), g[tag + '_%ssum/' % nm + k], g[tag + '_%sabs64/' % nm + k]
+                bad = np.abs(got_s - ref_s) / np.maximum(scale, 1e-30)
+                assert bad.max() <= 2e-3, (k, nm, int(bad.argmax()), float(bad.max()))
+        if (tag + '_full/' + k) in g:                       # one matrix element by element
+            fm = g[tag + '_full/' + k]
+            assert np.abs(full - fm).max() <= 3e-3 * gmax, (k, 'full', float(np.abs(full - fm).max() / gmax))
+            assert np.sqrt(np.mean((full.astype(np.float64) - fm) ** 2)) <= 1e-3 * np.sqrt(np.mean(fm.astype(np.float64) ** 2))
         rel = np.abs(mine - ref_g).max() / gmax
         rms = float(np.sqrt(np.mean((mine.astype(np.float64) - ref_g) ** 2)) / max(np.sqrt(np.mean(ref_g.astype(np.float64) ** 2)), 1e-30))
+        rms64 = float(np.sqrt(np.mean((mine.astype(np.float64) - ref_64) ** 2)) / max(np.sqrt(np.mean(ref_64 ** 2)), 1e-30))
         noise = float(g[tag + '_noise/' + k])
+        noise_rms = float(g[tag + '_noise_rms/' + k])
         n_out = int((np.abs(mine - ref_g) > max(3.0 * noise, 1e-3) * gmax).sum())
-        worst[k] = (float(rel), rms, noise, n_out)
-    print(tag, route, 'worst max-rel %.2e (%s), worst rms-rel %.2e (%s)' % (
+        worst[k] = (float(rel), rms, noise, n_out, rms64, noise_rms)
+    print(tag, route, 'worst max-rel %.2e (%s), worst rms-rel %.2e (%s), worst rms vs fp64 / reference\'s own %.2f (%s)' % (
         max(v[0] for v in worst.values()), max(worst, key=lambda k: worst[k][0]),
-        max(v[1] for v in worst.values()), max(worst, key=lambda k: worst[k][1])))
-    for k, (rel, rms, noise, n_out) in worst.items():
-        # Two bars per tensor.  The aggregate (rms error / rms of the tensor): 1e-3, or the reference's own fp32-vs-fp64 deviation
-        # where that is larger (w2.bias: its only gradient comes through the one-output head, 1e-5 of the others'); measured per
-        # route at 512 / 4096 rows (tools/exp_train_h1024.py): exact 2.4e-4 / 2.0e-4, mid 5.6e-4, fast 1.3e-4 -- a route that is
-        # wrong shows 3e-2 .. 1e-1 here (the xgemm prologue race of round 3 did).  The worst single element gets
-        # 3 x the reference's own fp32-vs-fp64 deviation with a floor of 1e-2 of the tensor's largest entry, and at most 4 elements of
-        # a tensor may lie beyond max(3 x that deviation, 1e-3) (measured: one or two, 4.6e-3 the largest): ReLU masks of
-        # pre-activations within rounding of zero flip between ANY two fp32 implementations, one flip moves a 512-row column sum
-        # (a BatchNorm bias gradient, a row of a weight gradient) by ~1/500 of its size, and which elements are hit changes with
-        # every change of summation order (measured on MI355X over several builds: 1.5e-4 .. 1.0e-3; the reference's own fp32 run
-        # sits up to 6.9e-4 from its fp64 run)
-        assert rel <= max(3.0 * noise, 1e-2) and n_out <= 4, (k, rel, noise, n_out)
+        max(v[1] for v in worst.values()), max(worst, key=lambda k: worst[k][1]),
+        max(v[4] / max(v[5], 2e-5) for v in worst.values()), max(worst, key=lambda k: worst[k][4] / max(worst[k][5], 2e-5))))
+    for k, (rel, rms, noise, n_out, rms64, noise_rms) in worst.items():
+        # Per tensor (DESIGN.md section 8 states the same numbers):
+        #  * worst single element <= max(3 x the reference's own fp32-vs-fp64 deviation, 3e-3) of the tensor's largest entry, and at
+        #    most 4 elements beyond max(3 x that deviation, 1e-3): a ReLU mask of a pre-activation within rounding of zero flips
+        #    between ANY two fp32 implementations, one flip moves a 512-row column sum (a BatchNorm bias gradient, a row of a weight
+        #    gradient) by ~1/500 of its size (the reference's own fp32 run sits up to 6.9e-4 from its fp64 run on such entries);
+        #  * rms error / rms of the tensor, against the reference's fp32 run: <= max(its own fp32-vs-fp64 rms, 1e-3); against its
+        #    fp64 run: <= 4 x the reference's own rms deviation from that run (floor 1e-4) -- i.e. the step is an fp32 implementation
+        #    of the same quality class as torch's, not merely "close to torch" (measured, profiles/r04_train_parity.md).
+        assert rel <= max(3.0 * noise, 3e-3) and n_out <= 4, (k, rel, noise, n_out)
         assert rms <= max(noise, 1e-3), (k, rms, noise)
+        assert rms64 <= 4.0 * max(noise_rms, 2.5e-5), (k, rms64, noise_rms)
     tr.close()
 
 
@@ -309,3 +351,53 @@ def test_trainer_evaluates_and_snapshots_on_the_device(hip_lib, cuda_device, mod
     back = tr.state_dict()
     assert all(torch.equal(kept[k], back[k]) for k in kept)
     tr.close()
+
+
+def test_relu_flip_accounting_at_headline_width(hip_lib, cuda_device):
+    """WHY gradients of two fp32 implementations differ by 1e-4 .. 6e-4 rms at hidden 1024 (round-3 review, weak 1a): the ReLU
+    masks.  An fp64 run of the same step (oracle/train_oracle.py's layers) gives every BatchNorm output before its ReLU; the
+    step's own activations give the masks it used.  Every disagreement must sit at a pre-activation within fp32 rounding of zero
+    (|pre| <= 2e-5 of the layer's rms), there are only a handful among 4.2 M units, and the routes differ in WHICH -- each flip
+    switches one unit's gradient on or off, which moves that column's BatchNorm bias gradient by ~1/512 of its size and, through
+    the dense layers below, every earlier tensor by ~1e-4 rms: the level and the layer-by-layer jump pattern of
+    tools/exp_train_h1024.py (profiles/r04_train_parity.md), and of the reference's own fp32-vs-fp64 columns there."""
+    import torch.nn.functional as F
+    from monoloco_amd.train import HipTrainer
+    g = dict(np.load(os.path.join(G, 'golden_train_h1024.npz')))
+    m, seed = [int(v) for v in g['r512_rows_seed']]
+    x, y = _batch('mono')
+    xb, yb = synth.big_train_batch(x.numpy(), y.numpy(), m, seed)
+    sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(seed, 34, 9, 1024).items()}
+    # fp64 pre-activations (architectures.py:50-66, 90-100 in train mode, dropout 0)
+    P = {k: v.double() for k, v in sd0.items()}
+    bn = lambda t, n: F.batch_norm(t, None, None, P[n + '.weight'], P[n + '.bias'], True, 0.1, 1e-5)
+    lin = lambda t, n: F.linear(t, P[n + '.weight'], P[n + '.bias'])
+    pre = []
+    t0 = bn(lin(torch.tensor(xb).double(), 'w1'), 'batch_norm1')
+    pre.append(t0)
+    a = torch.relu(t0)
+    for s in range(3):
+        p = 'linear_stages.%d.' % s
+        u = bn(lin(a, p + 'w1'), p + 'batch_norm1')
+        pre.append(u)
+        v = bn(lin(torch.relu(u), p + 'w2'), p + 'batch_norm2')
+        pre.append(v)
+        a = a + torch.relu(v)
+    pre.append(bn(lin(lin(a, 'w2'), 'w3'), 'batch_norm3'))
+    flips = {}
+    for route in ('exact', 'mid'):
+        tr = HipTrainer(sd0, p_dropout=0.0, lr=0.001, device=cuda_device, route=route)
+        tr.step(torch.tensor(xb), torch.tensor(yb), update=False)
+        masks = _unit_masks(tr, m, 1024)
+        tr.close()
+        n_flip, worst = 0, 0.0
+        for mk, pr in zip(masks, pre):
+            bad = mk != (pr > 0)
+            n_flip += int(bad.sum())
+            if bad.any():
+                worst = max(worst, float(pr[bad].abs().max() / pr.pow(2).mean().sqrt()))
+        flips[route] = (n_flip, worst)
+    print('ReLU mask disagreements with the fp64 run among %d units: %s' % (8 * m * 1024, flips))
+    for route, (n_flip, worst) in flips.items():
+        assert n_flip <= 64, (route, n_flip)             # a handful (measured: 0 .. 12) ...
+        assert worst <= 2e-5, (route, worst)             # ... all within fp32 rounding of zero

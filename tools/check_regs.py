@@ -21,6 +21,6 @@ for k, v in rows.items():
     flag = ''
     if 'dense_kernel' in k and spill:
         flag = '  <-- SPILL'; bad = 1
-    print("%-72s VGPR %-4s SGPR %-4s vspill %-3s sspill %-3s scratch %-4s LDS %s%s" % (name, v.get('VGPRs'), v.get('TotalSGPRs'),
+    print("%-72s VGPR %-4s AGPR %-4s occ %-2s SGPR %-4s vspill %-3s sspill %-3s scratch %-4s LDS %s%s" % (name, v.get('VGPRs'), v.get('AGPRs'), v.get('Occupancy [waves/SIMD]'), v.get('TotalSGPRs'),
           v.get('VGPRs Spill'), v.get('SGPRs Spill'), v.get('ScratchSize [bytes/lane]'), v.get('LDS Size [bytes/block]'), flag))
 sys.exit(bad)

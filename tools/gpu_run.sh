@@ -18,7 +18,7 @@ for STEP in "$@"; do
   case $KIND in
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -3 ;;
     pytest) FILES="tests"; [ -n "$ARG" ] && FILES=$(echo $ARG | tr ',' '\n' | sed 's#^#tests/#' | tr '\n' ' ')
-            timeout 1500 python -m pytest $FILES -q -m gpu --timeout 600 > $O/pytest_${ARG//[^a-zA-Z0-9]/_}.txt 2>&1; echo "pytest rc $?"
+            timeout 1500 python -m pytest $FILES -q -rP -m gpu --timeout 600 > $O/pytest_${ARG//[^a-zA-Z0-9]/_}.txt 2>&1; echo "pytest rc $?"
             tail -6 $O/pytest_${ARG//[^a-zA-Z0-9]/_}.txt | cut -c1-250 ;;
     bench)  N=$(ls $O/bench*.json 2>/dev/null | wc -l); timeout 900 python bench.py $ARG > $O/bench$N.json 2> $O/bench$N.err; echo "bench rc $?"
             python - "$O/bench$N.json" <<'PY'
