@@ -296,8 +296,11 @@ int ml_trainer_restore(ml_trainer* t, void* stream);
  * default 8; 0 leaves it); side_stream: 0 (default) = everything on the caller's stream, the data gradient and the weight
  * gradient of a Linear in ONE launch (xgemm_pair_kernel); 1 = the weight-gradient GEMMs, which only the optimizer needs, on an
  * internal side stream beside the data-gradient chain (events both ways; measured to pay from ~2000 rows); 2 = two launches per
- * Linear on the caller's stream (the A/B reference of 0); < 0 leaves it. */
-int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream);
+ * Linear on the caller's stream (the A/B reference of 0); < 0 leaves it.  dw_layout (large-batch route): 1 (default) = the
+ * weight-gradient GEMM dW = dz^T . x reads dz and x reduction-major, as the [batch][hidden] lines they already exist as
+ * (gfx950's transposing LDS read feeds the MFMA); 0 = through transposed copies of both (round 2's path: same bits, 2 ms more
+ * per 65536-row step); < 0 leaves it. */
+int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream, int dw_layout);
 int ml_trainer_destroy(ml_trainer* t);
 const char* ml_train_last_error(void);
 

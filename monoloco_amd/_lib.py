@@ -92,7 +92,7 @@ SIGNATURES = {
     'ml_trainer_snapshot': (c_int, [_P, _P]),
     'ml_trainer_restore': (c_int, [_P, _P]),
     'ml_trainer_debug_read': (c_int, [_P, c_int, POINTER(c_float), c_int64]),
-    'ml_trainer_set_tuning': (c_int, [_P, c_int, c_int]),
+    'ml_trainer_set_tuning': (c_int, [_P, c_int, c_int, c_int]),
     'ml_debug_xgemm': (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     'ml_trainer_destroy': (c_int, [_P]),
     'ml_train_last_error': (c_char_p, []),

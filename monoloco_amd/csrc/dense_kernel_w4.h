@@ -156,9 +156,21 @@ struct W4Frag {          // the fragments of one k32 step of one half (hi or lo)
 // HEAD == -3: as -2, and the reduction is split: p.ksplit work items per output tile, each over p.K of the operands'
 // p.K * p.ksplit columns, partial s of the output at y + s * M_pad * N floats (the weight-gradient GEMM: 16 output tiles,
 // K = the batch; a fixed-order reduction kernel adds the partials).
-template <int NSPLIT, bool RELU, bool RES, int HEAD>
+// TRANS (round 4; HEAD == -3 only): both operands are given REDUCTION-MAJOR -- x = [rows][M_pad] lines, w = [rows][N] lines, the
+// reduction runs over the rows (p.K * p.ksplit of them): the weight-gradient GEMM dW = dz^T . x reads dz and x as the [batch][H]
+// lines they already exist as (the data-gradient operand and the forward's activations), no transposed copies (tlines_kernel:
+// 2 ms of the 65536-row step).  A k32 step = 32 batch rows; per operand and slot 32 x 512 B (the hi or the lo halves of 256
+// columns) = the same 16 KiB: the DMA fetches two batch rows per instruction (lane = row * 32 + 16-byte chunk of the 512 B), the
+// LDS image is [k][256 columns] fp16, and the MFMA fragments (lane = operand row, 8 consecutive k) come out of it through
+// ds_read_b64_tr_b16, gfx950's transposing LDS read (two per 8-k fragment: lane s of a 16-lane group supplies the address of
+// columns 4 (s & 3) .. + 3 of k row s >> 2 and receives column s over the 4 k rows; semantics probed by tools/ubench/tr16.hip).
+// 64-byte column chunks are XOR-swizzled with k & 3 (on the DMA's source address and on the read address): the 4 k rows of a read
+// fall into the 4 different 64-byte windows of the 256-byte bank line.  Same k grouping per MFMA as the transposed-lines path:
+// bit-identical results.
+template <int NSPLIT, bool RELU, bool RES, int HEAD, bool TRANS = false>
 __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_kernel_w4(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[W4_LDS];
+    static_assert(!TRANS || HEAD == -3, "reduction-major operands: the split-K weight-gradient variant only");
     constexpr bool SPLIT = NSPLIT == 3;
     constexpr bool AUX = HEAD == -1;
     constexpr bool F32OUT = HEAD <= -2;
@@ -174,7 +186,9 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int otiles = (p.M_pad / BM) * NT;                   // output tiles
     const int ntiles = SPLITK ? otiles * p.ksplit : otiles;  // work items
     const int q8 = ntiles >> 3, r8 = ntiles & 7;
-    const size_t rowb = SPLITK ? (size_t)p.K * p.ksplit * 4 : (size_t)p.K * 4;
+    // bytes per operand row: a row of the k range (normal) / a batch row of all columns (TRANS: x and w may differ in width)
+    const size_t rowb = TRANS ? (size_t)p.N * 4 : (SPLITK ? (size_t)p.K * p.ksplit * 4 : (size_t)p.K * 4);
+    const size_t rowbx = TRANS ? (size_t)p.M_pad * 4 : rowb;
     const size_t yrowb = (size_t)p.N * 4;
     const int nk = p.K / 32;   // even (K % 64 == 0, guaranteed by the host)
     const float descale = p.descale_ptr ? *p.descale_ptr : p.descale;   // (before the first LDS-DMA: an ordinary load)
@@ -183,10 +197,17 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // lane -> (row = lane / 4, position = lane % 4); the LDS image is lane-linear, the bank swizzle
     // chunk ^= (row >> 2) & 3 is applied on the SOURCE address (and again on the ds_read address).
     // Source address = wave-uniform 64-bit base (request-stream pointer) + one of four lane offsets (+ 64 for lo halves).
-    unsigned goffq[4];
+    unsigned goffq[4], goffx[TRANS ? 4 : 1];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        goffq[q] = (unsigned)(((lane >> 2) + 16 * q) * (int)rowb + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+    for (int q = 0; q < 4; ++q) {
+        if (TRANS) {   // instruction q: batch rows 2q, 2q + 1 of this wave's 8; lane = row * 32 + (64-byte chunk * 4 + 16-byte part)
+            const int kr = 2 * q + (lane >> 5), ch = (lane >> 2) & 7;
+            goffq[q] = (unsigned)(kr * (int)rowb + ((ch ^ (kr & 3)) * 128) + (lane & 3) * 16);
+            goffx[q] = (unsigned)(kr * (int)rowbx + ((ch ^ (kr & 3)) * 128) + (lane & 3) * 16);
+        } else {
+            goffq[q] = (unsigned)(((lane >> 2) + 16 * q) * (int)rowb + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+        }
+    }
     // instruction q (0..3 = W rows, 4..7 = X rows) of this wave's share of ring slot `slot` (odd = lo halves) from the
     // request-stream pointers (rw, rx) = this wave's first row of the k32 step being requested
     // One asm statement per instruction: SGPR base + 32-bit lane offset + immediate (hipcc's own lowering of the builtin
@@ -201,12 +222,13 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         // (the instruction's immediate offset is added to the global AND to the LDS address: the lo halves' + 64 is taken
         //  out of M0 again)
         const int ldsa = dma_base + slot * W4_SLOT + (q < 4 ? 0 : W4_XOFF) + (q & 3) * 1024 - ((slot & 1) ? 64 : 0);
+        const unsigned go = (TRANS && q >= 4) ? goffx[TRANS ? (q & 3) : 0] : goffq[q & 3];
         if (slot & 1)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:64"
-                         :: "v"(goffq[q & 3]), "s"(q < 4 ? rw : rx), "s"(ldsa) : "memory");
+                         :: "v"(go), "s"(q < 4 ? rw : rx), "s"(ldsa) : "memory");
         else
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"
-                         :: "v"(goffq[q & 3]), "s"(q < 4 ? rw : rx), "s"(ldsa) : "memory");
+                         :: "v"(go), "s"(q < 4 ? rw : rx), "s"(ldsa) : "memory");
     };
 
     // ---- fragment addressing: MFMA 32x32x16, lane l supplies row (l & 31), k = 8 * (l >> 5) .. + 7 of the k16 step,
@@ -217,10 +239,42 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int xrow = W4_XOFF + (wm * 128 + ml) * 64;
     const int c0 = ((0 + hh) ^ swz) * 16, c1 = ((2 + hh) ^ swz) * 16;
 
+    // TRANS: lane (16-lane group g, s = lane & 15) of a transposing read addresses k row 8 (g >> 1) + (s >> 2) (+ 16 kk + 4 h
+    // per instruction), columns 32 it + 16 (g & 1) + 4 (s & 3) .. + 3 of the wave's 128: 64-byte chunk 4 wn + it, swizzled by k & 3
+    // = s >> 2, i.e. (it ^ (s >> 2)) in its low two bits -- one lane offset per it
+    int troff[TRANS ? 4 : 1];
+    if (TRANS) {
+        const int g = lane >> 4, sl = lane & 15;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            troff[it] = (8 * (g >> 1) + (sl >> 2)) * 512 + ((it ^ (sl >> 2)) * 64) + (16 * (g & 1) + 4 * (sl & 3)) * 2;
+    }
+    typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    struct H8Pair { fp16x4 a, b; };
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds0 = (lds_char*)smem;
+    auto tr_read8 = [&](int off) -> half8 {   // k rows +0..3 and +4..7: the 8 k values of this lane's operand row
+        H8Pair pr;
+        pr.a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(lds0 + off));
+        pr.b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(lds0 + off + 4 * 512));
+        return __builtin_bit_cast(half8, pr);
+    };
+
     // read quarter `qr` (0..7) of a fragment set from slot `slot`: 2 ds_read_b128 (both k16 steps of one 32-row tile)
     auto read_q = [&](W4Frag& f, int slot, int qr) {
         if (W4_DBG(8)) return;
         const char* sb = smem + slot * W4_SLOT;
+        if (TRANS) {
+            const int ob = slot * W4_SLOT + (qr < 4 ? wn * 256 : W4_XOFF + wm * 256) + troff[TRANS ? (qr & 3) : 0];
+            if (qr < 4) {
+                f.w[qr][0] = tr_read8(ob);
+                f.w[qr][1] = tr_read8(ob + 16 * 512);
+            } else {
+                f.x[qr - 4][0] = tr_read8(ob);
+                f.x[qr - 4][1] = tr_read8(ob + 16 * 512);
+            }
+            return;
+        }
         if (qr < 4) {
             f.w[qr][0] = *(const half8*)(sb + wrow + qr * 2048 + c0);
             f.w[qr][1] = *(const half8*)(sb + wrow + qr * 2048 + c1);
@@ -256,17 +310,26 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // request is conditional and every phase has the same vmcnt arithmetic.
     int rq_vb = vb, rq_left = nk;
     const size_t wave_rows = (size_t)(w * 64) * rowb;
-    const char* rq_w = p.w + (size_t)n0 * rowb + wave_rows + (size_t)ks0 * p.K * 4;   // (k offset in bytes: 128 per k32 block)
-    const char* rq_x = p.x + (size_t)m0 * rowb + wave_rows + (size_t)ks0 * p.K * 4;
+    // TRANS: first batch row of the work item's k range + this wave's 8 rows of every k32 step; column tile = byte n0 * 4 of a row
+    auto rq_w_of = [&](int tn0, int tks) -> const char* {
+        return TRANS ? p.w + ((size_t)tks * p.K + w * 8) * rowb + (size_t)tn0 * 4
+                     : p.w + (size_t)tn0 * rowb + wave_rows + (size_t)tks * p.K * 4;   // (k offset in bytes: 128 per k32 block)
+    };
+    auto rq_x_of = [&](int tm0, int tks) -> const char* {
+        return TRANS ? p.x + ((size_t)tks * p.K + w * 8) * rowbx + (size_t)tm0 * 4
+                     : p.x + (size_t)tm0 * rowb + wave_rows + (size_t)tks * p.K * 4;
+    };
+    const char* rq_w = rq_w_of(n0, ks0);
+    const char* rq_x = rq_x_of(m0, ks0);
     auto rq_advance = [&]() {   // after both slots of a k32 step have been requested
-        rq_w += LINE;
-        rq_x += LINE;
+        rq_w += TRANS ? 32 * rowb : (size_t)LINE;
+        rq_x += TRANS ? 32 * rowbx : (size_t)LINE;
         if (--rq_left == 0) {
             if (rq_vb + (int)gridDim.x < ntiles) rq_vb += (int)gridDim.x;
             int rm0, rn0, rks;
             tile_of(rq_vb, rm0, rn0, rks);
-            rq_w = p.w + (size_t)rn0 * rowb + wave_rows + (size_t)rks * p.K * 4;
-            rq_x = p.x + (size_t)rm0 * rowb + wave_rows + (size_t)rks * p.K * 4;
+            rq_w = rq_w_of(rn0, rks);
+            rq_x = rq_x_of(rm0, rks);
             rq_left = nk;
         }
     };

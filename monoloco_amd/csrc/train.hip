@@ -109,6 +109,10 @@ struct ml_trainer {
     std::vector<hipEvent_t> ev_dz, ev_w;
     int side_stream = 0;             // ml_trainer_set_tuning: 1 = weight gradients on the side stream (measured: pays from ~2000 rows)
     int ssq_per_mat = 0;
+    int dw_trans = 1;                // weight-gradient GEMM operands: 1 = reduction-major lines as they lie (dense_kernel_w4<.., -3, true>),
+                                     // 0 = transposed copies (tlines_kernel; the round-2 path, kept for the bit-identity test)
+    char* dzl = nullptr;             // [capT][H] lines: the scaled gradient dz of the layer being back-propagated
+    int64_t pad_m = -1;              // rows [pad_m, round_up(pad_m, 64 ks)) of every line buffer are zero
     int apply_cols = 8;              // columns a workgroup of the column-owner kernels takes (4 | 8 | 16): ml_trainer_set_tuning
     int pair_gemm = 1;               // both gradients of a Linear in one launch (xgemm_pair_kernel); side_stream = 2 turns it off
     double* h_loss = nullptr;        // pinned: up to HL_GRID x LOSS_NV partial sums
@@ -266,6 +270,7 @@ struct Block {  // Linear + BatchNorm + ReLU + Dropout
     int bn_idx;
     int in_dim;
     const float* x = nullptr;  // input activations (m x in_dim)
+    const char* x_lines = nullptr;   // ... and, on the large-batch route, the same activations as lines (the forward's GEMM operand)
     float* z = nullptr;        // pre-BN (m x H)
     float* y = nullptr;        // output (m x H) (residual already added if any)
     uint32_t site;
@@ -324,24 +329,44 @@ int fast_linear_bwd_data(ml_trainer* t, hipStream_t st, const char* dz_lines, co
     return launch_fast_gemm(t, st, dz_lines, t->wl[slot], t->zero_bias, sc + 4, dx, m, accumulate);
 }
 
-// dz (m x H fp32; its max |.| already in the Linear's scale word 3) -> scaled lines (lbufs[0], for dx) and scaled
-// transposed lines (tl_dz, for dW); publishes both descales
-void fast_grad_lines(ml_trainer* t, hipStream_t st, const float* dz, int64_t m, int slot) {
+int ensure_tl(ml_trainer* t) {   // the comparison path's transposed operand copies
+    if (t->tl_dz) return 0;
+    T_TRY(hipMalloc((void**)&t->tl_dz, (size_t)t->capT * t->H * 4));
+    T_TRY(hipMalloc((void**)&t->tl_x, (size_t)t->capT * t->H * 4));
+    return 0;
+}
+
+// dz (m x H fp32; its max |.| already in the Linear's scale word 3) -> scaled lines (t->dzl: the operand of dx = dz . W and,
+// read reduction-major, of dW = dz^T . x); publishes both descales.  Comparison path (dw_trans == 0): also the transposed lines.
+int fast_grad_lines(ml_trainer* t, hipStream_t st, const float* dz, int64_t m, int slot) {
+    if (t->dw_trans) {
+        hipLaunchKernelGGL(mlt::grad_lines_kernel, dim3(nblk(m * t->H / 8)), dim3(256), 0, st, dz, m, t->H, t->wsc_base + 8 * slot, t->dzl);
+        return 0;
+    }
+    int rc = ensure_tl(t);
+    if (rc) return rc;
     const int64_t mT = (m + 64 * t->ks - 1) / (64 * t->ks) * (64 * t->ks);
     hipLaunchKernelGGL(mlt::tlines_kernel<true>, dim3(t->H / 64, (unsigned)(mT / 64)), dim3(256), 0, st, dz, m, t->H, mT,
-                       t->wsc_base + 8 * slot, t->tl_dz, t->lbufs[0]);
+                       t->wsc_base + 8 * slot, t->tl_dz, t->dzl);
+    return 0;
 }
 
 // dW (H x H) = dz^T . x on the 3-product kernel: both operands as transposed lines (the reduction runs over the batch),
 // the batch split over t->ks work items per output tile, partials added in a fixed order.
-int fast_linear_bwd_weight(ml_trainer* t, hipStream_t st, const float* x, const std::string& lin, int64_t m, int slot) {
+int fast_linear_bwd_weight(ml_trainer* t, hipStream_t st, const float* x, const char* x_lines, const std::string& lin, int64_t m,
+                           int slot) {
     const int H = t->H;
     const int64_t mT = (m + 64 * t->ks - 1) / (64 * t->ks) * (64 * t->ks);
-    hipLaunchKernelGGL(mlt::tlines_kernel<false>, dim3(H / 64, (unsigned)(mT / 64)), dim3(256), 0, st, x, m, H, mT, (float*)nullptr,
-                       t->tl_x, (char*)nullptr);
+    const bool trans = t->dw_trans && x_lines;
+    if (!trans) {
+        int rc = ensure_tl(t);
+        if (rc) return rc;
+        hipLaunchKernelGGL(mlt::tlines_kernel<false>, dim3(H / 64, (unsigned)(mT / 64)), dim3(256), 0, st, x, m, H, mT, (float*)nullptr,
+                           t->tl_x, (char*)nullptr);
+    }
     mlk::DenseParams p;
-    p.x = t->tl_dz;
-    p.w = t->tl_x;
+    p.x = trans ? t->dzl : t->tl_dz;      // [mT][H] lines of dz (rows >= m zero) | [H][mT] transposed lines
+    p.w = trans ? x_lines : t->tl_x;      // the forward's lines of the layer input | its transposed copy
     p.bias = nullptr;
     p.bias_scaled = t->zero_bias;
     p.res = nullptr;
@@ -358,8 +383,9 @@ int fast_linear_bwd_weight(ml_trainer* t, hipStream_t st, const float* x, const 
     p.head_w = nullptr;
     p.head_part = nullptr;
     const int items = (H / mlk::BM) * (H / mlk::BN) * t->ks;
-    hipLaunchKernelGGL((mlk::dense_kernel_w4<3, false, false, -3>), dim3(items < t->n_cu ? items : t->n_cu), dim3(mlk::W4_THREADS), 0,
-                       st, p);
+    const dim3 wg_grid(items < t->n_cu ? items : t->n_cu), wg_block(mlk::W4_THREADS);
+    if (trans) hipLaunchKernelGGL((mlk::dense_kernel_w4<3, false, false, -3, true>), wg_grid, wg_block, 0, st, p);
+    else hipLaunchKernelGGL((mlk::dense_kernel_w4<3, false, false, -3>), wg_grid, wg_block, 0, st, p);
     hipLaunchKernelGGL(mlt::splitk_reduce_kernel, dim3(nblk((int64_t)H * H)), dim3(256), 0, st, (const float*)t->d_splitk, t->ks, H, H,
                        H, (const float*)nullptr, 0, G(t, lin + ".weight"));
     if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "fast weight-gradient GEMM launch failed");
@@ -457,8 +483,8 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
         hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)s_dz, H,
                            G(t, b.lin + ".bias"));
         if (slot >= 0) {
-            fast_grad_lines(t, st, dout, m, slot);
-            return fast_linear_bwd_weight(t, st, b.x, b.lin, m, slot);
+            if ((rc = fast_grad_lines(t, st, dout, m, slot))) return rc;
+            return fast_linear_bwd_weight(t, st, b.x, b.x_lines, b.lin, m, slot);
         }
         if (slot == -2 && skinny_ok(t, b.in_dim))   // the input layer: dW1 (H x in) = dz^T . x
             return skinny_dw(t, st, b.x, b.in_dim, b.in_dim, dout, m, G(t, b.lin + ".weight"), 1);
@@ -489,22 +515,27 @@ int ensure_cap(ml_trainer* t, int64_t m) {
     for (char* p : t->lbufs) (void)hipFree(p);
     t->lbufs.clear();
     if (t->H % 256 == 0) {
-        for (int i = 0; i < 2 * t->S + 2; ++i) {
-            char* p = nullptr;
-            T_TRY(hipMalloc((void**)&p, (size_t)m * t->H * 4));
-            t->lbufs.push_back(p);
-        }
         // weight gradient: (H / 256)^2 output tiles, the batch reduction split so that the work items about fill the chip
-        // (at most 32: the partial buffer); the transposed operands are zero-padded to whole 64-row k-steps per split
+        // (at most 32: the partial buffer); its operands are zero-padded to whole 64-row k-steps per split: the line buffers
+        // (the forward's activations and the gradient dz, read reduction-major) are allocated and zeroed up to capT rows
         const int otiles = (t->H / 256) * (t->H / 256);
         t->ks = 1;
         while (t->ks < 32 && otiles * t->ks * 2 <= 256) t->ks *= 2;
         t->capT = (m + 64 * t->ks - 1) / (64 * t->ks) * (64 * t->ks);
+        for (int i = 0; i < 2 * t->S + 2; ++i) {
+            char* p = nullptr;
+            T_TRY(hipMalloc((void**)&p, (size_t)t->capT * t->H * 4));
+            T_TRY(hipMemset(p, 0, (size_t)t->capT * t->H * 4));
+            t->lbufs.push_back(p);
+        }
+        if (t->dzl) (void)hipFree(t->dzl);
+        t->dzl = nullptr;
+        T_TRY(hipMalloc((void**)&t->dzl, (size_t)t->capT * t->H * 4));
+        T_TRY(hipMemset(t->dzl, 0, (size_t)t->capT * t->H * 4));
+        t->pad_m = -1;
         if (t->tl_dz) (void)hipFree(t->tl_dz);
         if (t->tl_x) (void)hipFree(t->tl_x);
-        t->tl_dz = t->tl_x = nullptr;
-        T_TRY(hipMalloc((void**)&t->tl_dz, (size_t)t->capT * t->H * 4));
-        T_TRY(hipMalloc((void**)&t->tl_x, (size_t)t->capT * t->H * 4));
+        t->tl_dz = t->tl_x = nullptr;   // (the transposed copies of the comparison path: allocated on first use, ensure_tl)
         if (t->wl.empty()) {
             hipDeviceProp_t prop;
             int dev = 0;
@@ -959,7 +990,7 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (hipEvent_t e : t->ev_dz) (void)hipEventDestroy(e);
     for (hipEvent_t e : t->ev_w) (void)hipEventDestroy(e);
     if (t->st2) (void)hipStreamDestroy(t->st2);
-    void* ptrs[] = {t->w_snap, t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    void* ptrs[] = {t->w_snap, t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->dzl, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -1130,10 +1161,11 @@ int ml_trainer_last_val_values(const ml_trainer* t, double* host10) {
     return ML_OK;
 }
 
-int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream) {
+int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream, int dw_layout) {
     if (!t || (apply_cols != 0 && apply_cols != 4 && apply_cols != 8 && apply_cols != 16))
         return tfail(ML_ERR_ARG, "apply_cols must be 4, 8 or 16 (0: unchanged)");
     if (apply_cols) t->apply_cols = apply_cols;
+    if (dw_layout >= 0) t->dw_trans = dw_layout ? 1 : 0;   // large-batch route: weight-gradient operands reduction-major (1) | transposed copies (0)
     if (side_stream >= 0) {   // 0: both gradients of a Linear in one launch (default); 1: weight gradients on the side stream; 2: two launches
         t->side_stream = side_stream == 1 ? 1 : 0;
         t->pair_gemm = side_stream == 0 ? 1 : 0;
@@ -1201,7 +1233,19 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     // fast forward path: the activations that feed an H x H Linear also exist as lines (la[s] = a_s, lt[s] = t_s, ly2 = y2);
     // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
     const bool fast = route == 1;
-    if (fast) T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 2) * 32, st));
+    if (fast) {
+        T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 2) * 32, st));
+        if (t->pad_m != m) {
+            // the weight-gradient GEMMs reduce over whole 64-row k-steps per split: rows m .. mT of every line buffer must be
+            // zero (a smaller batch than the last one leaves old rows there); the writers only touch rows < m
+            const int64_t mT = (m + 64 * t->ks - 1) / (64 * t->ks) * (64 * t->ks);
+            if (mT > m) {
+                for (char* lb : t->lbufs) T_TRY(hipMemsetAsync(lb + (size_t)m * H * 4, 0, (size_t)(mT - m) * H * 4, st));
+                T_TRY(hipMemsetAsync(t->dzl + (size_t)m * H * 4, 0, (size_t)(mT - m) * H * 4, st));
+            }
+            t->pad_m = m;
+        }
+    }
     auto la = [&](int s) { return fast ? t->lbufs[s] : (char*)nullptr; };
     auto lt = [&](int s) { return fast ? t->lbufs[S + 1 + s] : (char*)nullptr; };
     char* ly2 = fast ? t->lbufs[2 * S + 1] : nullptr;
@@ -1210,10 +1254,10 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     for (int s = 0; s < S; ++s) {
         const std::string p = "linear_stages." + std::to_string(s) + ".";
         sa[s].lin = p + "w1"; sa[s].bn = p + "batch_norm1"; sa[s].bn_idx = 1 + 2 * s; sa[s].in_dim = H;
-        sa[s].x = a[s]; sa[s].z = za[s]; sa[s].y = tt[s]; sa[s].site = 1 + 2 * s;
+        sa[s].x = a[s]; sa[s].x_lines = la(s); sa[s].z = za[s]; sa[s].y = tt[s]; sa[s].site = 1 + 2 * s;
         if ((rc = block_fwd(t, st, sa[s], m, nullptr, la(s), lt(s), fast ? 2 * s : -1))) return rc;
         sb[s].lin = p + "w2"; sb[s].bn = p + "batch_norm2"; sb[s].bn_idx = 2 + 2 * s; sb[s].in_dim = H;
-        sb[s].x = tt[s]; sb[s].z = zb[s]; sb[s].y = a[s + 1]; sb[s].site = 2 + 2 * s;
+        sb[s].x = tt[s]; sb[s].x_lines = lt(s); sb[s].z = zb[s]; sb[s].y = a[s + 1]; sb[s].site = 2 + 2 * s;
         if ((rc = block_fwd(t, st, sb[s], m, a[s], lt(s), la(s + 1), fast ? 2 * s + 1 : -1))) return rc;  // a_{s+1} = a_s + block(t_s)
     }
     if (fast) {
@@ -1224,7 +1268,8 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     if (!(skinny && skinny_heads(t, st, y2, m, P(t, "w_aux.weight"), P(t, "w_aux.bias"), 1, t->d_out + (C - 1), C)))
         if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
     Block b3;
-    b3.lin = "w3"; b3.bn = "batch_norm3"; b3.bn_idx = 2 * S + 1; b3.in_dim = H; b3.x = y2; b3.z = z3; b3.y = y3; b3.site = 2 * S + 1;
+    b3.lin = "w3"; b3.bn = "batch_norm3"; b3.bn_idx = 2 * S + 1; b3.in_dim = H; b3.x = y2; b3.x_lines = ly2; b3.z = z3; b3.y = y3;
+    b3.site = 2 * S + 1;
     if ((rc = block_fwd(t, st, b3, m, nullptr, ly2, nullptr, fast ? 2 * S + 1 : -1))) return rc;
     if (!(skinny && skinny_heads(t, st, y3, m, P(t, "w_fin.weight"), P(t, "w_fin.bias"), C - 1, t->d_out, C)))
         if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
@@ -1254,8 +1299,8 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     }
     if (rc) return rc;
     // fast path: the H x H data and weight gradients run on the 3-product kernel as well; dz goes there as scaled lines
-    // (lbufs[0]: the forward's line buffers are free by now) and transposed lines (tl_dz), see block_bwd
-    char* dzl = fast ? t->lbufs[0] : nullptr;
+    // (t->dzl; the forward's line buffers stay: they are the weight-gradient GEMMs' second operand), see block_bwd
+    char* dzl = fast ? t->dzl : nullptr;
     if ((rc = block_bwd(t, st, b3, m, gA, xhat, fast ? 2 * S + 1 : -1))) return rc;                              // gA = dz3
     if (fast) rc = fast_linear_bwd_data(t, st, dzl, "w3", gB, m, 2 * S + 1, false);
     else rc = linear_bwd_data(t, st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0);                          // gB = dy2
@@ -1273,8 +1318,8 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red, H, G(t, "w2.bias"));
     if (fast) {
         hipLaunchKernelGGL(mlt::wmax_kernel, dim3(1024), dim3(256), 0, st, (const float*)gB, m * H, t->wsc_base + 8 * (2 * S) + 3);
-        fast_grad_lines(t, st, gB, m, 2 * S);
-        if ((rc = fast_linear_bwd_weight(t, st, a[S], "w2", m, 2 * S))) return rc;
+        if ((rc = fast_grad_lines(t, st, gB, m, 2 * S))) return rc;
+        if ((rc = fast_linear_bwd_weight(t, st, a[S], la(S), "w2", m, 2 * S))) return rc;
         rc = fast_linear_bwd_data(t, st, dzl, "w2", gA, m, 2 * S, false);
     } else {
         if ((rc = linear_bwd_weight(t, st, gB, H, a[S], H, G(t, "w2.weight"), (int)m, H, H))) return rc;

@@ -550,6 +550,36 @@ __global__ __launch_bounds__(256) void act_lines_kernel(const float* __restrict_
     *(h8*)(dst + 64) = lo;
 }
 
+// a gradient dz (m, n) fp32 -> SCALED lines (the operand of dx = dz . W and, reduction-major, of dW = dz^T . x): scale 2^e from
+// its measured max (sc[3]; gradients carry a 1/m factor and would sit in fp16's subnormal range otherwise); thread 0 publishes the
+// two descale words (sc[4] for the data gradient: 2^-e x the weights' descale, sc[5] = 2^-e for the weight gradient).
+__global__ __launch_bounds__(256) void grad_lines_kernel(const float* __restrict__ dz, int64_t m, int n, float* __restrict__ sc,
+                                                        char* __restrict__ lines) {
+    const int e2 = wscale_exp(sc[3]);
+    const float scale = ldexpf(1.0f, e2);
+    const int gpr = n / 8;
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id == 0) {
+        sc[4] = ldexpf(1.0f, -e2) * sc[1];
+        sc[5] = ldexpf(1.0f, -e2);
+    }
+    if (id >= m * gpr) return;
+    const int64_t row = id / gpr;
+    const int g = (int)(id - row * gpr);
+    const f32x4 a = *(const f32x4*)(dz + row * n + g * 8), b = *(const f32x4*)(dz + row * n + g * 8 + 4);
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        _Float16 p, q;
+        split_h((e < 4 ? a[e] : b[e - 4]) * scale, p, q);
+        hi[e] = p;
+        lo[e] = q;
+    }
+    char* dst = lines + row * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16;
+    *(h8*)dst = hi;
+    *(h8*)(dst + 64) = lo;
+}
+
 // bn_relu_drop_kernel that ALSO writes its output as lines (the next layer's GEMM operand); identical per-element
 // arithmetic.  4 columns per lane (every fp32 access is a fully coalesced 16-byte one); an even / odd lane pair covers one
 // 8-column group of a line: the even lane stores the group's 8 hi halves, the odd lane its 8 lo halves.  n % 8 == 0.

@@ -50,9 +50,9 @@ def timing():
             tr = HipTrainer(sd, p_dropout=0.2, lr=0.001, device=dev, route=name[:3] if name.startswith('mid') else name)
             from monoloco_amd import _lib
             if name == 'mid1s':
-                _lib.check(_lib.load().ml_trainer_set_tuning(tr._h, 0, 1), train=True)
+                _lib.check(_lib.load().ml_trainer_set_tuning(tr._h, 0, 1, -1), train=True)
             if name == 'mid2l':
-                _lib.check(_lib.load().ml_trainer_set_tuning(tr._h, 0, 2), train=True)
+                _lib.check(_lib.load().ml_trainer_set_tuning(tr._h, 0, 2, -1), train=True)
             for _ in range(5): tr.step(x, y)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             n = 30
