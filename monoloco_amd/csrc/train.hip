@@ -111,6 +111,7 @@ struct ml_trainer {
     int ssq_per_mat = 0;
     int dw_trans = 1;                // weight-gradient GEMM operands: 1 = reduction-major lines as they lie (dense_kernel_w4<.., -3, true>),
                                      // 0 = transposed copies (tlines_kernel; the round-2 path, kept for the bit-identity test)
+    float* d_colmax = nullptr;       // per BatchNorm layer 2 H floats: column maxima of |dy|, |xhat| (bn_bwd_lines_kernel's scale bound)
     char* dzl = nullptr;             // [capT][H] lines: the scaled gradient dz of the layer being back-propagated
     int64_t pad_m = -1;              // rows [pad_m, round_up(pad_m, 64 ks)) of every line buffer are zero
     int apply_cols = 8;              // columns a workgroup of the column-owner kernels takes (4 | 8 | 16): ml_trainer_set_tuning
@@ -417,7 +418,7 @@ int pick_route(const ml_trainer* t, int64_t m) {
 // x_lines: the block input as lines (or null: exact-fp32 MFMA GEMM on b.x); y_lines: where to put the block output as
 // lines as well (or null)
 int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* residual, const char* x_lines = nullptr,
-              char* y_lines = nullptr, int slot = -1) {
+              char* y_lines = nullptr, int slot = -1, bool lines_only = false) {
     const int H = t->H;
     int rc;
     if (x_lines && slot >= 0) rc = fast_linear_fwd(t, st, x_lines, b.lin, b.z, m, slot);
@@ -434,8 +435,8 @@ int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* r
     if (y_lines)
         hipLaunchKernelGGL(mlt::bn_relu_drop_lines_kernel, dim3(nblk(m * H / 4)), dim3(256), 0, st, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
-                           (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site, residual, b.y,
-                           y_lines);
+                           (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site, residual,
+                           lines_only ? (float*)nullptr : b.y, y_lines);
     else
         hipLaunchKernelGGL(mlt::bn_relu_drop_kernel, dim3(nblk(m * H)), dim3(256), 0, st, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
@@ -470,20 +471,31 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
         if ((rc = next_red_slot(t, st))) return rc;
         double* s_dy = t->d_red;
         const float* src = din ? din : dout;
+        // large-batch route, H x H Linear below (slot >= 0): dz leaves as scaled lines only (bn_bwd_lines_kernel), scaled by a bound
+        // the statistics pass collects the column maxima for
+        const bool lines_only = slot >= 0 && t->dw_trans && b.x_lines;
+        float* colmax = lines_only ? t->d_colmax + (size_t)slot * 2 * H : nullptr;
         hipLaunchKernelGGL(mlt::bwd_stats_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, src, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
-                           (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, s_dy, s_dy + H);
+                           (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, s_dy, s_dy + H, colmax);
         if ((rc = next_red_slot(t, st))) return rc;
         double* s_dz = t->d_red;
-        hipLaunchKernelGGL(mlt::bn_bwd_fused_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, dout, src, (const float*)b.z, m, H,
-                           (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
-                           (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, (const double*)s_dy,
-                           (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz,
-                           slot >= 0 ? t->wsc_base + 8 * slot + 3 : (float*)nullptr);
+        if (lines_only)
+            hipLaunchKernelGGL(mlt::bn_bwd_lines_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, src, (const float*)b.z, m, H,
+                               (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
+                               (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, (const double*)s_dy,
+                               (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz, (const float*)colmax,
+                               t->wsc_base + 8 * slot, t->dzl);
+        else
+            hipLaunchKernelGGL(mlt::bn_bwd_fused_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, dout, src, (const float*)b.z, m, H,
+                               (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
+                               (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, (const double*)s_dy,
+                               (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz,
+                               slot >= 0 ? t->wsc_base + 8 * slot + 3 : (float*)nullptr);
         hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)s_dz, H,
                            G(t, b.lin + ".bias"));
         if (slot >= 0) {
-            if ((rc = fast_grad_lines(t, st, dout, m, slot))) return rc;
+            if (!lines_only && (rc = fast_grad_lines(t, st, dout, m, slot))) return rc;
             return fast_linear_bwd_weight(t, st, b.x, b.x_lines, b.lin, m, slot);
         }
         if (slot == -2 && skinny_ok(t, b.in_dim))   // the input layer: dW1 (H x in) = dz^T . x
@@ -542,6 +554,7 @@ int ensure_cap(ml_trainer* t, int64_t m) {
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                 t->n_cu = prop.multiProcessorCount;
             T_TRY(hipMalloc((void**)&t->wsc_base, (size_t)(2 * t->S + 2) * 32));
+            T_TRY(hipMalloc((void**)&t->d_colmax, (size_t)(2 * t->S + 2) * 2 * t->H * sizeof(float)));
             T_TRY(hipMalloc((void**)&t->zero_bias, (size_t)t->H * 4));
             T_TRY(hipMemset(t->zero_bias, 0, (size_t)t->H * 4));
             for (int i = 0; i < 2 * t->S + 2; ++i) {
@@ -990,7 +1003,7 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (hipEvent_t e : t->ev_dz) (void)hipEventDestroy(e);
     for (hipEvent_t e : t->ev_w) (void)hipEventDestroy(e);
     if (t->st2) (void)hipStreamDestroy(t->st2);
-    void* ptrs[] = {t->w_snap, t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->dzl, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    void* ptrs[] = {t->w_snap, t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->dzl, t->d_colmax, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -1235,6 +1248,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     const bool fast = route == 1;
     if (fast) {
         T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 2) * 32, st));
+        T_TRY(hipMemsetAsync(t->d_colmax, 0, (size_t)(2 * S + 2) * 2 * H * sizeof(float), st));
         if (t->pad_m != m) {
             // the weight-gradient GEMMs reduce over whole 64-row k-steps per split: rows m .. mT of every line buffer must be
             // zero (a smaller batch than the last one leaves old rows there); the writers only touch rows < m
@@ -1255,7 +1269,8 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         const std::string p = "linear_stages." + std::to_string(s) + ".";
         sa[s].lin = p + "w1"; sa[s].bn = p + "batch_norm1"; sa[s].bn_idx = 1 + 2 * s; sa[s].in_dim = H;
         sa[s].x = a[s]; sa[s].x_lines = la(s); sa[s].z = za[s]; sa[s].y = tt[s]; sa[s].site = 1 + 2 * s;
-        if ((rc = block_fwd(t, st, sa[s], m, nullptr, la(s), lt(s), fast ? 2 * s : -1))) return rc;
+        // (t_s is read by the next Linear's GEMMs only -- forward and, reduction-major, weight gradient --: lines, no fp32 copy)
+        if ((rc = block_fwd(t, st, sa[s], m, nullptr, la(s), lt(s), fast ? 2 * s : -1, fast && t->dw_trans))) return rc;
         sb[s].lin = p + "w2"; sb[s].bn = p + "batch_norm2"; sb[s].bn_idx = 2 + 2 * s; sb[s].in_dim = H;
         sb[s].x = tt[s]; sb[s].x_lines = lt(s); sb[s].z = zb[s]; sb[s].y = a[s + 1]; sb[s].site = 2 + 2 * s;
         if ((rc = block_fwd(t, st, sb[s], m, a[s], lt(s), la(s + 1), fast ? 2 * s + 1 : -1))) return rc;  // a_{s+1} = a_s + block(t_s)

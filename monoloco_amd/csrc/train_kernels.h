@@ -325,11 +325,13 @@ __global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict_
                                                        int n, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float p_drop, uint32_t seed, uint32_t site, double* __restrict__ s1,
-                                                       double* __restrict__ s2) {
+                                                       double* __restrict__ s2, float* __restrict__ colmax = nullptr) {
     __shared__ double r1[16][64], r2[16][64];
     const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int j0 = blockIdx.x * 64 + cg * 4;
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    // colmax (2 n floats, zeroed; may be null): per column max |dy| and max |xhat| -- the bound bn_bwd_lines_kernel scales dz by
+    float mdy[4] = {0.f, 0.f, 0.f, 0.f}, mxh[4] = {0.f, 0.f, 0.f, 0.f};
     const int64_t step = (int64_t)gridDim.y * 16;
     if (j0 + 3 < n) {
         const f32x4 mu = *(const f32x4*)(mean + j0), is = *(const f32x4*)(invstd + j0);
@@ -343,6 +345,8 @@ __global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict_
                 bwd_elem(d[e], zz[e], mu[e], is[e], ga[e], be[e], p_drop, seed, site, i, j0 + e, dy, xh);
                 a[e] += (double)dy;
                 b[e] += (double)dy * (double)xh;
+                mdy[e] = __builtin_fmaxf(mdy[e], __builtin_fabsf(dy));
+                mxh[e] = __builtin_fmaxf(mxh[e], __builtin_fabsf(xh));
             }
         }
     }
@@ -362,6 +366,31 @@ __global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict_
         }
         atomicAdd(&s1[blockIdx.x * 64 + cj], sa);
         atomicAdd(&s2[blockIdx.x * 64 + cj], sb);
+    }
+    if (colmax) {   // (uniform) the column maxima: through LDS over the 16 row groups, then ONE atomic per column and workgroup
+        // (an atomic per thread and column -- 4 M of them on 2 K addresses at 65536 x 1024 -- doubled the pass: 127 -> 243 us)
+        __syncthreads();
+        float* f1 = (float*)&r1[0][0];
+        float* f2 = (float*)&r2[0][0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f1[rg * 64 + cg * 4 + e] = mdy[e];
+            f2[rg * 64 + cg * 4 + e] = mxh[e];
+        }
+        __syncthreads();
+        if (cj < 64 && blockIdx.x * 64 + cj < n) {
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                v0 = __builtin_fmaxf(v0, f1[g * 64 + cj]);
+                v1 = __builtin_fmaxf(v1, f2[g * 64 + cj]);
+            }
+            // non-negative floats order like their bit patterns; NaN / inf saturate
+            v0 = v0 < 3.0e38f ? v0 : 3.0e38f;
+            v1 = v1 < 3.0e38f ? v1 : 3.0e38f;
+            if (v0 > 0.f) atomicMax((unsigned*)colmax + blockIdx.x * 64 + cj, __builtin_bit_cast(unsigned, v0));
+            if (v1 > 0.f) atomicMax((unsigned*)colmax + n + blockIdx.x * 64 + cj, __builtin_bit_cast(unsigned, v1));
+        }
     }
 }
 
@@ -580,6 +609,105 @@ __global__ __launch_bounds__(256) void grad_lines_kernel(const float* __restrict
     *(h8*)(dst + 64) = lo;
 }
 
+// bn_bwd_fused_kernel whose dz leaves as SCALED LINES only (the operand of both gradient GEMMs of the Linear below; no fp32 copy:
+// nothing else on the large-batch route reads it): the per-layer dz -> lines pass (grad_lines_kernel, 537 MB of traffic at
+// 65536 x 1024) disappears.  The scale 2^e must be known before the first element is written, so it comes from a BOUND instead
+// of the measured maximum:  |dz_ij| <= |g_j| (m max_i |dy_ij| + |sum dy_j| + max_i |xhat_ij| |sum dy xhat_j|),  g = gamma invstd / m,
+// with the column maxima bwd_stats_kernel collected (colmax).  The first term dominates (the sums are ~sqrt(m) terms), so the
+// bound sits within a few per cent of the true maximum: the scaled values stay in [0, 2^15), fp16's top octaves.  Every workgroup
+// evaluates the same bound over all n columns (L2-resident vectors): same scale everywhere, no extra launch; workgroup (0, 0)
+// publishes the descales (sc[4] = 2^-e x the weights' descale for dx, sc[5] = 2^-e for dW).  Same per-element arithmetic as
+// bn_bwd_fused_kernel (the fp32 dz is formed, then scaled by a power of two and split).
+__global__ __launch_bounds__(256) void bn_bwd_lines_kernel(const float* din, const float* __restrict__ z, int64_t m, int n,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float p_drop, uint32_t seed, uint32_t site,
+                                                          const double* __restrict__ sdy, const double* __restrict__ sdyx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          double* __restrict__ sdz, const float* __restrict__ colmax,
+                                                          float* __restrict__ sc, char* __restrict__ lines) {
+    __shared__ double r1[16][64];
+    __shared__ float wmax[4];
+    float bound = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float g = __builtin_fabsf(gamma[j] * invstd[j] / (float)m);
+        const float b = g * ((float)m * colmax[j] + __builtin_fabsf((float)sdy[j]) + colmax[n + j] * __builtin_fabsf((float)sdyx[j]));
+        bound = __builtin_fmaxf(bound, b < 3.0e38f ? b : 3.0e38f);   // (NaN -> 3e38: scale 2^-113.., finite garbage instead of NaN lines)
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bound = __builtin_fmaxf(bound, __shfl_xor(bound, o, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = bound;
+    __syncthreads();
+    bound = __builtin_fmaxf(__builtin_fmaxf(wmax[0], wmax[1]), __builtin_fmaxf(wmax[2], wmax[3]));
+    const int e2 = wscale_exp(bound);
+    const float scale = ldexpf(1.0f, e2);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        sc[3] = bound;
+        sc[4] = ldexpf(1.0f, -e2) * sc[1];
+        sc[5] = ldexpf(1.0f, -e2);
+    }
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j0 = blockIdx.x * 64 + cg * 4;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t step = (int64_t)gridDim.y * 16;
+    if (j0 + 3 < n) {
+        const f32x4 mu = *(const f32x4*)(mean + j0), is = *(const f32x4*)(invstd + j0);
+        const f32x4 ga = *(const f32x4*)(gamma + j0), be = *(const f32x4*)(beta + j0);
+        float sa[4], sb[4], gg[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sa[e] = (float)sdy[j0 + e];
+            sb[e] = (float)sdyx[j0 + e];
+            gg[e] = ga[e] * is[e] / (float)m;
+        }
+        const bool odd = cg & 1;
+        const int g8 = j0 >> 3;   // 8-column group of the row: the even lane stores its hi halves, the odd lane its lo halves
+        for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += step) {
+            const f32x4 d = *(const f32x4*)(din + i * n + j0);
+            const f32x4 zz = *(const f32x4*)(z + i * n + j0);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float dy, xh;
+                bwd_elem(d[e], zz[e], mu[e], is[e], ga[e], be[e], p_drop, seed, site, i, j0 + e, dy, xh);
+                o[e] = gg[e] * ((float)m * dy - sa[e] - xh * sb[e]);
+                a[e] += (double)o[e];
+            }
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            unsigned hi2[2], lo2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                _Float16 a0, b0, a1, b1;
+                split_h(o[2 * e] * scale, a0, b0);
+                split_h(o[2 * e + 1] * scale, a1, b1);
+                hi2[e] = __builtin_bit_cast(unsigned, h2{a0, a1});
+                lo2[e] = __builtin_bit_cast(unsigned, h2{b0, b1});
+            }
+            const unsigned s0 = __shfl_xor(odd ? hi2[0] : lo2[0], 1, 64), s1 = __shfl_xor(odd ? hi2[1] : lo2[1], 1, 64);
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const u4 out = odd ? u4{s0, s1, lo2[0], lo2[1]} : u4{hi2[0], hi2[1], s0, s1};
+            *(u4*)(lines + i * (int64_t)n * 4 + (g8 >> 2) * 128 + (g8 & 3) * 16 + (odd ? 64 : 0)) = out;
+        }
+        if (blockIdx.y == 0 && rg == 0) {  // one thread per column publishes the parameter gradients
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dgamma[j0 + e] = (float)sdyx[j0 + e];
+                dbeta[j0 + e] = (float)sdy[j0 + e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r1[rg][cg * 4 + e] = a[e];
+    __syncthreads();
+    const int cj = threadIdx.x;
+    if (cj < 64 && blockIdx.x * 64 + cj < n) {
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += r1[g][cj];
+        atomicAdd(&sdz[blockIdx.x * 64 + cj], s);
+    }
+}
+
 // bn_relu_drop_kernel that ALSO writes its output as lines (the next layer's GEMM operand); identical per-element
 // arithmetic.  4 columns per lane (every fp32 access is a fully coalesced 16-byte one); an even / odd lane pair covers one
 // 8-column group of a line: the even lane stores the group's 8 hi halves, the odd lane its 8 lo halves.  n % 8 == 0.
@@ -611,7 +739,7 @@ __global__ __launch_bounds__(256) void bn_relu_drop_lines_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += r[e];
     }
-    if (live) *(f32x4*)(y + base) = v;
+    if (live && y) *(f32x4*)(y + base) = v;   // (y null: only the lines are needed -- a stage's inner activation on the large-batch route)
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     unsigned hi2[2], lo2[2];
 #pragma unroll
