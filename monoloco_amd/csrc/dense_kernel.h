@@ -55,6 +55,11 @@ struct DenseParams {
     // fused head (dense_kernel_pp<.., HEAD>): out[m][o] partial sums instead of the activation tile
     const float* head_w;   // [HEAD][N] fp32
     float* head_part;      // [2*N/256][M_pad][16] fp32 partial dot products (per 128-column slice)
+    // dense_kernel_w4<.., -2> (training forward): column sums and sums of squares of the STORED fp32 tile, rows < m_valid, per
+    // 128-row block: colpart[(row block) * 2 * N + j] = sum, [.. + N + j] = sum of squares (fp64; BatchNorm batch statistics
+    // without a second pass over z); nullptr: none
+    double* colpart = nullptr;
+    int m_valid = 0;
 };
 
 __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {

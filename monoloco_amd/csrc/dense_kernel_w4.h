@@ -594,6 +594,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 }
             };
             float auxp[4] = {0.f, 0.f, 0.f, 0.f};   // AUX: this lane's part of w_aux . y for its person of row block jt
+            double cs[4] = {0.0, 0.0, 0.0, 0.0}, cq[4] = {0.0, 0.0, 0.0, 0.0};   // colpart: column sums / sums of squares of row block `it`
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 float auxw[16];
@@ -692,6 +693,46 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     for (int qq = 0; qq < 4; ++qq) {
                         d[qq] = *(const f32x4*)(buf + rd_off + qq * 1024);
                         if (F32OUT && RES) d[qq] += rq[pass][qq];   // fp32 accumulate: the residual is fp32 in store layout already
+                    }
+                    if (F32OUT && !RES && !SPLITK) {
+                        // BatchNorm batch statistics of the tile being stored (training forward, p.colpart): in store layout a lane
+                        // holds 4 consecutive columns (32 it + 4 (lane & 7) ..) of rows 32 jt + 8 qq + (lane >> 3): fp64 sums over
+                        // the 16 rows of the four passes of `it`, then over the 8 lanes that share the columns, one 128-row block per
+                        // wave -- no second pass over z (col_stats_kernel: 44 us per layer at 65536 x 1024), no atomics
+                        if (p.colpart) {   // (uniform)
+                            if (jt == 0) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) cs[e] = cq[e] = 0.0;
+                            }
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) {
+                                const bool valid = mbase + jt * 32 + 8 * qq + (elane >> 3) < p.m_valid;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const double v = valid ? (double)d[qq][e] : 0.0;
+                                    cs[e] += v;
+                                    cq[e] = __builtin_fma(v, v, cq[e]);
+                                }
+                            }
+                            if (jt == 3) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                                    for (int o = 8; o <= 32; o <<= 1) {
+                                        cs[e] += __shfl_xor(cs[e], o, 64);
+                                        cq[e] += __shfl_xor(cq[e], o, 64);
+                                    }
+                                }
+                                if ((elane >> 3) == 0) {
+                                    double* dstp = p.colpart + (size_t)(mbase >> 7) * 2 * p.N + nbase + it * 32 + (elane & 7) * 4;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        dstp[e] = cs[e];
+                                        dstp[p.N + e] = cq[e];
+                                    }
+                                }
+                            }
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);  // one region per pass: interleaving more of them costs registers
                 }

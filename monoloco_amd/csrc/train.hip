@@ -111,6 +111,7 @@ struct ml_trainer {
     int ssq_per_mat = 0;
     int dw_trans = 1;                // weight-gradient GEMM operands: 1 = reduction-major lines as they lie (dense_kernel_w4<.., -3, true>),
                                      // 0 = transposed copies (tlines_kernel; the round-2 path, kept for the bit-identity test)
+    double* d_colpart = nullptr;     // [cap / 128][2][H]: per 128-row block column sums / sums of squares the forward GEMM's epilogue leaves
     float* d_colmax = nullptr;       // per BatchNorm layer 2 H floats: column maxima of |dy|, |xhat| (bn_bwd_lines_kernel's scale bound)
     char* dzl = nullptr;             // [capT][H] lines: the scaled gradient dz of the layer being back-propagated
     int64_t pad_m = -1;              // rows [pad_m, round_up(pad_m, 64 ks)) of every line buffer are zero
@@ -279,7 +280,7 @@ struct Block {  // Linear + BatchNorm + ReLU + Dropout
 
 // one launch of the inference path's dense kernel with the fp32 epilogue: out (m x H fp32) [+]= x_lines . w_lines^T + bias
 int launch_fast_gemm(ml_trainer* t, hipStream_t st, const char* x_lines, const char* w_lines, const float* bias_scaled,
-                     const float* descale_ptr, float* out, int64_t m, bool accumulate) {
+                     const float* descale_ptr, float* out, int64_t m, bool accumulate, bool col_stats_too = false) {
     const int H = t->H;
     mlk::DenseParams p;
     p.x = x_lines;
@@ -298,6 +299,10 @@ int launch_fast_gemm(ml_trainer* t, hipStream_t st, const char* x_lines, const c
     p.trace = nullptr;
     p.head_w = nullptr;
     p.head_part = nullptr;
+    if (col_stats_too && !accumulate) {   // BatchNorm batch statistics of the tile as it is stored (rows < m)
+        p.colpart = t->d_colpart;
+        p.m_valid = (int)m;
+    }
     const int tiles = (p.M_pad / mlk::BM) * (p.N / mlk::BN);
     const dim3 grid(tiles < t->n_cu ? tiles : t->n_cu), block(mlk::W4_THREADS);
     if (accumulate) hipLaunchKernelGGL((mlk::dense_kernel_w4<3, false, true, -2>), grid, block, 0, st, p);
@@ -310,13 +315,14 @@ int launch_fast_gemm(ml_trainer* t, hipStream_t st, const char* x_lines, const c
 // the device (they change every step), then ONE launch of the inference path's dense kernel with the fp32 epilogue
 // (dense_kernel_w4<3, false, false, -2>): 3 fp16 MFMAs per product, fp32 accumulate -- fp32-class accuracy (~2^-22
 // relative per operand) at ~3x the rate of the exact-fp32 MFMA GEMM.  `slot` = which packed-weight image to use.
-int fast_linear_fwd(ml_trainer* t, hipStream_t st, const char* x_lines, const std::string& lin, float* z, int64_t m, int slot) {
+int fast_linear_fwd(ml_trainer* t, hipStream_t st, const char* x_lines, const std::string& lin, float* z, int64_t m, int slot,
+                    bool col_stats_too = false) {
     const int H = t->H;
     float* sc = t->wsc_base + 8 * slot;   // (zeroed at the start of the step)
     hipLaunchKernelGGL(mlt::wmax_kernel, dim3(64), dim3(256), 0, st, (const float*)P(t, lin + ".weight"), (int64_t)H * H, sc + 2);
     hipLaunchKernelGGL(mlt::wpack_kernel<false>, dim3(nblk((int64_t)H * H / 8)), dim3(256), 0, st, (const float*)P(t, lin + ".weight"),
                        (const float*)P(t, lin + ".bias"), H, H, H, sc, t->wl[slot], t->wbs[slot]);
-    return launch_fast_gemm(t, st, x_lines, t->wl[slot], t->wbs[slot], sc + 1, z, m, false);
+    return launch_fast_gemm(t, st, x_lines, t->wl[slot], t->wbs[slot], sc + 1, z, m, false, col_stats_too);
 }
 
 // dx (m x H, fp32) [+]= dz . W for the same Linear, dz given as lines: the image of W^T replaces the forward image (which
@@ -421,17 +427,24 @@ int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* r
               char* y_lines = nullptr, int slot = -1, bool lines_only = false) {
     const int H = t->H;
     int rc;
-    if (x_lines && slot >= 0) rc = fast_linear_fwd(t, st, x_lines, b.lin, b.z, m, slot);
+    const bool gemm_stats = x_lines && slot >= 0;   // the batch statistics come out of the GEMM's own epilogue
+    if (gemm_stats) rc = fast_linear_fwd(t, st, x_lines, b.lin, b.z, m, slot, true);
     else if (b.in_dim != H && skinny_ok(t, b.in_dim))   // the (narrow) input layer
         rc = skinny_out(t, st, b.x, b.in_dim, b.in_dim, P(t, b.lin + ".weight"), 1, b.in_dim, P(t, b.lin + ".bias"), b.z, m, 0);
     else rc = linear_fwd(t, st, b.x, b.in_dim, P(t, b.lin + ".weight"), P(t, b.lin + ".bias"), b.z, H, (int)m, H, b.in_dim);
     if (rc) return rc;
-    if ((rc = col_stats(t, st, b.z, nullptr, m, H))) return rc;
     float* mean = t->bn_mean + (size_t)b.bn_idx * H;
     float* inv = t->bn_invstd + (size_t)b.bn_idx * H;
-    hipLaunchKernelGGL(mlt::bn_finalize_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red,
-                       (const double*)(t->d_red + H), m, H, 1e-5f, 0.1f, mean, inv, ST(t, b.bn + ".running_mean"),
-                       ST(t, b.bn + ".running_var"));
+    if (gemm_stats) {
+        hipLaunchKernelGGL(mlt::bn_finalize_parts_kernel, dim3((H + 15) / 16), dim3(256), 0, st, (const double*)t->d_colpart,
+                           (int)((m + 127) / 128), m, H, 1e-5f, 0.1f, mean, inv, ST(t, b.bn + ".running_mean"),
+                           ST(t, b.bn + ".running_var"));
+    } else {
+        if ((rc = col_stats(t, st, b.z, nullptr, m, H))) return rc;
+        hipLaunchKernelGGL(mlt::bn_finalize_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red,
+                           (const double*)(t->d_red + H), m, H, 1e-5f, 0.1f, mean, inv, ST(t, b.bn + ".running_mean"),
+                           ST(t, b.bn + ".running_var"));
+    }
     if (y_lines)
         hipLaunchKernelGGL(mlt::bn_relu_drop_lines_kernel, dim3(nblk(m * H / 4)), dim3(256), 0, st, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
@@ -541,7 +554,10 @@ int ensure_cap(ml_trainer* t, int64_t m) {
             t->lbufs.push_back(p);
         }
         if (t->dzl) (void)hipFree(t->dzl);
+        if (t->d_colpart) (void)hipFree(t->d_colpart);
         t->dzl = nullptr;
+        t->d_colpart = nullptr;
+        T_TRY(hipMalloc((void**)&t->d_colpart, (size_t)(m / 128) * 2 * t->H * sizeof(double)));
         T_TRY(hipMalloc((void**)&t->dzl, (size_t)t->capT * t->H * 4));
         T_TRY(hipMemset(t->dzl, 0, (size_t)t->capT * t->H * 4));
         t->pad_m = -1;
@@ -1003,7 +1019,7 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (hipEvent_t e : t->ev_dz) (void)hipEventDestroy(e);
     for (hipEvent_t e : t->ev_w) (void)hipEventDestroy(e);
     if (t->st2) (void)hipStreamDestroy(t->st2);
-    void* ptrs[] = {t->w_snap, t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->dzl, t->d_colmax, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    void* ptrs[] = {t->w_snap, t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->dzl, t->d_colpart, t->d_colmax, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;

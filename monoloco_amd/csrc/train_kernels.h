@@ -253,6 +253,41 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     run_var[j] = (1.f - momentum) * run_var[j] + momentum * (float)unb;
 }
 
+// bn_finalize_kernel on the per-128-row-block partial sums the forward GEMM's epilogue left (dense_kernel_w4<.., -2>, p.colpart:
+// part[b][0][j] = sum, part[b][1][j] = sum of squares over the block's rows < m): added in block order (deterministic), then as above.
+__global__ __launch_bounds__(256) void bn_finalize_parts_kernel(const double* __restrict__ part, int nblocks, int64_t m, int n, float eps,
+                                                               float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                                               float* __restrict__ run_mean, float* __restrict__ run_var) {
+    // workgroup = 16 columns x 16 groups; group g adds the blocks b = g, g + 16, .. in order, then the 16 group sums in order
+    __shared__ double r1[16][16], r2[16][16];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + c;
+    double s1 = 0.0, s2 = 0.0;
+    if (j < n)
+        for (int b = g; b < nblocks; b += 16) {
+            s1 += part[(size_t)b * 2 * n + j];
+            s2 += part[(size_t)b * 2 * n + n + j];
+        }
+    r1[g][c] = s1;
+    r2[g][c] = s2;
+    __syncthreads();
+    if (g != 0 || j >= n) return;
+    s1 = s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        s1 += r1[q][c];
+        s2 += r2[q][c];
+    }
+    const double mu = s1 / (double)m;
+    double var = s2 / (double)m - mu * mu;
+    if (var < 0) var = 0;
+    mean[j] = (float)mu;
+    invstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+    const double unb = m > 1 ? var * (double)m / (double)(m - 1) : var;
+    run_mean[j] = (1.f - momentum) * run_mean[j] + momentum * (float)mu;
+    run_var[j] = (1.f - momentum) * run_var[j] + momentum * (float)unb;
+}
+
 __global__ __launch_bounds__(256) void bn_relu_drop_kernel(const float* __restrict__ z, int64_t m, int n,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -894,13 +929,71 @@ __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict_
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[c][e] = 0.f;
-    for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += (int64_t)gridDim.y * 16) {
-        const f32x4 v = *(const f32x4*)(x + i * n + j0);
+    if (NCT >= 8) {
+        // Round 4 (the 34-column input layer's weight gradient at 65536 rows ran at 1 TB/s, 263 us for one read of dz): with NCT x 4
+        // accumulators a SIMD holds ONE wave, and a wave with one 16-byte load in flight cannot cover the memory latency; the NCT
+        // 4-byte loads of the skinny row per 16 bytes of x were load-issue-bound on top.  Now a workgroup walks chunks of 64
+        // consecutive rows: the chunk's skinny rows go through LDS (a thread reads its row's values as NCT / 4 broadcast
+        // ds_read_b128), its four x rows per thread are requested one chunk AHEAD (4 loads in flight per thread).
+        constexpr int SP = (NCT + 3) / 4 * 4;
+        constexpr int SPT = (64 * SP + 255) / 256;   // skinny values a thread stages per chunk
+        __shared__ __attribute__((aligned(16))) float ss[64][SP];
+        const int64_t nchunk = (m + 63) / 64;
+        f32x4 vn[4];
+        float sn[SPT];
+        int sr[SPT], scn[SPT];   // (row, column) of this thread's staged values: chunk-invariant
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            const float sv = (c0 + c < nc) ? s[i * lds + c0 + c] : 0.f;
+        for (int q = 0; q < SPT; ++q) {
+            const int idx = threadIdx.x + 256 * q;
+            sr[q] = idx / SP;
+            scn[q] = idx - sr[q] * SP;
+        }
+        auto request = [&](int64_t chunk) {   // the NEXT chunk's x rows and skinny values: in flight while this chunk is multiplied
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(sv, v[e], acc[c][e]);
+            for (int q = 0; q < 4; ++q) {
+                const int64_t i = chunk * 64 + rg + 16 * q;
+                vn[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (chunk < nchunk && i < m) vn[q] = *(const f32x4*)(x + i * n + j0);
+            }
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int64_t i = chunk * 64 + sr[q];
+                sn[q] = 0.f;
+                if (chunk < nchunk && sr[q] < 64 && i < m && c0 + scn[q] < nc && scn[q] < NCT) sn[q] = s[i * lds + c0 + scn[q]];
+            }
+        };
+        request(blockIdx.y);
+        for (int64_t chunk = blockIdx.y; chunk < nchunk; chunk += gridDim.y) {
+#pragma unroll
+            for (int q = 0; q < SPT; ++q)
+                if (sr[q] < 64) ss[sr[q]][scn[q]] = sn[q];
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = vn[q];
+            __syncthreads();
+            request(chunk + gridDim.y);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c4 = 0; c4 < SP / 4; ++c4) {
+                    const f32x4 sv = *(const f32x4*)&ss[rg + 16 * q][c4 * 4];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+                        if (c4 * 4 + cc < NCT)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[c4 * 4 + cc][e] = __builtin_fmaf(sv[cc], v[q][e], acc[c4 * 4 + cc][e]);
+                }
+            __syncthreads();
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += (int64_t)gridDim.y * 16) {
+            const f32x4 v = *(const f32x4*)(x + i * n + j0);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float sv = (c0 + c < nc) ? s[i * lds + c0 + c] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(sv, v[e], acc[c][e]);
+            }
         }
     }
     // the 16 row groups: 4 per wave (lane bits 4, 5), 4 waves
