@@ -167,10 +167,18 @@ struct W4Frag {          // the fragments of one k32 step of one half (hi or lo)
 // 64-byte column chunks are XOR-swizzled with k & 3 (on the DMA's source address and on the read address): the 4 k rows of a read
 // fall into the 4 different 64-byte windows of the 256-byte bank line.  Same k grouping per MFMA as the transposed-lines path:
 // bit-identical results.
-template <int NSPLIT, bool RELU, bool RES, int HEAD, bool TRANS = false>
+// NJ (round 4): MFMA tiles per wave along m.  4 = the 256 (n) x 256 (m) workgroup tile above; 2 = the HALF-SIZE tile, 256 (n) x
+// 128 (m), 4 waves x 128 x 64, for 4096 < rows <= ~12000 where the full tiles are fewer than the CUs (8192 rows: 128 tiles on 256
+// CUs, 57 us per layer whatever the rows): same ring, same phases, same counted waits with 6 instead of 8 DMA instructions per
+// wave and phase (4 of 64 weight rows + 2 of 32 activation rows), 16 + 32 MFMAs per phase pair, 8 epilogue passes.  The X half of
+// a slot is half used.
+template <int NSPLIT, bool RELU, bool RES, int HEAD, bool TRANS = false, int NJ = 4>
 __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_kernel_w4(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[W4_LDS];
     static_assert(!TRANS || HEAD == -3, "reduction-major operands: the split-K weight-gradient variant only");
+    static_assert(NJ == 4 || (NJ == 2 && !TRANS && HEAD == 0), "half-size tile: plain / residual layers only");
+    constexpr int BMT = 64 * NJ;   // rows (m) of a workgroup tile
+    constexpr int NQ = 4 + NJ;     // fragment quarters = DMA instructions per wave and slot: 4 of W, NJ of X
     constexpr bool SPLIT = NSPLIT == 3;
     constexpr bool AUX = HEAD == -1;
     constexpr bool F32OUT = HEAD <= -2;
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int wm = w >> 1;   // 2 waves along m (128 persons each)
 
     const int NT = p.N / BN;
-    const int otiles = (p.M_pad / BM) * NT;                   // output tiles
+    const int otiles = (p.M_pad / BMT) * NT;                  // output tiles
     const int ntiles = SPLITK ? otiles * p.ksplit : otiles;  // work items
     const int q8 = ntiles >> 3, r8 = ntiles & 7;
     // bytes per operand row: a row of the k range (normal) / a batch row of all columns (TRANS: x and w may differ in width)
@@ -221,7 +229,9 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         if (W4_DBG(4)) return;
         // (the instruction's immediate offset is added to the global AND to the LDS address: the lo halves' + 64 is taken
         //  out of M0 again)
-        const int ldsa = dma_base + slot * W4_SLOT + (q < 4 ? 0 : W4_XOFF) + (q & 3) * 1024 - ((slot & 1) ? 64 : 0);
+        // (X rows of this wave: 16 NJ of the tile's 64 NJ, i.e. its LDS rows start 64 - 16 NJ rows earlier than the W share's)
+        const int ldsa = dma_base + slot * W4_SLOT + (q < 4 ? 0 : W4_XOFF - w * 64 * (64 - 16 * NJ)) + (q & 3) * 1024 -
+                         ((slot & 1) ? 64 : 0);
         const unsigned go = (TRANS && q >= 4) ? goffx[TRANS ? (q & 3) : 0] : goffq[q & 3];
         if (slot & 1)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:64"
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int ml = lane & 31, hh = lane >> 5;
     const int swz = (ml >> 2) & 3;
     const int wrow = (wn * 128 + ml) * 64;
-    const int xrow = W4_XOFF + (wm * 128 + ml) * 64;
+    const int xrow = W4_XOFF + (wm * 32 * NJ + ml) * 64;
     const int c0 = ((0 + hh) ^ swz) * 16, c1 = ((2 + hh) ^ swz) * 16;
 
     // TRANS: lane (16-lane group g, s = lane & 15) of a transposing read addresses k row 8 (g >> 1) + (s >> 2) (+ 16 kk + 4 h
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             tile -= ks * otiles;
         }
         const int mt = tile / NT, nt = tile - mt * NT;
-        m0 = mt * BM;
+        m0 = mt * BMT;
         n0 = nt * BN;
     };
 
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // tile of this workgroup; behind the last tile it re-requests that tile (valid memory, data never read), so that no
     // request is conditional and every phase has the same vmcnt arithmetic.
     int rq_vb = vb, rq_left = nk;
-    const size_t wave_rows = (size_t)(w * 64) * rowb;
+    const size_t wave_rows = (size_t)(w * 64) * rowb, wave_rows_x = (size_t)(w * 16 * NJ) * rowb;
     // TRANS: first batch row of the work item's k range + this wave's 8 rows of every k32 step; column tile = byte n0 * 4 of a row
     auto rq_w_of = [&](int tn0, int tks) -> const char* {
         return TRANS ? p.w + ((size_t)tks * p.K + w * 8) * rowb + (size_t)tn0 * 4
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     };
     auto rq_x_of = [&](int tm0, int tks) -> const char* {
         return TRANS ? p.x + ((size_t)tks * p.K + w * 8) * rowbx + (size_t)tm0 * 4
-                     : p.x + (size_t)tm0 * rowb + wave_rows + (size_t)tks * p.K * 4;
+                     : p.x + (size_t)tm0 * rowb + wave_rows_x + (size_t)tks * p.K * 4;
     };
     const char* rq_w = rq_w_of(n0, ks0);
     const char* rq_x = rq_x_of(m0, ks0);
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             issue1(rq_w, rq_x, 2 * st, q);
             if (SPLIT) issue1(rq_w, rq_x, 2 * st + 1, q);
         }
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     __builtin_amdgcn_s_barrier();
     W4Frag fa, fb, fl;   // hi fragments of even / odd k-steps, lo fragments of the current step
 #pragma unroll
-    for (int qr = 0; qr < 8; ++qr) read_q(fa, 0, qr);
+    for (int qr = 0; qr < NQ; ++qr) read_q(fa, 0, qr);
 
     // optional timeline (bring-up builds, -DML_BRINGUP -DML_DENSE_TRACE): per tile 16 slots of this wave <- s_memtime:
     //   0 tile start, 1..8 end of the first 8 phases, 9 end of main loop, 10 stream drained, 11 epilogue issued
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         // accumulators start at bias * 2^e (pre-scaled on the host, exact): the epilogue is (bias * 2^e + sum) * 2^-e with
         // no bias add.  Register r of MFMA tile (it, *) is weight row nbase + 32 it + 8 (r >> 2) + 4 (lane >> 5) + (r & 3):
         // eight consecutive floats per (it, r >> 2) through the scalar cache, the lane half selects four of them.
-        f32x16 acc[4][4];
+        f32x16 acc[4][NJ];
         {
             const float* bsc = p.bias_scaled + n0 + wn * 128;   // wave-uniform
             // (lane half recomputed here and made opaque: a kernel-lifetime copy gets spilled around the main loop)
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     for (int e = 0; e < 4; ++e) {
                         const float b = upper ? b8[g][4 + e] : b8[g][e];
 #pragma unroll
-                        for (int jt = 0; jt < 4; ++jt) acc[it][jt][g * 4 + e] = b;
+                        for (int jt = 0; jt < NJ; ++jt) acc[it][jt][g * 4 + e] = b;
                     }
             }
         }
@@ -410,7 +420,9 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             asm volatile("" : "+s"(dma_base));      // (opaque: m0 = base + constant per DMA instead of 32 hoisted SGPRs)
             if (W4_DBG(32)) return;
             if (since_drain >= (SPLIT ? 3 : 1)) {
-                if (SPLIT) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                // (the DMA groups of the two phases in between: 2 x NQ instructions of this wave)
+                if (SPLIT && NJ == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (SPLIT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             ++since_drain;
@@ -435,10 +447,12 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     const int blk = kk * 4 + it;   // 8 blocks of 4 MFMAs
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) acc[it][jt] = w4_mfma<NSPLIT>(FH.w[it][kk], FH.x[jt][kk], acc[it][jt]);
+                    for (int jt = 0; jt < NJ; ++jt) acc[it][jt] = w4_mfma<NSPLIT>(FH.w[it][kk], FH.x[jt][kk], acc[it][jt]);
                     __builtin_amdgcn_sched_barrier(0);
+                    // NJ == 4: quarters 0..3 behind blocks 0..3, two each behind blocks 4 and 5; NJ == 2: quarters 0..5 behind blocks 0..5
 #pragma unroll
-                    for (int qd = (blk < 4 ? blk : (blk < 6 ? 4 + 2 * (blk - 4) : 8)); qd < (blk < 4 ? blk + 1 : (blk < 6 ? 6 + 2 * (blk - 4) : 8)); ++qd) {
+                    for (int qd = (NJ == 2 ? (blk < 6 ? blk : 6) : (blk < 4 ? blk : (blk < 6 ? 4 + 2 * (blk - 4) : 8)));
+                         qd < (NJ == 2 ? (blk < 6 ? blk + 1 : 6) : (blk < 4 ? blk + 1 : (blk < 6 ? 6 + 2 * (blk - 4) : 8))); ++qd) {
                         issue1(rq_w, rq_x, S, qd);
                         if (SPLIT) read_q(fl, S + 1, qd);
                         else read_q(FN, S ^ 2, qd);   // single-product modes: the next step's hi fragments are read here
@@ -456,14 +470,14 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                             const int blk = (kk * 2 + half) * 4 + it;   // 16 blocks of 4 MFMAs
                             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int jt = 0; jt < 4; ++jt) {
+                            for (int jt = 0; jt < NJ; ++jt) {
                                 if (half == 0) acc[it][jt] = w4_mfma<NSPLIT>(FH.w[it][kk], fl.x[jt][kk], acc[it][jt]);
                                 else acc[it][jt] = w4_mfma<NSPLIT>(fl.w[it][kk], FH.x[jt][kk], acc[it][jt]);
                             }
                             __builtin_amdgcn_sched_barrier(0);
                             // quarters behind blocks 0, 2, .., 10, 11, 12: blocks 13-15 cover the last reads
                             const int qd = (blk <= 10) ? ((blk & 1) == 0 ? blk >> 1 : -1) : (blk <= 12 ? blk - 5 : -1);
-                            if (qd >= 0) {
+                            if (qd >= 0 && qd < NQ) {
                                 issue1(rq_w, rq_x, S + 1, qd);
                                 read_q(FN, S ^ 2, qd);
                             }
@@ -490,7 +504,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 
         // ---- epilogue of the finished tile, one 32 (n) x 32 (m) MFMA tile per pass, it-major (4 passes share a bias)
         const int nbase = n0 + wn * 128;
-        const int mbase = m0 + wm * 128;
+        const int mbase = m0 + wm * 32 * NJ;
         int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(elane));   // lane-dependent epilogue addresses are derived here, per tile (not hoisted)
         const int eml = elane & 31, eh = elane >> 5;
@@ -501,8 +515,8 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         // that hipcc does not pre-compute 16 + 16 address pairs into SGPRs and spill them)
         const size_t tile_off = (size_t)mbase * yrowb + (size_t)nbase * 4 + (SPLITK ? (size_t)ks0 * p.M_pad * yrowb : 0);
         const unsigned row8 = (unsigned)(8 * (int)yrowb);
-        auto pass_off = [&](int pass) {   // pass = it * 4 + jt
-            unsigned o = (unsigned)((pass & 3) * 32) * (unsigned)yrowb + (unsigned)((pass >> 2) * 128);
+        auto pass_off = [&](int pass) {   // pass = it * NJ + jt
+            unsigned o = (unsigned)((pass % NJ) * 32) * (unsigned)yrowb + (unsigned)((pass / NJ) * 128);
             asm volatile("" : "+s"(o));
             return o;
         };
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
             for (int it = 0; it < 4; ++it)
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) sdbg += w4_acc(acc[it][jt][(it * 4 + jt) & 15]);
+                for (int jt = 0; jt < NJ; ++jt) sdbg += w4_acc(acc[it][jt][(it * 4 + jt) & 15]);
             if (sdbg == 123456.789f) p.y[tid] = 1;
         } else if (HEAD > 0) {
             // the activation tile is not stored: each wave multiplies its relu'd 128-column slice with the HEAD x 128
@@ -526,7 +540,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             __builtin_amdgcn_wave_barrier();
             const int slice = (n0 / BN) * 2 + wn;
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
+            for (int jt = 0; jt < NJ; ++jt) {
                 float part[HEAD > 0 ? HEAD : 1];
 #pragma unroll
                 for (int o = 0; o < HEAD; ++o) part[o] = 0.0f;
@@ -570,7 +584,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             //              [global stores of pass p-1 (its transposed lines were read in region p-1: latency hidden)]
             //              [packed hi|lo of pass p -> buffer p&1 -> 16-byte lines read back for region p+1]
             // hipcc counts these loads and stores itself (no LDS-DMA is in flight here), in issue order.
-            f32x4 rq[RES ? 16 : 1][4];
+            f32x4 rq[RES ? 4 * NJ : 1][4];
             auto load_res = [&](int pass) {
                 const char* src = p.res + tile_off;
                 const unsigned o = pass_off(pass) + st_off;
@@ -607,12 +621,12 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                         for (int e = 0; e < 4; ++e) auxw[g * 4 + e] = eh ? a8[g][4 + e] : a8[g][e];
                 }
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    const int pass = it * 4 + jt;
+                for (int jt = 0; jt < NJ; ++jt) {
+                    const int pass = it * NJ + jt;
                     char* const buf = scr + (pass & 1) * 4096;
                     u32x2 rh[4], rl[4];
                     if (RES) {
-                        if (pass + RDEPTH < 16) load_res(pass + RDEPTH);
+                        if (pass + RDEPTH < 4 * NJ) load_res(pass + RDEPTH);
                     }
                     if (RES && !F32OUT) {
 #pragma unroll
@@ -694,7 +708,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                         d[qq] = *(const f32x4*)(buf + rd_off + qq * 1024);
                         if (F32OUT && RES) d[qq] += rq[pass][qq];   // fp32 accumulate: the residual is fp32 in store layout already
                     }
-                    if (F32OUT && !RES && !SPLITK) {
+                    if (F32OUT && !RES && !SPLITK && NJ == 4) {
                         // BatchNorm batch statistics of the tile being stored (training forward, p.colpart): in store layout a lane
                         // holds 4 consecutive columns (32 it + 4 (lane & 7) ..) of rows 32 jt + 8 qq + (lane >> 3): fp64 sums over
                         // the 16 rows of the four passes of `it`, then over the 8 lanes that share the columns, one 128-row block per
@@ -737,11 +751,11 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     __builtin_amdgcn_sched_barrier(0);  // one region per pass: interleaving more of them costs registers
                 }
             }
-            flush(15);
+            flush(4 * NJ - 1);
             if (AUX) {   // combine the two lane halves (weight rows 4h..4h+3 of every group of 8), one partial per person
                 const int slice = (n0 / BN) * 2 + wn;
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
+                for (int jt = 0; jt < NJ; ++jt) {
                     const float sum = auxp[jt] + __shfl_xor(auxp[jt], 32, 64);
                     if (eh == 0) p.head_part[(size_t)slice * p.M_pad + (mbase + jt * 32 + eml)] = sum;
                 }
@@ -758,7 +772,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         // the next tile's first hi fragments again (the copy read in the last phase is not kept live across the
         // epilogue: 64 registers the epilogue needs; slot 0 is untouched until the next request behind the barrier)
 #pragma unroll
-        for (int qr = 0; qr < 8; ++qr) read_q(fa, 0, qr);
+        for (int qr = 0; qr < NQ; ++qr) read_q(fa, 0, qr);
     }
 }
 

@@ -158,6 +158,7 @@ struct Tuning {
     int small_rows = 512, small32_rows = 128, chunk_rows = 0;
     int tile_kernel = 4, tile_all = 0;
     int mid_rows = 8192, mid_tile = 0;
+    int half_from = 4096;   // mid window, rows above this: the long-K layers on dense_kernel_w4's half-size tile (mid_tile 256 forces it)
 };
 
 struct ml_loco {
@@ -471,8 +472,28 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
 
     if (mid) {  // the caller chose the mid-size path (no fused heads there)
         if (head_nh != 0 || p.N % mlk::MID_TN != 0) return fail(ML_ERR_STATE, "dense_mid_kernel: no fused head, N %% 128 == 0");
+        // the upper part of the window: dense_kernel_w4 with its HALF-SIZE tile (256 n x 128 m, NJ = 2) for the long-K layers --
+        // one wave per SIMD, AGPR accumulators, the LDS-DMA ring: half the LDS traffic per MFMA of dense_mid_kernel's 64 x 64 wave
+        // tiles, and (rows / 128) * (N / 256) tiles where the full-size kernel has half as many (8192 rows: 256 instead of 128)
+        const bool half = precision == ML_PREC_F16X2 && p.K > 128 && p.K % 64 == 0 && p.N % 256 == 0 && p.M_pad % 128 == 0 &&
+                          (tu.mid_tile == 256 || (tu.mid_tile == 0 && p.M_pad > tu.half_from));
+        if (half) {
+            const int htiles = (p.M_pad / 128) * (p.N / mlk::BN);
+            const dim3 hgrid((unsigned)(htiles < num_cus() ? htiles : num_cus()));
+#define ML_HALF(RL, RS) hipLaunchKernelGGL((mlk::dense_kernel_w4<3, RL, RS, 0, false, 2>), hgrid, dim3(mlk::W4_THREADS), 0, st, p)
+            if (p.relu) {
+                if (p.res) ML_HALF(true, true);
+                else ML_HALF(true, false);
+            } else {
+                if (p.res) ML_HALF(false, true);
+                else ML_HALF(false, false);
+            }
+#undef ML_HALF
+            HIP_TRY(hipGetLastError());
+            return ML_OK;
+        }
         const int tiles128 = (p.M_pad / 128) * (p.N / mlk::MID_TN);
-        const int tm = tu.mid_tile ? tu.mid_tile : (tiles128 >= num_cus() ? 128 : 64);   // (measured: 4096 rows 256 vs 266 us)
+        const int tm = (tu.mid_tile == 64 || tu.mid_tile == 128) ? tu.mid_tile : (tiles128 >= num_cus() ? 128 : 64);   // (measured: 4096 rows 256 vs 266 us)
         const int tiles = (p.M_pad / tm) * (p.N / mlk::MID_TN);
         const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
 #define ML_MID(NS, RL, RS)                                                                                                  \
@@ -1460,7 +1481,8 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
 
 int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel, int mid_rows, int mid_tile) {
     // negative = keep; the defaults are 512 / 128 / 0 / 4 / 8192 / 0 (measured crossovers, profiles/r03_mid_sweep.txt)
-    if (mid_tile > 0 && mid_tile != 64 && mid_tile != 128) return fail(ML_ERR_ARG, "mid tile height must be 0 (auto), 64 or 128");
+    if (mid_tile > 0 && mid_tile != 64 && mid_tile != 128 && mid_tile != 256)
+        return fail(ML_ERR_ARG, "mid tile must be 0 (auto), 64 or 128 (dense_mid_kernel's tile height) or 256 (dense_kernel_w4's half-size tile)");
     if (!h) return fail(ML_ERR_ARG, "null handle");
     if (tile_kernel >= 0) {
         const int which = tile_kernel & 255;
@@ -1569,7 +1591,8 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
     if (precision & ML_DEBUG_TILE_PP) tu.tile_kernel = 2;
     if (precision & ML_DEBUG_TILE_W4) tu.tile_all = 1;
     const bool mid_path = (precision & (ML_DEBUG_MID_64 | ML_DEBUG_MID_128)) != 0;   // dense_mid_kernel with that tile height
-    if (mid_path) tu.mid_tile = (precision & ML_DEBUG_MID_64) ? 64 : 128;
+    if (mid_path)   // (both bits: dense_kernel_w4's half-size tile for the long-K layers)
+        tu.mid_tile = ((precision & ML_DEBUG_MID_64) && (precision & ML_DEBUG_MID_128)) ? 256 : ((precision & ML_DEBUG_MID_64) ? 64 : 128);
     precision &= ~(ML_DEBUG_SMALL_PATH | ML_DEBUG_TILE_PP | ML_DEBUG_TILE_W4 | ML_DEBUG_MID_64 | ML_DEBUG_MID_128);
     if ((small_path || mid_path) && precision == ML_PREC_BF16) return fail(ML_ERR_ARG, "the bf16 mode runs on the 256x256-tile kernels only");
     hipStream_t st = (hipStream_t)stream;

@@ -236,7 +236,8 @@ def laplace_sampling_device(mu_b, n_samples, seed=1):
 
 def debug_linear(x, w, b, relu=False, res=None, precision='f16x2', small_path=False, tile_kernel=None):
     """Single dense layer through the MFMA kernel (test hook): the tile kernel (tile_kernel: None = the default choice, 'pp' =
-    dense_kernel_pp, 'w4' = dense_kernel_w4 wherever it runs, 'mid64' / 'mid128' = dense_mid_kernel with that tile height), or
+    dense_kernel_pp, 'w4' = dense_kernel_w4 wherever it runs, 'mid64' / 'mid128' = dense_mid_kernel with that tile height, 'half' =
+    dense_kernel_w4's half-size 256 x 128 tile for K > 128), or
     the small-row kernels."""
     lib = _lib.load()
     dev = _require_cuda(x.device)
@@ -250,7 +251,8 @@ def debug_linear(x, w, b, relu=False, res=None, precision='f16x2', small_path=Fa
         check(lib.ml_debug_linear(_ptr(x), x.shape[0], k, fptr(w), fptr(b), n, int(bool(relu)), _ptr(res), _ptr(y),
                                   PRECISIONS[precision] | (_lib.ML_DEBUG_SMALL_PATH if small_path else 0)
                                   | {None: 0, 'pp': _lib.ML_DEBUG_TILE_PP, 'w4': _lib.ML_DEBUG_TILE_W4, 'mid64': _lib.ML_DEBUG_MID_64,
-                                     'mid128': _lib.ML_DEBUG_MID_128}[tile_kernel], _stream(dev)))
+                                     'mid128': _lib.ML_DEBUG_MID_128, 'half': _lib.ML_DEBUG_MID_64 | _lib.ML_DEBUG_MID_128}[tile_kernel],
+                                  _stream(dev)))
     return y
 
 
@@ -312,7 +314,7 @@ class LocoEngine:
         kernels, above small32_rows with 32x32 tiles; chunk_rows > 0 walks the batch in row chunks; tile_kernel 4 (default) =
         dense_kernel_w4 for the long-K layers + dense_kernel_pp for the input / fused-head layers, 2 = dense_kernel_pp
         everywhere; everywhere=True with 4 = dense_kernel_w4 for every layer it supports; small_rows < rows <= mid_rows run
-        dense_mid_kernel (mid_tile 0 = tile height from the row count, 64, 128)."""
+        dense_mid_kernel (mid_tile 0 = by row count, 64, 128) or, mid_tile 256 / rows > 4096, dense_kernel_w4's half-size tile."""
         tk = int(tile_kernel) | (256 if everywhere else 0) if tile_kernel >= 0 else -1
         check(_lib.load().ml_loco_set_tuning(self._h, int(small_rows), int(small32_rows), int(chunk_rows), tk, int(mid_rows),
                                              int(mid_tile)))

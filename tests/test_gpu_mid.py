@@ -9,8 +9,9 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("tile", ["mid64", "mid128"])
-@pytest.mark.parametrize("m,k,n", [(256, 64, 256), (700, 96, 256), (1000, 1024, 1024), (3000, 32, 512), (9000, 1024, 1024)])
+@pytest.mark.parametrize("tile", ["mid64", "mid128", "half"])
+@pytest.mark.parametrize("m,k,n", [(256, 64, 256), (700, 96, 256), (1000, 1024, 1024), (3000, 32, 512), (9000, 1024, 1024), (5000, 256, 512),
+                                   (128, 192, 256)])
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
 def test_mid_single_layer(hip_lib, cuda_device, tile, m, k, n, relu, res):
     """One layer: fp32-class accuracy against fp64, and the same operands through the 256x256-tile kernel (only the fp32
@@ -69,8 +70,8 @@ def test_mid_path_matches_tile_path(hip_lib, cuda_device, m, mode):
     eng.set_tuning(mid_rows=0)
     raw_tile = eng.forward_raw(x).cpu()
     raws = {}
-    for tile in (0, 64, 128):
-        eng.set_tuning(mid_rows=12288, mid_tile=tile)      # (the default window ends at 8192 rows)
+    for tile in (0, 64, 128, 256):   # (256: dense_kernel_w4's half-size tile for the long-K layers)
+        eng.set_tuning(mid_rows=12288, mid_tile=tile)      # (the window's end is a tuning default)
         raws[tile] = eng.forward_raw(x).cpu()
     ref64 = O.loco_forward(sd, x.cpu(), dtype=torch.float64)
     scale = max(1.0, ref64.abs().max().item())
@@ -78,7 +79,8 @@ def test_mid_path_matches_tile_path(hip_lib, cuda_device, m, mode):
     for tile, raw in raws.items():
         assert (raw.double() - ref64).abs().max().item() <= 1e-4, tile
         assert (raw - raw_tile).abs().max().item() <= 2e-6 * scale, tile
-    assert torch.equal(raws[0], raws[64 if m < 4096 else 128])      # the automatic choice: 128-row tiles from one per CU
+    # the automatic choice: dense_mid_kernel with 64-row tiles, 128-row tiles from one per CU, above 4096 rows the half-size w4 tile
+    assert torch.equal(raws[0], raws[64 if m < 4096 else (128 if m == 4096 else 256)])
     eng.close()
 
 

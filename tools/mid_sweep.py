@@ -19,7 +19,7 @@ def main():
     eng = engine.LocoEngine(sd, device=dev)
     kinv = engine.inverse_intrinsics(synth.KITTI_K)
     routes = {'small/tile': dict(mid_rows=0, small_rows=2048), 'mid64': dict(mid_rows=1 << 30, mid_tile=64, small_rows=0),
-              'mid128': dict(mid_rows=1 << 30, mid_tile=128, small_rows=0)}
+              'mid128': dict(mid_rows=1 << 30, mid_tile=128, small_rows=0), 'half (w4 256x128)': dict(mid_rows=1 << 30, mid_tile=256, small_rows=0)}
     print('%8s ' % 'rows' + ' '.join('%22s' % r for r in routes))
     for m in rows:
         kps = torch.tensor(synth.make_poses(m, 3)).to(dev)
