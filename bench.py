@@ -100,7 +100,19 @@ def cpu_baseline(sd, kps_np, kk, budget_s):
         t *= 2
     torch.set_num_threads(prev)
     best_t = max(results, key=results.get)
+    # the port against the REAL reference on the build container's CPU (tools/cpu_port_vs_reference.py: same threads, same batch,
+    # outputs bit-identical): a committed calibration -- the reference itself does not exist on the GPU box
+    pvr, pvr_src = None, None
+    for name in ('r04_port_vs_reference.json',):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            rec = json.load(open(path))
+            pvr, pvr_src = rec.get("port_vs_reference"), "replayed:profiles/%s (%s, %s host cores; per thread count: %s)" % (
+                name, rec.get("cpu_model"), rec.get("host_cores"),
+                {k: v.get("port_vs_reference") for k, v in rec.get("by_threads", {}).items()})
     return {"value": round(results[best_t], 1), "unit": "persons/s", "cores": best_t, "kind": "port",
+            "port_vs_reference": pvr, "port_vs_reference_source": pvr_src,
+            "reference_estimate": round(results[best_t] / pvr, 1) if pvr else None,
             "one_thread": round(results.get(1, 0.0), 1), "host_cores": ncpu, "usable_cores": usable,
             "cgroup_cpu_quota": quota, "cpu_model": cpu_model(),
             "sweep": {str(t): round(v, 1) for t, v in sorted(results.items())},
@@ -110,15 +122,16 @@ def cpu_baseline(sd, kps_np, kk, budget_s):
 
 
 def traffic_from_profiles(args):
-    """HBM bytes per dense launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
-    collected with rocprofv3 in separate runs of this very command; PMC cannot be read live).  None if the
+    """HBM bytes per dense launch (and the MFMA-busy share / HBM rate of the same launches) from the PMC passes committed under
+    profiles/ (tools/traffic_from_pmc.py: FETCH_SIZE x2 + WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE, collected
+    with rocprofv3 in separate runs of this very command; PMC cannot be read live).  Returns (record, source) or None if the
     committed measurement does not cover this configuration."""
     if args.workload != 'mono' or args.precision != 'f16x2' or args.batch != 65536 or args.no_merge or args.total_rows:
         return None
-    for name in ('r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
+    for name in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
-            return json.load(open(path))['hbm_bytes_per_launch'], "replayed:profiles/" + name
+            return json.load(open(path)), "replayed:profiles/" + name
     return None
 
 
@@ -394,7 +407,7 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         g = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_train_inputs.npz'))
         res = {"config": "BASELINE configs[4]: LocoModel 34->1024->9 train-mode fwd + MultiTaskLoss + bwd + clip + Adam, "
                          "dropout 0.2; fp32 tensors.  Below 4096 rows the mid route (monoloco_amd/csrc/train_mid.h): every GEMM "
-                         "on the exact fp32 MFMA reading the row-major tensors as they lie, 42 launches per step -> fraction of "
+                         "on the exact fp32 MFMA reading the row-major tensors as they lie (launch list: profiles/r04_train_kernel_stats_rows331.txt) -> fraction of "
                          "the 157 TF fp32-MFMA peak.  From 4096 rows the hidden-layer GEMMs run on the 3-product fp16 MFMA "
                          "kernel (fp32-class accuracy): fraction of the 833 TF (2500 / 3) a 3-product scheme can reach"}
         sd_t = {k: torch.tensor(v) for k, v in synth.make_state_dict(31, 34, 9, 1024).items()}
@@ -460,7 +473,7 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
                    "val_d_first_last": [round(tr2.epoch_losses['val']['d'][0], 4), round(tr2.epoch_losses['val']['d'][-1], 4)],
                    "note": "device_call = time inside ml_trainer_step / ml_trainer_eval (each synchronises the stream); the rest "
                            "is the epoch's row permutation (the draws of the reference's DataLoader, without the loader), one index upload and two "
-                           "index_selects per batch, and the epoch bookkeeping"}
+                           "row-gather launches per batch, and the epoch bookkeeping"}
             tr.hip.close()
             tr2.hip.close()
             return res
@@ -484,14 +497,14 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         # row counts between one image and the headline batch (a video batch, a handful of camera streams): the same pipeline, the
         # dense layers on the kernel the engine picks for that row count (small-row <= 512 < dense_mid_kernel <= 8192 < 256x256 tiles)
         res = {"config": "the same mono pipeline at other batch sizes, one GPU; route = the dense kernel family the engine chooses"}
-        for rows in (1024, 2048, 4096, 8192, 16384):
+        for rows in (1024, 2048, 4096, 6144, 8192, 16384):
             k = kps[:rows].contiguous()
             c = conf[:rows].contiguous()
             o = torch.empty((rows, 16), dtype=torch.float32, device=dev)
             x = torch.empty((rows, 5), dtype=torch.float32, device=dev)
             ms = _ms(lambda: eng.forward_mono(k, kinv, box_conf=c, out=o, xyzds=x), 60, 10, dev)
             res["rows_%d" % rows] = {"us_per_step": round(ms * 1e3, 1), "persons_per_s": round(rows / ms * 1e3, 1),
-                                     "route": "small" if rows <= 512 else ("mid" if rows <= 8192 else "tile")}
+                                     "route": eng.route_for_rows(rows)}
         return res
     guarded("other_batches", other_batches)
 
@@ -791,12 +804,21 @@ def main(argv=None):
             line["config4_strong"] = strong4
         if prof and prof['launches']:
             dense_s = prof['total_ms'] * 1e-3
+            replay = traffic_from_profiles(args)
             alg_flop = FLOP_PER_ROW[args.workload] * rows * args.steps
             achieved = alg_flop / dense_s / 1e12
             line["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16_DENSE, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS_F16_DENSE, 4), "traffic": (traffic_from_profiles(args) or (None, None))[0],
-                "traffic_source": (traffic_from_profiles(args) or (None, "none: PMC cannot be read live; no committed pass covers this configuration"))[1],
+                "frac": round(achieved / PEAK_TFLOPS_F16_DENSE, 4),
+                "traffic": replay[0]["hbm_bytes_per_launch"] if replay else None,
+                "traffic_source": replay[1] if replay else "none: PMC cannot be read live; no committed pass covers this configuration",
+                "algorithmic_bytes_per_launch": replay[0].get("algorithmic_bytes_per_launch") if replay else None,
+                # the two counters the north_star names, replayed from the same committed passes (their own *_source fields)
+                "mfma_busy": replay[0].get("mfma_busy") if replay else None,
+                "mfma_busy_source": (replay[1] + " (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), launch-weighted)") if replay and replay[0].get("mfma_busy") is not None else None,
+                "hbm_gbps": replay[0].get("hbm_gbps") if replay else None,
+                "hbm_gbps_source": (replay[1] + " (HBM bytes / kernel duration under rocprofv3; HBM peak ~8000 GB/s)") if replay and replay[0].get("hbm_gbps") is not None else None,
+                "hbm_gbps_live": round((replay[0]["hbm_bytes_per_launch"] * prof['launches']) / (prof['total_ms'] * 1e-3) / 1e9, 1) if replay else None,
                 "kernel": "mlk::dense_kernel_%s<%d,*,*,*>" % ({2: "pp", 260: "w4"}.get(args.tile_kernel, "w4 (6 long-K layers) + dense_kernel_pp (input and fused-head layers)"), {'f16x2': 3, 'f16': 1, 'bf16': 0}[args.precision]),
                 "launches": prof['launches'], "avg_launch_ms": round(prof['total_ms'] / prof['launches'], 5),
                 "per_layer_avg_ms": [round(a / max(n, 1), 5) for a, n in zip(prof['per_layer_ms'], prof['per_layer_n'])],

@@ -360,6 +360,15 @@ int ml_debug_get_layer(const ml_loco* h, int layer, float* w_host, float* b_host
 int ml_debug_num_layers(const ml_loco* h);
 /* How many ml_loco_frame_mono calls of this process ran without any copy operation (pinned buffers, <= 128 persons). */
 long long ml_debug_frames_without_copies(void);
+/* Which dense kernel family a forward of `rows` network rows takes on this handle (its precision and tuning): one of the
+ * ML_ROUTE_* codes below (-1: bad argument).  Reporting only (bench.py labels its per-batch-size lines with it). */
+#define ML_ROUTE_SMALL16 0 /* dense_small_kernel, 16 x 16 output tiles (a single image) */
+#define ML_ROUTE_SMALL32 1 /* dense_small32_kernel */
+#define ML_ROUTE_MID64 2   /* dense_mid_kernel, 128 x 64 workgroup tiles */
+#define ML_ROUTE_MID128 3  /* dense_mid_kernel, 128 x 128 */
+#define ML_ROUTE_HALF 4    /* dense_kernel_w4 with its half-size 256 x 128 tile for the long-K layers (dense_mid_kernel for the input layer) */
+#define ML_ROUTE_TILE 5    /* the persistent 256 x 256-tile kernels (dense_kernel_w4 / dense_kernel_pp) with fused heads */
+int ml_loco_route(const ml_loco* h, int64_t rows);
 /* Path selection of ONE handle, for tests / A-B runs that compare the paths (negative = leave unchanged; defaults 512 / 128 /
  * 0 / 4): rows <= small_rows take the small-row dense kernels, above small32_rows those use 32x32 tiles; chunk_rows > 0 walks
  * the batch in row chunks of that size through all layers; tile_kernel: 4 = dense_kernel_w4 for the long-K layers,

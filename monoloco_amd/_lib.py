@@ -109,6 +109,7 @@ SIGNATURES = {
     'ml_debug_get_layer': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),
                                    POINTER(c_int)]),
     'ml_debug_num_layers': (c_int, [_P]),
+    'ml_loco_route': (c_int, [_P, c_int64]),
     'ml_loco_set_tuning': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int]),
     'ml_debug_get_packed': (c_int, [_P, c_int, POINTER(c_uint16), c_int64]),
     'ml_debug_get_head': (c_int, [_P, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_int),

@@ -464,8 +464,15 @@ bool w4_runs(const Tuning& tu, int K, int head_nh) {
     return tu.tile_kernel == 4 && K % 64 == 0 && (tu.tile_all || (K > 128 && head_nh <= 0));
 }
 
+// does a call of `rows` network rows (inside the mid window) put its long-K layers on dense_kernel_w4's half-size tile?  Decided on
+// the whole call like the window itself: row chunks of one call must take the same kernels (bit-identical results)
+bool use_half_tile(const Tuning& tu, int precision, int64_t rows) {
+    return precision == ML_PREC_F16X2 && (tu.mid_tile == 256 || (tu.mid_tile == 0 && round_up64(rows, 256) > tu.half_from));
+}
+
+// mid: 0 = no, 1 = the mid-size path (dense_mid_kernel), 2 = ... with dense_kernel_w4's half-size tile for the long-K layers
 int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0, int64_t rows = -1,
-                 bool mid = false) {
+                 int mid = 0) {
     mlk::DenseParams p = p_in;
     p.debug = dense_debug_bits();
     p.trace = nullptr;
@@ -475,8 +482,7 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
         // the upper part of the window: dense_kernel_w4 with its HALF-SIZE tile (256 n x 128 m, NJ = 2) for the long-K layers --
         // one wave per SIMD, AGPR accumulators, the LDS-DMA ring: half the LDS traffic per MFMA of dense_mid_kernel's 64 x 64 wave
         // tiles, and (rows / 128) * (N / 256) tiles where the full-size kernel has half as many (8192 rows: 256 instead of 128)
-        const bool half = precision == ML_PREC_F16X2 && p.K > 128 && p.K % 64 == 0 && p.N % 256 == 0 && p.M_pad % 128 == 0 &&
-                          (tu.mid_tile == 256 || (tu.mid_tile == 0 && p.M_pad > tu.half_from));
+        const bool half = mid == 2 && precision == ML_PREC_F16X2 && p.K > 128 && p.K % 64 == 0 && p.N % 256 == 0 && p.M_pad % 128 == 0;
         if (half) {
             const int htiles = (p.M_pad / 128) * (p.N / mlk::BN);
             const dim3 hgrid((unsigned)(htiles < num_cus() ? htiles : num_cus()));
@@ -752,7 +758,8 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             }
             const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
             if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
-            int rc = launch_dense(h->tune, h->precision, p, st, fused ? fused->nh : (fused_aux ? -1 : 0), small ? rows_here : -1, mid);
+            int rc = launch_dense(h->tune, h->precision, p, st, fused ? fused->nh : (fused_aux ? -1 : 0), small ? rows_here : -1,
+                                  mid ? (use_half_tile(h->tune, h->precision, rows) ? 2 : 1) : 0);
             if (rc) return rc;
             if (timed) {
                 HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));
@@ -1135,8 +1142,9 @@ static int launch_prep(hipStream_t st, const float* kps, int64_t m, const mlk::K
     if (cover <= 8192)
         hipLaunchKernelGGL(mlk::prep_kernel<32>, dim3((unsigned)((cover + 31) / 32)), dim3(256), 0, st, kps, m, ki, z_met, x_f32, centre,
                            lines, kpad, fill_rows, zero_center);
-    else
-        hipLaunchKernelGGL(mlk::prep_kernel<256>, dim3((unsigned)((cover + 255) / 256)), dim3(256), 0, st, kps, m, ki, z_met, x_f32,
+    else   // 64 persons per workgroup (round 4; 256 before: one workgroup per CU at 65536 persons, its load / compute / store phases
+           // in sequence with nothing to overlap them: 24.6 us = 1.25 TB/s; with 22 KiB of LDS several workgroups share a CU)
+        hipLaunchKernelGGL(mlk::prep_kernel<64>, dim3((unsigned)((cover + 63) / 64)), dim3(256), 0, st, kps, m, ki, z_met, x_f32,
                            centre, lines, kpad, fill_rows, zero_center);
     HIP_TRY(hipGetLastError());
     return ML_OK;
@@ -1479,6 +1487,20 @@ int ml_debug_split_f16(const float* host_in, int64_t n, uint16_t* host_hi, uint1
     return ML_OK;
 }
 
+int ml_loco_route(const ml_loco* h, int64_t rows) {
+    // which dense kernel family a forward of `rows` network rows takes on this handle (its precision and tuning); the mid window's
+    // long-K layers: 64- / 128-row dense_mid_kernel tiles or dense_kernel_w4's half-size tile
+    if (!h || rows < 0) return -1;
+    if (use_small_path(h->tune, h->precision, rows)) return rows > h->tune.small32_rows ? ML_ROUTE_SMALL32 : ML_ROUTE_SMALL16;
+    if (use_mid_path(h->tune, h->precision, rows)) {
+        const int64_t m_pad = round_up64(rows, 256);
+        if (use_half_tile(h->tune, h->precision, rows)) return ML_ROUTE_HALF;
+        if (h->tune.mid_tile == 64 || h->tune.mid_tile == 128) return h->tune.mid_tile == 64 ? ML_ROUTE_MID64 : ML_ROUTE_MID128;
+        return (m_pad / 128) * (h->hidden / mlk::MID_TN) >= num_cus() ? ML_ROUTE_MID128 : ML_ROUTE_MID64;
+    }
+    return ML_ROUTE_TILE;
+}
+
 int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel, int mid_rows, int mid_tile) {
     // negative = keep; the defaults are 512 / 128 / 0 / 4 / 8192 / 0 (measured crossovers, profiles/r03_mid_sweep.txt)
     if (mid_tile > 0 && mid_tile != 64 && mid_tile != 128 && mid_tile != 256)
@@ -1646,7 +1668,7 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
                 hipLaunchKernelGGL(mlk::lines_to_bf16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, rl, pairs);
             }
         }
-        rc = launch_dense(tu, precision, p, st, 0, small_path ? m : -1, mid_path);
+        rc = launch_dense(tu, precision, p, st, 0, small_path ? m : -1, mid_path ? (use_half_tile(tu, precision, m) ? 2 : 1) : 0);
         if (!rc) {
             const int64_t groups = m * (n / 8);
             hipLaunchKernelGGL(mlk::lines_to_f32_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, p.y, m,

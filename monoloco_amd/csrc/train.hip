@@ -118,6 +118,7 @@ struct ml_trainer {
     int apply_cols = 8;              // columns a workgroup of the column-owner kernels takes (4 | 8 | 16): ml_trainer_set_tuning
     int pair_gemm = 1;               // both gradients of a Linear in one launch (xgemm_pair_kernel); side_stream = 2 turns it off
     double* h_loss = nullptr;        // pinned: up to HL_GRID x LOSS_NV partial sums
+    double* h_loss_dev = nullptr;    // the device address of h_loss (heads_loss_kernel writes there directly), null: copy from d_lpart
     double* d_lpart = nullptr;       // the same on the device (heads_loss_kernel)
     float* w_snap = nullptr;         // ml_trainer_snapshot: parameters + running statistics kept on the device (best epoch)
     double last_vals[10] = {0};      // plain task means + validation-type d (L1) / ori (angle, radians) of the last step's outputs
@@ -754,7 +755,9 @@ int mid_forward(ml_trainer* t, hipStream_t st, const float* x_dev, const float* 
         p.lab = labels_dev; p.L = label_cols; p.m = (long)m; p.H = H;
         p.out = t->d_out; p.dout = eval ? nullptr : t->d_dout;
         p.tw = task_weights ? t->d_tw : nullptr;
-        p.part = t->d_lpart;
+        // the per-workgroup partial sums go straight into PINNED host memory (a kernel may write device-mapped host memory; the
+        // step's stream synchronisation makes them visible): no device-to-host copy operation behind the kernel
+        p.part = t->h_loss_dev ? t->h_loss_dev : t->d_lpart;
         if (C == 10) hipLaunchKernelGGL(mlt::heads_loss_kernel<10>, dim3(hl_grid), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(mlt::heads_loss_kernel<9>, dim3(hl_grid), dim3(256), 0, st, p);
     }
@@ -794,7 +797,8 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     int hl_grid = 0;
     if ((rc = mid_forward(t, st, x_dev, labels_dev, label_cols, m, seed, false, task_weights, &hl_grid))) return rc;
     if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
-    T_TRY(hipMemcpyAsync(t->h_loss, t->d_lpart, (size_t)hl_grid * mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));   // pinned
+    if (!t->h_loss_dev)
+        T_TRY(hipMemcpyAsync(t->h_loss, t->d_lpart, (size_t)hl_grid * mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));   // pinned
     // ---------------- backward (every gradient tensor is written in full: no memset of g).  The narrow gradients (head weights
     // and biases, input-layer weights) ride in the column-owner kernels of the blocks whose data they read.
     // dz of one block from its incoming gradient
@@ -951,6 +955,10 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
     t->red_slots = red_slots_for(num_stage);
     T_TRY(hipMalloc((void**)&t->d_red_base, (size_t)t->red_slots * (2 * hidden + 32) * sizeof(double)));
     T_TRY(hipHostMalloc((void**)&t->h_loss, HL_GRID * mlt::LOSS_NV * sizeof(double), hipHostMallocDefault));
+    if (hipHostGetDevicePointer((void**)&t->h_loss_dev, t->h_loss, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        t->h_loss_dev = nullptr;
+    }
     T_TRY(hipMalloc((void**)&t->d_lpart, HL_GRID * mlt::LOSS_NV * sizeof(double)));
     {   // flat offsets of the H x H matrices by Linear slot (2s, 2s + 1 = stage s w1 / w2, 2S = w2, 2S + 1 = w3) and the
         // segments between them (everything else), for the mid route's gradient norm
@@ -1111,7 +1119,8 @@ int ml_trainer_eval(ml_trainer* t, const float* x_dev, const float* labels_dev, 
             return rc;
         if (raw_out_dev)
             T_TRY(hipMemcpyAsync(raw_out_dev + off * t->C, t->d_out, (size_t)mc * t->C * 4, hipMemcpyDeviceToDevice, st));
-        T_TRY(hipMemcpyAsync(t->h_loss, t->d_lpart, (size_t)parts * mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (!t->h_loss_dev)
+            T_TRY(hipMemcpyAsync(t->h_loss, t->d_lpart, (size_t)parts * mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));
         T_TRY(hipStreamSynchronize(st));
         double v[mlt::LOSS_NV];
         sum_loss_parts(t, parts, v);

@@ -400,6 +400,13 @@ class LocoEngine:
                                                        int(seed), _ptr(epi), None, _stream(dev)))
         return epi
 
+    ROUTES = ('small16', 'small32', 'mid64', 'mid128', 'half', 'tile')
+
+    def route_for_rows(self, rows):
+        """Name of the dense kernel family a forward of `rows` network rows takes on this engine (ml_loco_route)."""
+        code = int(_lib.load().ml_loco_route(self._h, int(rows)))
+        return self.ROUTES[code] if 0 <= code < len(self.ROUTES) else 'unknown'
+
     # -- measurement
     def profile_begin(self, max_launches=65536):
         check(_lib.load().ml_loco_profile_begin(self._h, int(max_launches)))

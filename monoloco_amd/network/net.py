@@ -9,6 +9,9 @@ reference's per-person Python loop is quadratic in the number of persons).
 import ctypes
 import logging
 from collections import defaultdict
+from itertools import chain as _chain_cls
+
+_chain = _chain_cls.from_iterable
 
 import numpy as np
 import torch
@@ -23,6 +26,24 @@ def _f64_list(t):
     """A column of fp32 results as Python floats (each the exact double of its fp32 value: what float(tensor[i]) yields)."""
     a = t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float32)
     return a.reshape(-1).astype(np.float64).tolist()
+
+
+def _lists_to_f32(keypoints):
+    """[m][3][17] nested Python lists (preprocess_pifpaf's keypoints) -> one (m, 3, 17) float32 array.  np.fromiter over the
+    flattened lists is ~1.5x faster than np.asarray on nested lists (the per-frame host cost the reference's list API implies);
+    anything that is not a plain list of [3][17] lists takes np.asarray (which also raises on ragged input)."""
+    m = len(keypoints)
+    first = keypoints[0]
+    if (type(keypoints) is list and type(first) is list and len(first) == 3 and type(first[0]) is list and len(first[0]) == 17
+            and type(keypoints[-1]) is list and len(keypoints[-1]) == 3 and len(keypoints[-1][2]) == 17):
+        it = _chain(_chain(keypoints))
+        try:
+            arr = np.fromiter(it, dtype=np.float32, count=m * 51)
+            if next(it, None) is None:
+                return arr.reshape(m, 3, 17)
+        except (ValueError, TypeError):
+            pass
+    return np.asarray(keypoints, dtype=np.float32)
 
 
 class _LocoOut(dict):
@@ -85,7 +106,7 @@ class Loco:
         dev = self.device
         if self.net == 'monoloco_pp' and not (isinstance(keypoints, torch.Tensor) and keypoints.is_cuda):
             # one image from the host (the reference's call, predict.py:231-249): lists -> ONE float32 array, staged below
-            kps = np.asarray(keypoints, dtype=np.float32) if not isinstance(keypoints, torch.Tensor) else keypoints.float().numpy()
+            kps = _lists_to_f32(keypoints) if not isinstance(keypoints, torch.Tensor) else keypoints.float().numpy()
         else:
             kps = engine._dev_f32(keypoints, dev)
         kk_list = kk.tolist() if hasattr(kk, 'tolist') else kk

@@ -77,8 +77,8 @@ def main():
            "cpu_model": next((ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')), '?'),
            "host_cores": os.cpu_count(), "torch": torch.__version__, "by_threads": res,
            "port_vs_reference": round(statistics.median(ratios), 4),
-           "note": "ratio > 1: the port is faster than the reference (it skips nothing of the arithmetic, but builds fewer "
-                   "intermediate tensors); the reference's persons/s on the GPU box's CPU is estimated as cpu_baseline.value / ratio"}
+           "note": "ratio < 1: the port is a little slower than the reference on this CPU (same arithmetic, bit-identical outputs; it builds a few more "
+                   "intermediate tensors); reference persons/s on the GPU box = cpu_baseline.value / ratio"}
     path = os.path.join(ROOT, 'profiles', 'r04_port_vs_reference.json')
     json.dump(out, open(path, 'w'), indent=1)
     print("wrote", path, "ratio", out["port_vs_reference"])
