@@ -46,6 +46,27 @@ def _lists_to_f32(keypoints):
     return np.asarray(keypoints, dtype=np.float32)
 
 
+_PYHOST = [False]
+
+
+def _pyhost():
+    """The optional CPython helper (monoloco_amd/lib/libmonoloco_pyhost.so, csrc/pyhost.c) or None: nested keypoint lists -> the
+    pinned staging buffer without an intermediate array.  Host-side marshalling only; numpy does the same job when it is missing."""
+    if _PYHOST[0] is False:
+        import os
+        lib = None
+        path = os.path.join(os.path.dirname(engine._lib.LIB_PATH), 'libmonoloco_pyhost.so')
+        if os.path.exists(path):
+            try:
+                lib = ctypes.PyDLL(path)
+                lib.ml_py_fill_kps.restype = ctypes.c_int
+                lib.ml_py_fill_kps.argtypes = [ctypes.py_object, ctypes.c_void_p, ctypes.c_long]
+            except (OSError, AttributeError):
+                lib = None
+        _PYHOST[0] = lib
+    return _PYHOST[0]
+
+
 class _LocoOut(dict):
     """The dictionary Loco.forward returns: a plain dict of the reference's keys, plus (as an attribute, not a key) the
     geometry block of the same keypoints that post_process would otherwise recompute."""
@@ -106,7 +127,9 @@ class Loco:
         dev = self.device
         if self.net == 'monoloco_pp' and not (isinstance(keypoints, torch.Tensor) and keypoints.is_cuda):
             # one image from the host (the reference's call, predict.py:231-249): lists -> ONE float32 array, staged below
-            kps = _lists_to_f32(keypoints) if not isinstance(keypoints, torch.Tensor) else keypoints.float().numpy()
+            # (a plain list stays a list here: _forward_pp_staged walks it straight into the pinned staging buffer)
+            kps = keypoints if type(keypoints) is list else (
+                _lists_to_f32(keypoints) if not isinstance(keypoints, torch.Tensor) else keypoints.float().numpy())
         else:
             kps = engine._dev_f32(keypoints, dev)
         kk_list = kk.tolist() if hasattr(kk, 'tolist') else kk
@@ -125,7 +148,7 @@ class Loco:
             dic_out = extract_outputs_mono(self.engine.forward_raw(x))
             n_out = kps.shape[0]
         elif self.net == 'monoloco_pp':
-            dic_out, geo_host = self._forward_pp_staged(kps, kinv)
+            dic_out, geo_host, kps = self._forward_pp_staged(kps, kinv)   # (kps: now the float32 array / device tensor)
             n_out = kps.shape[0]
         else:
             if keypoints_r is not None and len(keypoints_r) > 0:
@@ -174,7 +197,7 @@ class Loco:
         (dictionary of fresh CPU tensors, fresh (m,12) geometry tensor)."""
         lib = engine._lib.load()
         dev = self.device
-        m = int(kps.shape[0])
+        m = len(kps) if type(kps) is list else int(kps.shape[0])
         stride = engine._lib.ML_OUT_STRIDE
         st = self._stage.get(m)
         if st is None:
@@ -186,6 +209,10 @@ class Loco:
                       buf=torch.empty((m * (stride + 12),), dtype=torch.float32, device=dev),
                       xyzds=torch.empty((m, engine._lib.ML_XYZDS_STRIDE), dtype=torch.float32, device=dev),
                       pin_out=pin_out, np_out=pin_out.numpy())
+            # where every value of the result layout lies in the pinned [packed (m,16) | geometry (m,12)] block
+            idx = np.arange(m * stride).reshape(m, stride)
+            st['perm'] = np.concatenate([idx[:, [8, 9, 10, 4, 5, 6, 3]].T.reshape(-1), idx[:, 12:14].reshape(-1), idx[:, 0:4].reshape(-1),
+                                         np.arange(m * stride, m * (stride + 12))]).astype(np.intp)
             st['p_in'] = ctypes.c_void_p(st['dev_in'].data_ptr())
             st['p_out'] = ctypes.c_void_p(st['buf'].data_ptr())
             st['p_d'] = ctypes.c_void_p(st['buf'].data_ptr() + 3 * 4)
@@ -205,26 +232,25 @@ class Loco:
                 st['pin_out'].copy_(st['buf'], non_blocking=True)
                 torch.cuda.current_stream(dev).synchronize()
         else:                                 # the frame in ONE foreign call: H2D, pipeline, geometry, D2H, stream sync
-            assert kps.shape[1:] == (3, 17), "keypoints must be (m, 3, 17)"
-            np.copyto(st['np_in'], kps)
+            if type(kps) is list:   # nested lists: the C walk (csrc/pyhost.c) where it applies, numpy otherwise
+                ph = _pyhost()
+                if ph is None or ph.ml_py_fill_kps(kps, st['p_pin_in'], m) != 0:
+                    np.copyto(st['np_in'], _lists_to_f32(kps))
+                kps = st['np_in']
+            else:
+                assert kps.shape[1:] == (3, 17), "keypoints must be (m, 3, 17)"
+                np.copyto(st['np_in'], kps)
             with torch.cuda.device(dev):
                 engine.check(lib.ml_loco_frame_mono(self.engine._h, st['p_pin_in'], m, kinv_p, st['p_in'], st['p_out'], st['p_xyzds'],
                                                     st['p_pin_out'], stream))
-        host = st['np_out']
-        n = m * stride
-        packed = host[:n].reshape(m, stride)
         # the reference's dictionary (process.py:240-278) out of ONE fresh buffer: 7 single columns (h w l bi yaw yaw_ego d), then
-        # ori (m,2), xyzd (m,4) and the (m,12) geometry block; one torch.from_numpy, every output a view of its own range
-        fresh = np.empty((25 * m,), dtype=np.float32)
-        fresh[:7 * m].reshape(7, m)[...] = packed[:, [8, 9, 10, 4, 5, 6, 3]].T
-        fresh[7 * m:9 * m].reshape(m, 2)[...] = packed[:, 12:14]
-        fresh[9 * m:13 * m].reshape(m, 4)[...] = packed[:, 0:4]
-        fresh[13 * m:] = host[n:]
-        t = torch.from_numpy(fresh)
+        # ori (m,2), xyzd (m,4) and the (m,12) geometry block -- one gather of the pinned result through an index vector cached per
+        # person count, one torch.from_numpy, every output a view of its own range
+        t = torch.from_numpy(st['np_out'].take(st['perm']))
         h_, w_, l_, bi_, yaw_, yawe_, d_ = t[:7 * m].view(7, m, 1).unbind(0)
         dic = {'h': h_, 'w': w_, 'l': l_, 'ori': t[7 * m:9 * m].view(m, 2), 'bi': bi_, 'xyzd': t[9 * m:13 * m].view(m, 4), 'd': d_,
                'yaw': (yaw_, yawe_)}
-        return dic, t[13 * m:].view(m, 12)
+        return dic, t[13 * m:].view(m, 12), kps
 
     def _packed_buffers(self, m):
         """One device allocation for the packed (m,16) network result and the (m,12) post-process geometry."""

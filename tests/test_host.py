@@ -250,3 +250,33 @@ def test_epoch_batches_are_the_dataloaders():
         ref = [[b.tolist() for b in loader] for _ in range(2)]
         assert mine == ref and torch.equal(state_mine, torch.get_rng_state())
         assert sorted(i for b in mine[0] for i in b) == list(range(n))
+
+
+def test_pyhost_list_walk_matches_numpy():
+    """csrc/pyhost.c (optional host helper of Loco.forward): [m][3][17] nested lists straight into a float32 buffer -- the same
+    values as np.asarray(dtype=float32), ints accepted, anything else refused (the caller then takes the numpy route)."""
+    import ctypes
+    import subprocess
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(['make', '-C', os.path.join(root, 'monoloco_amd', 'csrc'), 'pyhost'], check=True, stdout=subprocess.DEVNULL)
+    from monoloco_amd.network import net as N
+    N._PYHOST[0] = False
+    ph = N._pyhost()
+    assert ph is not None
+    rng = np.random.default_rng(0)
+    kp = (rng.random((16, 3, 17)) * 1000).tolist()
+    kp[2][1][5] = 7                                            # a Python int among the floats
+    dst = np.full((16, 3, 17), -1.0, dtype=np.float32)
+    assert ph.ml_py_fill_kps(kp, dst.ctypes.data, 16) == 0
+    assert np.array_equal(dst, np.asarray(kp, dtype=np.float32))
+    assert ph.ml_py_fill_kps(kp, dst.ctypes.data, 15) == 1     # wrong person count
+    bad = [list(p) for p in kp]
+    bad[3] = bad[3][:2]                                        # ragged
+    assert ph.ml_py_fill_kps(bad, dst.ctypes.data, 16) == 1
+    bad = [list(p) for p in kp]
+    bad[0] = [list(r) for r in bad[0]]
+    bad[0][0][0] = 'x'
+    assert ph.ml_py_fill_kps(bad, dst.ctypes.data, 16) == 1
+    assert ph.ml_py_fill_kps(tuple(kp), dst.ctypes.data, 16) == 1   # not a list: numpy's job
+    assert np.array_equal(N._lists_to_f32(kp), np.asarray(kp, dtype=np.float32))
