@@ -148,3 +148,22 @@ def test_trainer_eval_walks_a_large_set_in_chunks(hip_lib, cuda_device):
                      device=cuda_device)
     assert not tr2.can_evaluate
     tr2.close()
+
+
+def test_route_query_follows_the_tuning(hip_lib, cuda_device):
+    """ml_loco_route: the dense kernel family a forward of `rows` rows takes (bench.py labels its lines with it)."""
+    from monoloco_amd import engine
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(1, 34, 9, 1024).items()}
+    eng = engine.LocoEngine(sd, device=cuda_device)
+    got = [eng.route_for_rows(r) for r in (16, 128, 129, 512, 513, 2048, 4096, 4097, 6144, 8192, 8193, 65536)]
+    assert got == ['small16', 'small16', 'small32', 'small32', 'mid64', 'mid64', 'mid128', 'half', 'half', 'half', 'tile', 'tile']
+    eng.set_tuning(mid_tile=64)
+    assert eng.route_for_rows(6144) == 'mid64'
+    eng.set_tuning(mid_tile=256)
+    assert eng.route_for_rows(1024) == 'half'
+    eng.set_tuning(mid_rows=0)
+    assert eng.route_for_rows(1024) == 'tile' and eng.route_for_rows(100) == 'small16'
+    eng.close()
+    bf = engine.LocoEngine(sd, device=cuda_device, precision='bf16')
+    assert bf.route_for_rows(100) == 'tile'          # the bf16 comparison mode exists on the tile path only
+    bf.close()
