@@ -298,8 +298,9 @@ int ml_trainer_restore(ml_trainer* t, void* stream);
  * internal side stream beside the data-gradient chain (events both ways; measured to pay from ~2000 rows); 2 = two launches per
  * Linear on the caller's stream (the A/B reference of 0); < 0 leaves it.  dw_layout (large-batch route): 1 (default) = the
  * weight-gradient GEMM dW = dz^T . x reads dz and x reduction-major, as the [batch][hidden] lines they already exist as
- * (gfx950's transposing LDS read feeds the MFMA); 0 = through transposed copies of both (round 2's path: same bits, 2 ms more
- * per 65536-row step); < 0 leaves it. */
+ * (gfx950's transposing LDS read feeds the MFMA), and dz / a stage's inner activation / the residual stream exist as lines only;
+ * 0 = through transposed copies of both operands with the fp32 chain of rounds 2-3 (2.2 ms more per 65536-row step); 2 = the
+ * reduction-major GEMM on that same fp32 chain (same bits as 0: the test's reference); < 0 leaves it. */
 int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream, int dw_layout);
 int ml_trainer_destroy(ml_trainer* t);
 const char* ml_train_last_error(void);

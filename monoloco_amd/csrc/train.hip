@@ -109,6 +109,8 @@ struct ml_trainer {
     std::vector<hipEvent_t> ev_dz, ev_w;
     int side_stream = 0;             // ml_trainer_set_tuning: 1 = weight gradients on the side stream (measured: pays from ~2000 rows)
     int ssq_per_mat = 0;
+    int lines_chain = 1;             // large-batch route: dz / inner activations / the residual stream as lines ONLY (round 4); 0 keeps their
+                                     // fp32 copies and the dz -> lines pass (ml_trainer_set_tuning dw_layout 2: the same-bits test's reference)
     int dw_trans = 1;                // weight-gradient GEMM operands: 1 = reduction-major lines as they lie (dense_kernel_w4<.., -3, true>),
                                      // 0 = transposed copies (tlines_kernel; the round-2 path, kept for the bit-identity test)
     double* d_colpart = nullptr;     // [cap / 128][2][H]: per 128-row block column sums / sums of squares the forward GEMM's epilogue leaves
@@ -424,8 +426,9 @@ int pick_route(const ml_trainer* t, int64_t m) {
 
 // x_lines: the block input as lines (or null: exact-fp32 MFMA GEMM on b.x); y_lines: where to put the block output as
 // lines as well (or null)
+// lines_only: the output is written as lines only (nothing reads it as fp32); res_lines: the residual comes from its lines
 int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* residual, const char* x_lines = nullptr,
-              char* y_lines = nullptr, int slot = -1, bool lines_only = false) {
+              char* y_lines = nullptr, int slot = -1, bool lines_only = false, const char* res_lines = nullptr) {
     const int H = t->H;
     int rc;
     const bool gemm_stats = x_lines && slot >= 0;   // the batch statistics come out of the GEMM's own epilogue
@@ -446,11 +449,11 @@ int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* r
                            (const double*)(t->d_red + H), m, H, 1e-5f, 0.1f, mean, inv, ST(t, b.bn + ".running_mean"),
                            ST(t, b.bn + ".running_var"));
     }
-    if (y_lines)
+    if (y_lines || (x_lines && (H & 7) == 0))   // (also the large-batch route's last block, no lines: 4 columns per lane instead of 1)
         hipLaunchKernelGGL(mlt::bn_relu_drop_lines_kernel, dim3(nblk(m * H / 4)), dim3(256), 0, st, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
-                           (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site, residual,
-                           lines_only ? (float*)nullptr : b.y, y_lines);
+                           (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site,
+                           res_lines ? (const float*)nullptr : residual, lines_only ? (float*)nullptr : b.y, y_lines, res_lines);
     else
         hipLaunchKernelGGL(mlt::bn_relu_drop_kernel, dim3(nblk(m * H)), dim3(256), 0, st, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
@@ -487,7 +490,7 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
         const float* src = din ? din : dout;
         // large-batch route, H x H Linear below (slot >= 0): dz leaves as scaled lines only (bn_bwd_lines_kernel), scaled by a bound
         // the statistics pass collects the column maxima for
-        const bool lines_only = slot >= 0 && t->dw_trans && b.x_lines;
+        const bool lines_only = slot >= 0 && t->dw_trans && t->lines_chain && b.x_lines;
         float* colmax = lines_only ? t->d_colmax + (size_t)slot * 2 * H : nullptr;
         hipLaunchKernelGGL(mlt::bwd_stats_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, src, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
@@ -1203,7 +1206,10 @@ int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream, int dw
     if (!t || (apply_cols != 0 && apply_cols != 4 && apply_cols != 8 && apply_cols != 16))
         return tfail(ML_ERR_ARG, "apply_cols must be 4, 8 or 16 (0: unchanged)");
     if (apply_cols) t->apply_cols = apply_cols;
-    if (dw_layout >= 0) t->dw_trans = dw_layout ? 1 : 0;   // large-batch route: weight-gradient operands reduction-major (1) | transposed copies (0)
+    if (dw_layout >= 0) {   // large-batch route: 0 transposed operand copies (round 2); 1 reduction-major operands + lines-only chain
+        t->dw_trans = dw_layout ? 1 : 0;   // (default); 2 reduction-major operands, fp32 chain as with 0
+        t->lines_chain = dw_layout == 1 ? 1 : 0;
+    }
     if (side_stream >= 0) {   // 0: both gradients of a Linear in one launch (default); 1: weight gradients on the side stream; 2: two launches
         t->side_stream = side_stream == 1 ? 1 : 0;
         t->pair_gemm = side_stream == 0 ? 1 : 0;
@@ -1288,17 +1294,22 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     auto la = [&](int s) { return fast ? t->lbufs[s] : (char*)nullptr; };
     auto lt = [&](int s) { return fast ? t->lbufs[S + 1 + s] : (char*)nullptr; };
     char* ly2 = fast ? t->lbufs[2 * S + 1] : nullptr;
-    if ((rc = block_fwd(t, st, b0, m, nullptr, nullptr, la(0)))) return rc;
+    // (round 4: on the large-batch route the residual stream a_0 .. a_S exists as lines only -- every consumer, the next Linear's
+    // GEMMs and the next stage's skip connection, reads the lines)
+    const bool stream_lines = fast && t->dw_trans && t->lines_chain;
+    if ((rc = block_fwd(t, st, b0, m, nullptr, nullptr, la(0), -1, stream_lines))) return rc;
     std::vector<Block> sa(S), sb(S);
     for (int s = 0; s < S; ++s) {
         const std::string p = "linear_stages." + std::to_string(s) + ".";
         sa[s].lin = p + "w1"; sa[s].bn = p + "batch_norm1"; sa[s].bn_idx = 1 + 2 * s; sa[s].in_dim = H;
         sa[s].x = a[s]; sa[s].x_lines = la(s); sa[s].z = za[s]; sa[s].y = tt[s]; sa[s].site = 1 + 2 * s;
         // (t_s is read by the next Linear's GEMMs only -- forward and, reduction-major, weight gradient --: lines, no fp32 copy)
-        if ((rc = block_fwd(t, st, sa[s], m, nullptr, la(s), lt(s), fast ? 2 * s : -1, fast && t->dw_trans))) return rc;
+        if ((rc = block_fwd(t, st, sa[s], m, nullptr, la(s), lt(s), fast ? 2 * s : -1, stream_lines))) return rc;
         sb[s].lin = p + "w2"; sb[s].bn = p + "batch_norm2"; sb[s].bn_idx = 2 + 2 * s; sb[s].in_dim = H;
         sb[s].x = tt[s]; sb[s].x_lines = lt(s); sb[s].z = zb[s]; sb[s].y = a[s + 1]; sb[s].site = 2 + 2 * s;
-        if ((rc = block_fwd(t, st, sb[s], m, a[s], lt(s), la(s + 1), fast ? 2 * s + 1 : -1))) return rc;  // a_{s+1} = a_s + block(t_s)
+        if ((rc = block_fwd(t, st, sb[s], m, a[s], lt(s), la(s + 1), fast ? 2 * s + 1 : -1, stream_lines,
+                            stream_lines ? la(s) : nullptr)))
+            return rc;  // a_{s+1} = a_s + block(t_s)
     }
     if (fast) {
         if ((rc = fast_linear_fwd(t, st, la(S), "w2", y2, m, 2 * S))) return rc;

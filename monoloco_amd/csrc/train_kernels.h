@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256) void bn_relu_drop_lines_kernel(const float* __
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float p_drop, uint32_t seed, uint32_t site,
                                                                 const float* __restrict__ residual, float* __restrict__ y,
-                                                                char* __restrict__ lines) {
+                                                                char* __restrict__ lines, const char* __restrict__ res_lines = nullptr) {
     const int qpr = n / 4;
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = id < m * qpr;   // (m * n / 4 is even: a lane pair is live or dead together)
@@ -773,6 +773,14 @@ __global__ __launch_bounds__(256) void bn_relu_drop_lines_kernel(const float* __
         const f32x4 r = *(const f32x4*)(residual + base);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += r[e];
+    } else if (res_lines) {
+        // the residual stream a_s exists as lines only on the large-batch route (round 4: no layer reads it as fp32): the value of
+        // a line entry is hi + lo, exact in fp32 (22 significant bits; the stream is re-rounded to that once per stage)
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const char* rp = res_lines + i * (int64_t)n * 4 + (q >> 3) * 128 + ((q >> 1) & 3) * 16 + (q & 1) * 8;
+        const h4 rh = *(const h4*)rp, rl = *(const h4*)(rp + 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
     }
     if (live && y) *(f32x4*)(y + base) = v;   // (y null: only the lines are needed -- a stage's inner activation on the large-batch route)
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(256) void bn_relu_drop_lines_kernel(const float* __
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     const u4 out = odd ? u4{s0, s1, lo2[0], lo2[1]} : u4{hi2[0], hi2[1], s0, s1};
     const int g = q >> 1;   // 8-column group
-    if (live) *(u4*)(lines + i * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16 + (odd ? 64 : 0)) = out;
+    if (live && lines) *(u4*)(lines + i * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16 + (odd ? 64 : 0)) = out;
 }
 
 // fp32 (m, n) -> TRANSPOSED lines [n][m_pad] (row j = column j of src over the batch, k32 blocks of 32 consecutive rows:
