@@ -80,6 +80,9 @@ struct ml_trainer {
     std::vector<char*> lbufs;                         // 2S + 2 buffers of cap x H lines
     std::vector<char*> wl;                            // 2S + 2 packed weight images (H x H lines)
     std::vector<float*> wbs;                          // bias * 2^e
+    std::vector<char*> wlT;                           // ... and of W^T (data gradient); all images of a step are packed up front
+    mlt::WLayer* d_wdesc = nullptr;                   // device table of the 2S + 2 Linears for wmax_multi / wpack_multi
+    bool packed_all = false;                          // this step's images are already packed (pack_all_weights)
     float* wsc_base = nullptr;                        // per image 8 scale words (train_kernels.h, wmax_kernel)
     char *tl_dz = nullptr, *tl_x = nullptr;           // transposed lines [H][capT] of dz and of a layer input (dW = dz^T . x)
     int64_t capT = 0;
@@ -322,9 +325,11 @@ int fast_linear_fwd(ml_trainer* t, hipStream_t st, const char* x_lines, const st
                     bool col_stats_too = false) {
     const int H = t->H;
     float* sc = t->wsc_base + 8 * slot;   // (zeroed at the start of the step)
-    hipLaunchKernelGGL(mlt::wmax_kernel, dim3(64), dim3(256), 0, st, (const float*)P(t, lin + ".weight"), (int64_t)H * H, sc + 2);
-    hipLaunchKernelGGL(mlt::wpack_kernel<false>, dim3(nblk((int64_t)H * H / 8)), dim3(256), 0, st, (const float*)P(t, lin + ".weight"),
-                       (const float*)P(t, lin + ".bias"), H, H, H, sc, t->wl[slot], t->wbs[slot]);
+    if (!t->packed_all) {
+        hipLaunchKernelGGL(mlt::wmax_kernel, dim3(64), dim3(256), 0, st, (const float*)P(t, lin + ".weight"), (int64_t)H * H, sc + 2);
+        hipLaunchKernelGGL(mlt::wpack_kernel<false>, dim3(nblk((int64_t)H * H / 8)), dim3(256), 0, st, (const float*)P(t, lin + ".weight"),
+                           (const float*)P(t, lin + ".bias"), H, H, H, sc, t->wl[slot], t->wbs[slot]);
+    }
     return launch_fast_gemm(t, st, x_lines, t->wl[slot], t->wbs[slot], sc + 1, z, m, false, col_stats_too);
 }
 
@@ -334,6 +339,7 @@ int fast_linear_bwd_data(ml_trainer* t, hipStream_t st, const char* dz_lines, co
                          bool accumulate) {
     const int H = t->H;
     float* sc = t->wsc_base + 8 * slot;
+    if (t->packed_all) return launch_fast_gemm(t, st, dz_lines, t->wlT[slot], t->zero_bias, sc + 4, dx, m, accumulate);
     hipLaunchKernelGGL(mlt::wpack_kernel<true>, dim3(nblk((int64_t)H * H / 8)), dim3(256), 0, st, (const float*)P(t, lin + ".weight"),
                        (const float*)nullptr, H, H, H, sc, t->wl[slot], (float*)nullptr);
     return launch_fast_gemm(t, st, dz_lines, t->wl[slot], t->zero_bias, sc + 4, dx, m, accumulate);
@@ -584,6 +590,26 @@ int ensure_cap(ml_trainer* t, int64_t m) {
                 T_TRY(hipMalloc((void**)&b, (size_t)t->H * 4));
                 t->wl.push_back(w);
                 t->wbs.push_back(b);
+                char* wt = nullptr;
+                T_TRY(hipMalloc((void**)&wt, (size_t)t->H * t->H * 4));
+                t->wlT.push_back(wt);
+            }
+            {   // the table the multi-layer pack kernels index by Linear slot (2s, 2s + 1 = stage s w1 / w2, 2S = w2, 2S + 1 = w3)
+                std::vector<mlt::WLayer> desc;
+                auto add = [&](const std::string& lin, int slot) {
+                    mlt::WLayer l;
+                    l.w = P(t, lin + ".weight"); l.bias = P(t, lin + ".bias"); l.sc = t->wsc_base + 8 * slot;
+                    l.lines = t->wl[slot]; l.linesT = t->wlT[slot]; l.bias_scaled = t->wbs[slot];
+                    desc.push_back(l);
+                };
+                for (int s2 = 0; s2 < t->S; ++s2) {
+                    add("linear_stages." + std::to_string(s2) + ".w1", 2 * s2);
+                    add("linear_stages." + std::to_string(s2) + ".w2", 2 * s2 + 1);
+                }
+                add("w2", 2 * t->S);
+                add("w3", 2 * t->S + 1);
+                T_TRY(hipMalloc((void**)&t->d_wdesc, desc.size() * sizeof(mlt::WLayer)));
+                T_TRY(hipMemcpy(t->d_wdesc, desc.data(), desc.size() * sizeof(mlt::WLayer), hipMemcpyHostToDevice));
             }
         }
     }
@@ -1025,6 +1051,8 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (float* p : t->bufs) (void)hipFree(p);
     for (char* p : t->lbufs) (void)hipFree(p);
     for (char* p : t->wl) (void)hipFree(p);
+    for (char* p : t->wlT) (void)hipFree(p);
+    if (t->d_wdesc) (void)hipFree(t->d_wdesc);
     for (float* p : t->wbs) (void)hipFree(p);
     if (t->h_loss) (void)hipHostFree(t->h_loss);
     for (hipEvent_t e : t->ev_dz) (void)hipEventDestroy(e);
@@ -1277,9 +1305,16 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     // fast forward path: the activations that feed an H x H Linear also exist as lines (la[s] = a_s, lt[s] = t_s, ly2 = y2);
     // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
     const bool fast = route == 1;
+    t->packed_all = false;
     if (fast) {
         T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 2) * 32, st));
         T_TRY(hipMemsetAsync(t->d_colmax, 0, (size_t)(2 * S + 2) * 2 * H * sizeof(float), st));
+        // every weight image of the step -- W for the forward GEMMs, W^T for the data-gradient GEMMs -- in two launches up front
+        // (the weights only change in the optimizer at the end of a step)
+        hipLaunchKernelGGL(mlt::wmax_multi_kernel, dim3(64, 2 * S + 2), dim3(256), 0, st, (const mlt::WLayer*)t->d_wdesc, (int64_t)H * H);
+        hipLaunchKernelGGL(mlt::wpack_multi_kernel, dim3(nblk((int64_t)H * H / 8), 2 * S + 2, 2), dim3(256), 0, st,
+                           (const mlt::WLayer*)t->d_wdesc, H);
+        t->packed_all = true;
         if (t->pad_m != m) {
             // the weight-gradient GEMMs reduce over whole 64-row k-steps per split: rows m .. mT of every line buffer must be
             // zero (a smaller batch than the last one leaves old rows there); the writers only touch rows < m

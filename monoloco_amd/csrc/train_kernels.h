@@ -548,10 +548,9 @@ __device__ __forceinline__ int wscale_exp(float m) {
 // TRANS: the image of W^T (k rows of n values) for the data-gradient GEMM; its scale is the forward image's (same
 // weights, same step) and there is no bias.
 template <bool TRANS>
-__global__ __launch_bounds__(256) void wpack_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int kpad,
-                                                    float* __restrict__ scale2, char* __restrict__ lines,
-                                                    float* __restrict__ bias_scaled) {
-    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wpack_body(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int kpad,
+                                           float* __restrict__ scale2, char* __restrict__ lines, float* __restrict__ bias_scaled,
+                                           int64_t id) {
     const int e2 = wscale_exp(scale2[2]);
     const float sc = ldexpf(1.0f, e2);
     if (id == 0 && !TRANS) {
@@ -591,6 +590,52 @@ __global__ __launch_bounds__(256) void wpack_kernel(const float* __restrict__ w,
     char* dst = lines + (int64_t)row * width * 4 + (g >> 2) * 128 + (g & 3) * 16;
     *(h8*)dst = hi;
     *(h8*)(dst + 64) = lo;
+}
+
+template <bool TRANS>
+__global__ __launch_bounds__(256) void wpack_kernel(const float* __restrict__ w, const float* __restrict__ bias, int n, int k, int kpad,
+                                                    float* __restrict__ scale2, char* __restrict__ lines,
+                                                    float* __restrict__ bias_scaled) {
+    wpack_body<TRANS>(w, bias, n, k, kpad, scale2, lines, bias_scaled, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// All H x H Linears of a step at once (round 4: 8 x (wmax + wpack + wpack<true>) = 24 launches of 6-14 us each became 2): the
+// weights only change in the optimizer, so every image of a step -- W for the forward GEMM, W^T for the data-gradient GEMM -- can be
+// packed before the forward starts.  blockIdx.y = the Linear; wpack_multi_kernel's blockIdx.z: 0 = W, 1 = W^T.
+struct WLayer {
+    const float* w;       // [H][H]
+    const float* bias;    // [H]
+    float* sc;            // the Linear's 8 scale words
+    char* lines;          // image of W   (forward)
+    char* linesT;         // image of W^T (data gradient)
+    float* bias_scaled;   // bias * 2^e
+};
+__global__ __launch_bounds__(256) void wmax_multi_kernel(const WLayer* __restrict__ L, int64_t numel) {
+    __shared__ float red[256];
+    const float* w = L[blockIdx.y].w;
+    float mx = 0.f;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < numel; i += (int64_t)gridDim.x * 1024) {
+        const f32x4 v = *(const f32x4*)(w + i);
+        mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1]))),
+                             __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    }
+    red[threadIdx.x] = mx;   // (numel = H x H with H % 256 == 0: no tail)
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = __builtin_fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float r = red[0];
+        if (!(r < 3.0e38f)) r = 3.0e38f;
+        atomicMax((unsigned*)(L[blockIdx.y].sc + 2), __builtin_bit_cast(unsigned, r));
+    }
+}
+__global__ __launch_bounds__(256) void wpack_multi_kernel(const WLayer* __restrict__ L, int H) {
+    const WLayer l = L[blockIdx.y];
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.z == 0) wpack_body<false>(l.w, l.bias, H, H, H, l.sc, l.lines, l.bias_scaled, id);
+    else wpack_body<true>(l.w, nullptr, H, H, H, l.sc, l.linesT, nullptr, id);
 }
 
 // fp32 (m, n) -> lines (rows >= m of the padded buffer are left alone: a row of the GEMM only depends on its own input row)
