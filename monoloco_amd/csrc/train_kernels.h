@@ -10,6 +10,8 @@
 
 namespace mlt {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------
@@ -939,8 +941,8 @@ __global__ __launch_bounds__(256) void skinny_out_kernel(const float* __restrict
     const int cg = threadIdx.x & 15, rq = threadIdx.x >> 4;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (bias) b4 = *(const f32x4*)(bias + jb + cg * 4);
-    // the skinny rows of the NEXT pass are requested before this pass is multiplied (round 4: a pass used to start with a global
-    // load -> LDS -> barrier chain nothing overlapped: the input layer's forward at 65536 rows ran at 1.7 TB/s)
+    // the skinny rows of the NEXT pass are requested before this pass is multiplied (round 4; a pass used to start with a global
+    // load -> LDS -> barrier chain; measured neutral for the input layer's forward at 65536 rows: 158 us = 1.7 TB/s either way)
     constexpr int SPT = (SK_NC * 64 + 255) / 256;
     float sn[SPT];
     const int64_t step = (int64_t)gridDim.y * 64;
@@ -965,22 +967,27 @@ __global__ __launch_bounds__(256) void skinny_out_kernel(const float* __restrict
         }
         __syncthreads();
         if (i0 + step < m) request(i0 + step);
-        f32x4 acc[4] = {b4, b4, b4, b4};
+        // packed fp32 FMAs (v_pk_fma_f32: two of the same fmaf per lane and instruction -- same bits, half the VALU instructions;
+        // measured neutral at 65536 rows: the pass is bound by its store / staging latency, not by the VALU)
+        f32x2 alo[4] = {b4.xy, b4.xy, b4.xy, b4.xy}, ahi[4] = {b4.zw, b4.zw, b4.zw, b4.zw};
         for (int c = 0; c < nc; ++c) {
             const f32x4 wv = *(const f32x4*)&wl[c][cg * 4];
             const f32x4 sv = *(const f32x4*)&sl[c][rq * 4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[r][e] = __builtin_fmaf(sv[r], wv[e], acc[r][e]);
+            for (int r = 0; r < 4; ++r) {
+                const f32x2 sr = {sv[r], sv[r]};
+                alo[r] = __builtin_elementwise_fma(sr, wv.xy, alo[r]);
+                ahi[r] = __builtin_elementwise_fma(sr, wv.zw, ahi[r]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t i = i0 + rq * 4 + r;
             if (i < m) {
                 float* o = out + i * n + jb + cg * 4;
-                if (accumulate) acc[r] += *(const f32x4*)o;
-                *(f32x4*)o = acc[r];
+                f32x4 a4 = {alo[r].x, alo[r].y, ahi[r].x, ahi[r].y};
+                if (accumulate) a4 += *(const f32x4*)o;
+                *(f32x4*)o = a4;
             }
         }
     }
@@ -1051,9 +1058,16 @@ __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict_
                     const f32x4 sv = *(const f32x4*)&ss[rg + 16 * q][c4 * 4];
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc)
-                        if (c4 * 4 + cc < NCT)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[c4 * 4 + cc][e] = __builtin_fmaf(sv[cc], v[q][e], acc[c4 * 4 + cc][e]);
+                        if (c4 * 4 + cc < NCT) {   // packed fp32 FMAs (v_pk_fma_f32): the same fmaf per element, two per instruction (neutral)
+                            const f32x2 s2 = {sv[cc], sv[cc]};
+                            f32x2 lo = {acc[c4 * 4 + cc][0], acc[c4 * 4 + cc][1]}, hi = {acc[c4 * 4 + cc][2], acc[c4 * 4 + cc][3]};
+                            lo = __builtin_elementwise_fma(s2, v[q].xy, lo);
+                            hi = __builtin_elementwise_fma(s2, v[q].zw, hi);
+                            acc[c4 * 4 + cc][0] = lo.x;
+                            acc[c4 * 4 + cc][1] = lo.y;
+                            acc[c4 * 4 + cc][2] = hi.x;
+                            acc[c4 * 4 + cc][3] = hi.y;
+                        }
                 }
             __syncthreads();
         }
