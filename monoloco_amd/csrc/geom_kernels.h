@@ -589,7 +589,9 @@ __global__ __launch_bounds__(256) void heads_small_kernel(SmallHeads hp, int H, 
 // mid-size path, where two heads_kernel launches + post_kernel are ~10 % of a 4096-row forward: heads_kernel's loop and fma
 // order per head (same bits as the separate launches), then, when post_out is given, the mono post-process of the row by the
 // lane that holds it (post_person) -- raw may then be null.  Dynamic LDS: (NH + 1) * H floats.
-template <int NH>
+// RW = rows per wave and pass (round 4: 2; with 4 the kernel held 256 VGPRs + 76 AGPRs = ONE wave per SIMD, one workgroup per CU,
+// and the 512 workgroups of an 8192-row batch ran in two rounds: 46 us for 64 MB; with 2 rows three workgroups share a CU).
+template <int NH, int RW = 2>
 __global__ __launch_bounds__(256) void heads_pair_kernel(const char* __restrict__ act_fin, const char* __restrict__ act_aux, int H,
                                                          const float* __restrict__ w_fin, const float* __restrict__ b_fin,
                                                          const float* __restrict__ w_aux, const float* __restrict__ b_aux,
@@ -602,15 +604,15 @@ __global__ __launch_bounds__(256) void heads_pair_kernel(const char* __restrict_
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int npairs = H / 8;
-    const int64_t nquads = (m + 3) / 4;
-    // one 8-column group of 4 rows of both sources: 16 independent 16-byte loads per lane
+    const int64_t nquads = (m + RW - 1) / RW;   // ("quads": groups of RW rows)
+    // one 8-column group of RW rows of both sources: 4 RW independent 16-byte loads per lane
     struct Rows {
-        half8 hi[4], lo[4], hj[4], lj[4];
+        half8 hi[RW], lo[RW], hj[RW], lj[RW];
     };
     auto fetch = [&](Rows& x, int64_t r0, int pr) {
         const int b = pr >> 2, sub = pr & 3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RW; ++r) {
             const int64_t row = (r0 + r < m) ? (r0 + r) : (m - 1);
             const size_t off = (size_t)row * H * 4 + b * LINE + sub * 16;
             x.hi[r] = *(const half8*)(act_fin + off);
@@ -619,31 +621,27 @@ __global__ __launch_bounds__(256) void heads_pair_kernel(const char* __restrict_
             x.lj[r] = *(const half8*)(act_aux + off + 64);
         }
     };
-    // the first rows of this wave are requested BEFORE the weights are staged: the two latencies overlap (a workgroup has only
-    // one to a few quads of rows at the mid-size batches, so the staging is not amortised over many)
-    Rows first;
+    // (round 3 requested the wave's first rows BEFORE staging the weights, in a second register set: with the 2-row passes of round 4
+    // the other resident workgroups cover that latency, and the 32 registers buy occupancy)
     const int64_t qd0 = (int64_t)blockIdx.x * 4 + wave;
-    const bool have = qd0 < nquads && lane < npairs;
-    if (have) fetch(first, qd0 * 4, lane);
     for (int i = threadIdx.x * 4; i < NH * H; i += 1024) *(f32x4*)(s_w + i) = *(const f32x4*)(w_fin + i);
     for (int i = threadIdx.x * 4; i < H; i += 1024) *(f32x4*)(s_w + NH * H + i) = *(const f32x4*)(w_aux + i);
     __syncthreads();
     for (int64_t qd = qd0; qd < nquads; qd += (int64_t)gridDim.x * 4) {
-        const int64_t r0 = qd * 4;
-        float acc[4][NH + 1];
+        const int64_t r0 = qd * RW;
+        float acc[RW][NH + 1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RW; ++r)
 #pragma unroll
             for (int o = 0; o <= NH; ++o) acc[r][o] = 0.0f;
         for (int pr = lane; pr < npairs; pr += 64) {
             const int b = pr >> 2, sub = pr & 3;
             const int n = b * 32 + sub * 8;
             Rows x;
-            if (qd == qd0 && pr == lane) x = first;
-            else fetch(x, r0, pr);
-            float xv[4][8], xa[4][8];
+            fetch(x, r0, pr);
+            float xv[RW][8], xa[RW][8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < RW; ++r)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     xv[r][e] = (float)x.hi[r][e] + (float)x.lo[r][e];
@@ -654,7 +652,7 @@ __global__ __launch_bounds__(256) void heads_pair_kernel(const char* __restrict_
                 const f32x4 wa = *(const f32x4*)(s_w + o * H + n);
                 const f32x4 wb = *(const f32x4*)(s_w + o * H + n + 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < RW; ++r) {
                     float a = acc[r][o];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a = __builtin_fmaf(o < NH ? xv[r][e] : xa[r][e], wa[e], a);
@@ -665,7 +663,7 @@ __global__ __launch_bounds__(256) void heads_pair_kernel(const char* __restrict_
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RW; ++r)
 #pragma unroll
             for (int o = 0; o <= NH; ++o) {
                 float a = acc[r][o];
@@ -675,7 +673,7 @@ __global__ __launch_bounds__(256) void heads_pair_kernel(const char* __restrict_
             }
         // every lane holds all sums; lane r finishes row r0 + r
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RW; ++r) {
             if (lane == r && r0 + r < m) {
                 float rowv[NH + 1];   // the raw row: w_fin's NH outputs, then the aux logit (the host checks that column order)
 #pragma unroll

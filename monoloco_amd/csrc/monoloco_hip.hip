@@ -810,7 +810,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             if (pf) {
                 if (li + 1 == h->layers.size() && rows_here > 0) {
                     const size_t lds = (size_t)(pf->nh + 1) * h->hidden * 4;
-                    int grid = (int)((((rows_here + 3) / 4) + 3) / 4);
+                    int grid = (int)((((rows_here + 1) / 2) + 3) / 4);   // 4 waves per workgroup, 2 rows per wave and pass (heads_pair_kernel's RW)
                     if (grid > 2048) grid = 2048;
                     const bool with_post = defer;
                     float* raw_dst = with_post ? tail->raw : raw_out + r0 * h->out_f;
