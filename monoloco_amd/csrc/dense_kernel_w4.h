@@ -412,7 +412,12 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         // all there, so the epilogue's stores keep retiring behind the next tile's MFMAs.
         int since_drain = 0;          // phases since the last vmcnt(0)
         stamp(0);
-        auto phase_wait = [&]() {
+        // REBAL (half-size tile): a 16-MFMA phase A cannot cover six LDS-DMA issues (~100 cycles each), so phase A requests only the
+        // four W instructions of H(t+2) and phase B its two X instructions in front of L(t+2)'s six (4 + 8 per k-step): in steady
+        // state phase A (reads L(t), requested as the last six of B(t-2)) has A(t-1)'s 4 + B(t-1)'s 8 = 12 younger instructions,
+        // phase B (reads H(t+1): A(t-1)'s 4 + the first 2 of B(t-1)) the other 6 of B(t-1) + A(t)'s 4 = 10
+        constexpr bool REBAL = NJ == 2 && SPLIT;
+        auto phase_wait = [&](bool phase_b = false) {
 #ifdef ML_DENSE_TRACE
             if (since_drain >= 1 && since_drain <= 8) stamp(since_drain);
 #endif
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             if (since_drain >= (SPLIT ? 3 : 1)) {
                 // (the DMA groups of the two phases in between: 2 x NQ instructions of this wave)
                 if (SPLIT && NJ == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (REBAL && phase_b) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                 else if (SPLIT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -453,14 +459,19 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
                     for (int qd = (NJ == 2 ? (blk < 6 ? blk : 6) : (blk < 4 ? blk : (blk < 6 ? 4 + 2 * (blk - 4) : 8)));
                          qd < (NJ == 2 ? (blk < 6 ? blk + 1 : 6) : (blk < 4 ? blk + 1 : (blk < 6 ? 6 + 2 * (blk - 4) : 8))); ++qd) {
-                        issue1(rq_w, rq_x, S, qd);
+                        if (REBAL) {   // the W instructions behind blocks 0, 2, 4, 6; the fragment reads as before
+                            if ((blk & 1) == 0) issue1(rq_w, rq_x, S, blk >> 1);
+                        } else {
+                            issue1(rq_w, rq_x, S, qd);
+                        }
                         if (SPLIT) read_q(fl, S + 1, qd);
                         else read_q(FN, S ^ 2, qd);   // single-product modes: the next step's hi fragments are read here
                     }
+                    if (REBAL && blk == 6) issue1(rq_w, rq_x, S, 3);   // (blocks 6, 7 carry no fragment quarter)
                 }
             if (SPLIT) {
                 // ---------------- phase B: hi.lo + lo.hi, 64 MFMAs; reads the NEXT step's hi fragments; requests L(t+2)
-                phase_wait();
+                phase_wait(true);
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -477,7 +488,14 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                             __builtin_amdgcn_sched_barrier(0);
                             // quarters behind blocks 0, 2, .., 10, 11, 12: blocks 13-15 cover the last reads
                             const int qd = (blk <= 10) ? ((blk & 1) == 0 ? blk >> 1 : -1) : (blk <= 12 ? blk - 5 : -1);
-                            if (qd >= 0 && qd < NQ) {
+                            if (REBAL) {
+                                // H(t+2)'s two X instructions first, then L(t+2)'s six: one instruction per block 0, 1, 3, 5, 7, 9, 11, 12
+                                if (blk == 0) issue1(rq_w, rq_x, S, 4);
+                                else if (blk == 1) issue1(rq_w, rq_x, S, 5);
+                                else if (blk >= 3 && blk <= 11 && (blk & 1)) issue1(rq_w, rq_x, S + 1, (blk - 3) >> 1);
+                                else if (blk == 12) issue1(rq_w, rq_x, S + 1, 5);
+                                if (qd >= 0 && qd < NQ) read_q(FN, S ^ 2, qd);
+                            } else if (qd >= 0 && qd < NQ) {
                                 issue1(rq_w, rq_x, S + 1, qd);
                                 read_q(FN, S ^ 2, qd);
                             }
