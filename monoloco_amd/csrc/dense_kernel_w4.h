@@ -416,7 +416,14 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         // four W instructions of H(t+2) and phase B its two X instructions in front of L(t+2)'s six (4 + 8 per k-step): in steady
         // state phase A (reads L(t), requested as the last six of B(t-2)) has A(t-1)'s 4 + B(t-1)'s 8 = 12 younger instructions,
         // phase B (reads H(t+1): A(t-1)'s 4 + the first 2 of B(t-1)) the other 6 of B(t-1) + A(t)'s 4 = 10
-        constexpr bool REBAL = NJ == 2 && SPLIT;
+        // The same split on the FULL-size tile (A: the 4 W instructions, B: H(t+2)'s 4 X instructions + L(t+2)'s 8; vmcnt 16 / 12) is
+        // kept behind -DML_W4_REBAL4: measured 2.560 vs 2.545 ms per 65536-row step, three alternations on one box
+        // (profiles/r04_ablation.md) -- its 32-MFMA phase A already covers its issues, and the chip sits at its power cap.
+#ifdef ML_W4_REBAL4
+        constexpr bool REBAL = SPLIT;
+#else
+        constexpr bool REBAL = SPLIT && NJ == 2;
+#endif
         auto phase_wait = [&](bool phase_b = false) {
 #ifdef ML_DENSE_TRACE
             if (since_drain >= 1 && since_drain <= 8) stamp(since_drain);
@@ -426,8 +433,9 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             if (W4_DBG(32)) return;
             if (since_drain >= (SPLIT ? 3 : 1)) {
                 // (the DMA groups of the two phases in between: 2 x NQ instructions of this wave)
-                if (SPLIT && NJ == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else if (REBAL && phase_b) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                if (SPLIT && NJ == 4 && REBAL && phase_b) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (SPLIT && NJ == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (REBAL && phase_b && NJ == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                 else if (SPLIT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     for (int qd = (NJ == 2 ? (blk < 6 ? blk : 6) : (blk < 4 ? blk : (blk < 6 ? 4 + 2 * (blk - 4) : 8)));
                          qd < (NJ == 2 ? (blk < 6 ? blk + 1 : 6) : (blk < 4 ? blk + 1 : (blk < 6 ? 6 + 2 * (blk - 4) : 8))); ++qd) {
                         if (REBAL) {   // the W instructions behind blocks 0, 2, 4, 6; the fragment reads as before
-                            if ((blk & 1) == 0) issue1(rq_w, rq_x, S, blk >> 1);
+                            if ((blk & 1) == 0 && (NJ == 2 || blk < 4 || qd == 4 + 2 * (blk - 4))) issue1(rq_w, rq_x, S, blk >> 1);
                         } else {
                             issue1(rq_w, rq_x, S, qd);
                         }
@@ -488,7 +496,12 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                             __builtin_amdgcn_sched_barrier(0);
                             // quarters behind blocks 0, 2, .., 10, 11, 12: blocks 13-15 cover the last reads
                             const int qd = (blk <= 10) ? ((blk & 1) == 0 ? blk >> 1 : -1) : (blk <= 12 ? blk - 5 : -1);
-                            if (REBAL) {
+                            if (REBAL && NJ == 4) {
+                                // H(t+2)'s four X instructions behind blocks 0..3, L(t+2)'s eight behind blocks 4..11
+                                if (blk < 4) issue1(rq_w, rq_x, S, 4 + blk);
+                                else if (blk < 12) issue1(rq_w, rq_x, S + 1, blk - 4);
+                                if (qd >= 0 && qd < NQ) read_q(FN, S ^ 2, qd);
+                            } else if (REBAL) {
                                 // H(t+2)'s two X instructions first, then L(t+2)'s six: one instruction per block 0, 1, 3, 5, 7, 9, 11, 12
                                 if (blk == 0) issue1(rq_w, rq_x, S, 4);
                                 else if (blk == 1) issue1(rq_w, rq_x, S, 5);
