@@ -213,6 +213,7 @@ class Loco:
             idx = np.arange(m * stride).reshape(m, stride)
             st['perm'] = np.concatenate([idx[:, [8, 9, 10, 4, 5, 6, 3]].T.reshape(-1), idx[:, 12:14].reshape(-1), idx[:, 0:4].reshape(-1),
                                          np.arange(m * stride, m * (stride + 12))]).astype(np.intp)
+            st['sizes'] = [7 * m, 2 * m, 4 * m, 12 * m]
             st['p_in'] = ctypes.c_void_p(st['dev_in'].data_ptr())
             st['p_out'] = ctypes.c_void_p(st['buf'].data_ptr())
             st['p_d'] = ctypes.c_void_p(st['buf'].data_ptr() + 3 * 4)
@@ -247,10 +248,10 @@ class Loco:
         # ori (m,2), xyzd (m,4) and the (m,12) geometry block -- one gather of the pinned result through an index vector cached per
         # person count, one torch.from_numpy, every output a view of its own range
         t = torch.from_numpy(st['np_out'].take(st['perm']))
-        h_, w_, l_, bi_, yaw_, yawe_, d_ = t[:7 * m].view(7, m, 1).unbind(0)
-        dic = {'h': h_, 'w': w_, 'l': l_, 'ori': t[7 * m:9 * m].view(m, 2), 'bi': bi_, 'xyzd': t[9 * m:13 * m].view(m, 4), 'd': d_,
-               'yaw': (yaw_, yawe_)}
-        return dic, t[13 * m:].view(m, 12), kps
+        cols, ori, xyzd, geo = t.split_with_sizes(st['sizes'])   # (one call instead of four slices)
+        h_, w_, l_, bi_, yaw_, yawe_, d_ = cols.view(7, m, 1).unbind(0)
+        dic = {'h': h_, 'w': w_, 'l': l_, 'ori': ori.view(m, 2), 'bi': bi_, 'xyzd': xyzd.view(m, 4), 'd': d_, 'yaw': (yaw_, yawe_)}
+        return dic, geo.view(m, 12), kps
 
     def _packed_buffers(self, m):
         """One device allocation for the packed (m,16) network result and the (m,12) post-process geometry."""
