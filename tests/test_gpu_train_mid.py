@@ -403,7 +403,7 @@ def test_relu_flip_accounting_at_headline_width(hip_lib, cuda_device):
         assert worst <= 2e-5, (route, worst)             # ... all within fp32 rounding of zero
 
 
-@pytest.mark.parametrize("hidden,rows", [(1024, 4096), (1024, 5000), (256, 4099), (512, 8192)])
+@pytest.mark.parametrize("hidden,rows", [(1024, 4096), (1024, 5000), (256, 4099), (512, 8192), (2048, 4100)])
 def test_weight_gradient_operands_reduction_major_same_bits(hip_lib, cuda_device, hidden, rows):
     """Large-batch route, dW = dz^T . x: reading dz and x as the [batch][hidden] lines they already exist as
     (dense_kernel_w4<.., -3, true>: LDS-DMA of batch rows + ds_read_b64_tr_b16 fragments) against round 2's transposed copies of
