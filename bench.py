@@ -546,6 +546,32 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         return res
     guarded("latency_16_persons", latency)
 
+    def reference_weights():
+        # the same workload on the checkpoint the REFERENCE's own fixture training produced (width 1024) and SURVEY 8d's parity set P
+        # (the fixture's real poses tiled to the batch, jittered): its own timing and its own parity block against the CPU oracle
+        from oracle import monoloco_oracle as O
+        gdir = os.path.join(ROOT, 'tests', 'golden')
+        sd_r = dict(np.load(os.path.join(gdir, 'ckpt_mono_h1024.npz')))
+        base = np.load(os.path.join(gdir, 'golden_path.npz'))['mono_kps']
+        rng = np.random.default_rng(100)
+        k = base[rng.integers(0, len(base), m)].astype(np.float32)
+        k[:, 0:2, :] += rng.normal(0, 0.5, (m, 2, 17)).astype(np.float32)
+        kr = torch.tensor(k).to(dev)
+        eng_r = engine.LocoEngine({kk_: torch.tensor(v) for kk_, v in sd_r.items()}, device=dev, reserve_rows=m)
+        o = torch.empty((m, 16), dtype=torch.float32, device=dev)
+        x = torch.empty((m, 5), dtype=torch.float32, device=dev)
+        r = torch.empty((m, eng_r.out_features), dtype=torch.float32, device=dev)
+        ms = _ms(lambda: eng_r.forward_mono(kr, kinv, box_conf=conf, out=o, xyzds=x, raw=r), 20, 5, dev)
+        par = parity_of_timed_run(sd_r, kr, conf, x, r, kk)
+        d_col = r[:, 2]
+        eng_r.close()
+        return {"config": "the headline workload on the reference-TRAINED 1024-wide checkpoint (tests/golden/ckpt_mono_h1024.npz: the "
+                          "reference's own fixture training, oracle/make_golden.py wb1024) and real fixture poses tiled to the batch "
+                          "(+ N(0, 0.5 px)); same kernels and work as `value`",
+                "ms_per_step": round(ms, 4), "persons_per_s": round(m / ms * 1e3, 1), "vs_synthetic_values": round(main_ms / ms, 4),
+                "parity": par, "d_metres_min_max": [round(float(d_col.min()), 2), round(float(d_col.max()), 2)]}
+    guarded("reference_trained_weights", reference_weights)
+
     def bf16():
         from oracle import monoloco_oracle as O
         eng_b = engine.LocoEngine({k: torch.tensor(v) for k, v in sd.items()}, device=dev, precision='bf16', reserve_rows=m)
@@ -626,6 +652,13 @@ def main(argv=None):
     ap.add_argument('--chunk-rows', type=int, default=-1,
                     help='walk the batch in row chunks of this size through all layers (-1 = library default)')
     ap.add_argument('--gather', default='gather', choices=['gather', 'all_gather'], help='N > 1: the final collective')
+    ap.add_argument('--weights', default='synthetic', choices=['reference', 'synthetic'],
+                    help="'reference': the 1024-wide checkpoint the reference's own fixture training produced "
+                         "(tests/golden/ckpt_*_h1024.npz, oracle/make_golden.py wb1024) on SURVEY 8d's parity set P (the fixture's real "
+                         "poses tiled to the batch, jittered by N(0, 0.5 px)); 'synthetic' (default, as in every round): seeded weights on uniform "
+                         "random keypoints (set T).  Same kernels, same work; the board's power -- hence the clock at its cap -- depends on the "
+                         "values by about 1 %% (measured: 2.647 vs 2.622 ms, tools/ab_weights.sh); `extra.reference_trained_weights` times and "
+                         "checks the other set in every default run")
     ap.add_argument('--stub-engine', action='store_true',
                     help='launch-contract test on a box without a GPU: tests/stub_engine.py on CPU over gloo; the line is '
                          'marked "data": "stub" and measures nothing')
@@ -635,7 +668,7 @@ def main(argv=None):
         # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) and relay their line
         return self_launch(args.gpus, list(sys.argv[1:] if argv is None else argv))
 
-    import numpy as np  # noqa: F401
+    import numpy as np
     import torch
     import torch.distributed as dist
     import synth
@@ -668,16 +701,31 @@ def main(argv=None):
         m = args.batch
     kk = synth.KITTI_K
     kinv = engine.inverse_intrinsics(kk)
+    gdir = os.path.join(ROOT, 'tests', 'golden')
+    ckpt = os.path.join(gdir, 'ckpt_%s_h1024.npz' % args.workload)
+    use_ref = args.weights == 'reference' and os.path.exists(ckpt) and os.path.exists(os.path.join(gdir, 'golden_path.npz'))
+    weights_txt = ("reference-trained: tests/golden/ckpt_%s_h1024.npz (the reference's own fixture training at width 1024, "
+                   "oracle/make_golden.py wb1024); poses = the fixture's real poses tiled to the batch, jittered by N(0, 0.5 px)"
+                   % args.workload) if use_ref else "seeded synthetic (tests/synth.py) on uniform random keypoints"
+
+    def poses(n, seed, key='mono_kps'):
+        if not use_ref:
+            return synth.make_keypoints(n, seed=seed)
+        base = np.load(os.path.join(gdir, 'golden_path.npz'))[key]
+        rng = np.random.default_rng(seed)
+        k = base[rng.integers(0, len(base), n)].astype(np.float32)
+        k[:, 0:2, :] += rng.normal(0, 0.5, (n, 2, 17)).astype(np.float32)
+        return k
     if args.workload == 'mono':
-        sd = synth.make_state_dict(1, 34, 9, 1024)
-        kps_np = synth.make_keypoints(m, seed=100 + rank)
+        sd = dict(np.load(ckpt)) if use_ref else synth.make_state_dict(1, 34, 9, 1024)
+        kps_np = poses(m, 100 + rank)
         rows = m
     else:  # MonStereo: ml x mr all-vs-all pairs = `batch` network rows
-        sd = synth.make_state_dict(3, 68, 10, 1024)
+        sd = dict(np.load(ckpt)) if use_ref else synth.make_state_dict(3, 68, 10, 1024)
         mr = 128
         ml = m // mr
-        kps_np = synth.make_keypoints(ml, seed=100 + rank)
-        kps_r = torch.tensor(synth.make_keypoints(mr, seed=200 + rank)).to(dev)
+        kps_np = poses(ml, 100 + rank, 'stereo_kps_l')
+        kps_r = torch.tensor(poses(mr, 200 + rank, 'stereo_kps_r')).to(dev)
         rows = ml * mr
     eng = make_engine({k: torch.tensor(v) for k, v in sd.items()}, device=dev, precision=args.precision,
                       merge_w2w3=not args.no_merge, reserve_rows=rows)
@@ -785,7 +833,7 @@ def main(argv=None):
                                        else "batch %d per GPU" % m)) if args.workload == 'mono' else
                                    ("MonStereo 68->1024->10, %d x %d all-vs-all pairs per GPU" % (ml, mr)),
                        "rows_per_gpu": rows, "precision": args.precision, "merge_w2w3": not args.no_merge,
-                       "weights": "seeded synthetic (tests/synth.py)",
+                       "weights": weights_txt,
                        "parallelism": "rows sharded x%d, 1 %s" % (world, args.gather)},
         }
         line["ranks_seen"] = len({(r["rank"], r["device"]) for r in seen})
