@@ -82,7 +82,9 @@ struct ml_trainer {
     std::vector<float*> wbs;                          // bias * 2^e
     std::vector<char*> wlT;                           // ... and of W^T (data gradient); all images of a step are packed up front
     mlt::WLayer* d_wdesc = nullptr;                   // device table of the 2S + 2 Linears for wmax_multi / wpack_multi
-    bool packed_all = false;                          // this step's images are already packed (pack_all_weights)
+    bool packed_all = false;
+    mlt::ColSumItems csf;                             // deferred fp64 column sums -> fp32 gradient vectors (flushed before the optimizer)
+    bool csf_defer = false;                          // this step's images are already packed (pack_all_weights)
     float* wsc_base = nullptr;                        // per image 8 scale words (train_kernels.h, wmax_kernel)
     char *tl_dz = nullptr, *tl_x = nullptr;           // transposed lines [H][capT] of dz and of a layer input (dW = dz^T . x)
     int64_t capT = 0;
@@ -228,6 +230,27 @@ int col_stats(ml_trainer* t, hipStream_t st, const float* z, const float* w2, in
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(mlt::col_stats_kernel, dim3((n + 63) / 64, gy), dim3(256), 0, st, z, w2, m, n, t->d_red, t->d_red + n);
     return 0;
+}
+
+// a vector of fp64 column sums (a reduction slot of this step) becomes an fp32 gradient vector: one launch each, or -- large-batch
+// route -- noted and converted by ONE launch in front of the optimizer (the slots live until the end of the step)
+void col_sum_to_float(ml_trainer* t, hipStream_t st, const double* src, int n, float* dst) {
+    if (t->csf_defer && t->csf.count < 16) {
+        t->csf.src[t->csf.count] = src;
+        t->csf.dst[t->csf.count] = dst;
+        t->csf.n[t->csf.count] = n;
+        ++t->csf.count;
+        return;
+    }
+    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(n)), dim3(256), 0, st, src, n, dst);
+}
+void flush_col_sums(ml_trainer* t, hipStream_t st) {
+    if (t->csf.count > 0) {
+        int nmax = 0;
+        for (int i = 0; i < t->csf.count; ++i) nmax = t->csf.n[i] > nmax ? t->csf.n[i] : nmax;
+        hipLaunchKernelGGL(mlt::col_sum_multi_kernel, dim3(nblk(nmax), t->csf.count), dim3(256), 0, st, t->csf);
+    }
+    t->csf.count = 0;
 }
 
 // ---- skinny products (input layer, output heads) on their own kernels (train_kernels.h) at every batch size; callers
@@ -446,7 +469,7 @@ int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* r
     float* mean = t->bn_mean + (size_t)b.bn_idx * H;
     float* inv = t->bn_invstd + (size_t)b.bn_idx * H;
     if (gemm_stats) {
-        hipLaunchKernelGGL(mlt::bn_finalize_parts_kernel, dim3((H + 15) / 16), dim3(256), 0, st, (const double*)t->d_colpart,
+        hipLaunchKernelGGL(mlt::bn_finalize_parts_kernel, dim3((H + 7) / 8), dim3(256), 0, st, (const double*)t->d_colpart,
                            (int)((m + 127) / 128), m, H, 1e-5f, 0.1f, mean, inv, ST(t, b.bn + ".running_mean"),
                            ST(t, b.bn + ".running_var"));
     } else {
@@ -515,8 +538,7 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
                                (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, (const double*)s_dy,
                                (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz,
                                slot >= 0 ? t->wsc_base + 8 * slot + 3 : (float*)nullptr);
-        hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)s_dz, H,
-                           G(t, b.lin + ".bias"));
+        col_sum_to_float(t, st, (const double*)s_dz, H, G(t, b.lin + ".bias"));
         if (slot >= 0) {
             if (!lines_only && (rc = fast_grad_lines(t, st, dout, m, slot))) return rc;
             return fast_linear_bwd_weight(t, st, b.x, b.x_lines, b.lin, m, slot);
@@ -1370,12 +1392,14 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     double lv[16];
     T_TRY(hipMemcpyAsync(lv, d_loss, mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));
     // ---------------- backward
-    T_TRY(hipMemsetAsync(t->g, 0, (size_t)t->n_param * 4, st));
+    // (large-batch route: every gradient tensor is written in full by its producer -- no 34 MB memset of the gradient buffer)
+    if (!fast) T_TRY(hipMemsetAsync(t->g, 0, (size_t)t->n_param * 4, st));
+    t->csf.count = 0;
+    t->csf_defer = fast;
     // heads: column sums of dout give both biases
     if ((rc = col_stats(t, st, t->d_dout, nullptr, m, C))) return rc;
-    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)t->d_red, C - 1, G(t, "w_fin.bias"));
-    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(1), dim3(256), 0, st, (const double*)(t->d_red + (C - 1)), 1,
-                       G(t, "w_aux.bias"));
+    col_sum_to_float(t, st, (const double*)t->d_red, C - 1, G(t, "w_fin.bias"));
+    col_sum_to_float(t, st, (const double*)(t->d_red + (C - 1)), 1, G(t, "w_aux.bias"));
     if (skinny) {
         if ((rc = skinny_dw(t, st, t->d_dout, C, C - 1, y3, m, G(t, "w_fin.weight"), 0))) return rc;
         rc = skinny_out(t, st, t->d_dout, C, C - 1, P(t, "w_fin.weight"), H, 1, nullptr, gA, m, 0);
@@ -1401,7 +1425,7 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     if (rc) return rc;
     // y2 = w2 a_S + b2
     if ((rc = col_stats(t, st, gB, nullptr, m, H))) return rc;
-    hipLaunchKernelGGL(mlt::col_sum_to_float_kernel, dim3(nblk(H)), dim3(256), 0, st, (const double*)t->d_red, H, G(t, "w2.bias"));
+    col_sum_to_float(t, st, (const double*)t->d_red, H, G(t, "w2.bias"));
     if (fast) {
         hipLaunchKernelGGL(mlt::wmax_kernel, dim3(1024), dim3(256), 0, st, (const float*)gB, m * H, t->wsc_base + 8 * (2 * S) + 3);
         if ((rc = fast_grad_lines(t, st, gB, m, 2 * S))) return rc;
@@ -1435,6 +1459,8 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     const float bc1 = 1.f - std::pow(0.9f, (float)k), bc2 = 1.f - std::pow(0.999f, (float)k);
     {
         double* d_ss = t->d_red + 2 * H + 16;  // pre-zeroed, never shared with d_loss (other offset)
+        flush_col_sums(t, st);
+        t->csf_defer = false;
         hipLaunchKernelGGL(mlt::sumsq_kernel, dim3(512), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
         hipLaunchKernelGGL(mlt::clip_adam_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
                            (const double*)d_ss, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);

@@ -260,23 +260,26 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 __global__ __launch_bounds__(256) void bn_finalize_parts_kernel(const double* __restrict__ part, int nblocks, int64_t m, int n, float eps,
                                                                float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                                                float* __restrict__ run_mean, float* __restrict__ run_var) {
-    // workgroup = 16 columns x 16 groups; group g adds the blocks b = g, g + 16, .. in order, then the 16 group sums in order
-    __shared__ double r1[16][16], r2[16][16];
-    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int j = blockIdx.x * 16 + c;
+    // workgroup = 8 columns x 32 groups (128 workgroups at H = 1024); group g adds the blocks b = g, g + 32, .. in order, then the 32
+    // group sums are added in order: fixed order whatever the launch
+    __shared__ double r1[32][8], r2[32][8];
+    const int c = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int j = blockIdx.x * 8 + c;
     double s1 = 0.0, s2 = 0.0;
-    if (j < n)
-        for (int b = g; b < nblocks; b += 16) {
+    if (j < n) {
+#pragma unroll 4
+        for (int b = g; b < nblocks; b += 32) {
             s1 += part[(size_t)b * 2 * n + j];
             s2 += part[(size_t)b * 2 * n + n + j];
         }
+    }
     r1[g][c] = s1;
     r2[g][c] = s2;
     __syncthreads();
     if (g != 0 || j >= n) return;
     s1 = s2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 32; ++q) {
         s1 += r1[q][c];
         s2 += r2[q][c];
     }
@@ -1170,6 +1173,20 @@ __global__ __launch_bounds__(256) void skinny_heads_kernel(const float* __restri
 __global__ __launch_bounds__(256) void col_sum_to_float_kernel(const double* __restrict__ s, int n, float* __restrict__ out) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < n) out[j] = (float)s[j];
+}
+
+// all the fp64 column sums of a step that become fp32 gradient vectors (the Linear / head biases), in ONE launch before the optimizer
+// (round 4: they were 11 launches of ~5 us each at 65536 rows); blockIdx.y = the item
+struct ColSumItems {
+    const double* src[16];
+    float* dst[16];
+    int n[16];
+    int count;
+};
+__global__ __launch_bounds__(256) void col_sum_multi_kernel(ColSumItems it) {
+    const int k = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (k < it.count && j < it.n[k]) it.dst[k][j] = (float)it.src[k][j];
 }
 
 __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
