@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("tile", ["mid64", "mid128", "half"])
 @pytest.mark.parametrize("m,k,n", [(256, 64, 256), (700, 96, 256), (1000, 1024, 1024), (3000, 32, 512), (9000, 1024, 1024), (5000, 256, 512),
-                                   (128, 192, 256)])
+                                   (128, 192, 256), (4500, 2048, 512), (8192, 192, 1024)])
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
 def test_mid_single_layer(hip_lib, cuda_device, tile, m, k, n, relu, res):
     """One layer: fp32-class accuracy against fp64, and the same operands through the 256x256-tile kernel (only the fp32
