@@ -543,6 +543,29 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         t2 = time.perf_counter()
         res["loco_forward_us"] = round((t1 - t0) / n * 1e6, 1)
         res["post_process_us"] = round((t2 - t1) / n * 1e6, 1)
+        # with ground truth, as GenerateKitti calls it on every image (reference eval/generate_kitti.py:114-132): IoU of all
+        # detection x ground-truth pairs, greedy matching, left-to-right order and the matched xyz_real in batched calls
+        dic_gt = {'boxes': [[b[0] + 3., b[1] - 2., b[2] + 1., b[3] + 4.] for b in boxes[::-1]],
+                  'ys': [[0., 0., 0., 5.0 + i] for i in range(len(boxes))]}
+        for _ in range(20):
+            out = net.post_process(dic, boxes, kpl, kk1, dic_gt=dic_gt)
+        t3 = time.perf_counter()
+        for _ in range(n):
+            net.post_process(dic, boxes, kpl, kk1, dic_gt=dic_gt)
+        res["post_process_with_gt_us"] = round((time.perf_counter() - t3) / n * 1e6, 1)
+        res["post_process_with_gt_matches"] = int(sum(out['gt']))
+        # an image crowd of 2048 detections against 2048 ground-truth boxes: matching alone (the IoUs on the device from 32768
+        # pairs on); the reference's scalar Python loop needs seconds here
+        import synth as _synth
+        from monoloco_amd.utils import iou as _iou
+        for mm in (256, 2048):
+            bx, gx = _synth.make_boxes(mm, mm, 5)
+            _iou.get_iou_matches_ordered(bx, gx)
+            t4 = time.perf_counter()
+            for _ in range(5):
+                found = _iou.get_iou_matches_ordered(bx, gx)
+            res["gt_matching_%d_boxes_ms" % mm] = round((time.perf_counter() - t4) / 5 * 1e3, 3)
+            res["gt_matching_%d_boxes_matches" % mm] = len(found)
         return res
     guarded("latency_16_persons", latency)
 

@@ -330,6 +330,40 @@ int ml_kitti_txt_format(int64_t m, const double* boxes, const double* xyz, const
                         int64_t* written);
 const char* ml_formats_last_error(void);
 
+/* ---- ground-truth association of Loco.post_process (monoloco/network/net.py:170-190) ---- */
+/* All of this section is IEEE double in the evaluation order of the reference's Python expressions (Python floats are
+ * doubles), with Python's max / min and np.argmax tie rules, so the matches equal the reference's exactly.  Boxes are rows
+ * of >= 4 doubles x1, y1, x2, y2 (detections carry their confidence in column 4; only columns 0..3 are read here);
+ * ldb / ldg are the row strides in doubles.  *zero_div is OR-ed with 1 when some union area is 0 -- the reference's
+ * calculate_iou raises ZeroDivisionError there (monoloco/utils/iou.py:25), and the host side re-raises it.
+ * The device entry points are asynchronous on `stream` and allocate nothing; the *_host ones are plain host loops for
+ * images with a handful of boxes (where the launch and the copies would cost more than the m*g IoUs).
+ * Error text: ml_matching_last_error(). */
+/* Per detection the first arg-max over all ground-truth boxes of calculate_iou (monoloco/utils/iou.py:6-28, the inner loop
+ * and np.argmax of get_iou_matches, iou.py:55-60): jmax (m) int32, vmax (m) double.  g must be >= 1. */
+int ml_iou_best(const double* boxes_dev, int64_t m, int64_t ldb, const double* gt_dev, int64_t g, int64_t ldg,
+                int32_t* jmax_dev, double* vmax_dev, int32_t* zero_div_dev, void* stream);
+int ml_iou_best_host(const double* boxes, int64_t m, int64_t ldb, const double* gt, int64_t g, int64_t ldg,
+                     int32_t* jmax, double* vmax, int32_t* zero_div);
+/* get_iou_matrix (monoloco/utils/iou.py:31-41): out (m, g) row-major doubles. */
+int ml_iou_matrix(const double* boxes_dev, int64_t m, int64_t ldb, const double* gt_dev, int64_t g, int64_t ldg,
+                  double* out_dev, int32_t* zero_div_dev, void* stream);
+int ml_iou_matrix_host(const double* boxes, int64_t m, int64_t ldb, const double* gt, int64_t g, int64_t ldg, double* out,
+                       int32_t* zero_div);
+/* The greedy pass of get_iou_matches (monoloco/utils/iou.py:53-63) over host arrays: visit detections in `order` (n entries,
+ * each in 0..m-1; the caller passes reversed(np.argsort(confidences)) so that ties keep numpy's order), match a detection to
+ * its best ground-truth box jmax[idx] when vmax[idx] >= iou_min and that box is still free.  pairs (min(n,g), 2) int64 =
+ * (idx, idx_gt), *n_pairs = matches found.  order_left == NULL: pairs in visiting order (get_iou_matches' result);
+ * otherwise order_left (m) = np.argsort(left edges) and the pairs come out left to right -- reorder_matches
+ * (monoloco/utils/iou.py:86-100) applied to that result, as Loco.post_process does (net.py:187-188). */
+int ml_iou_greedy(const int64_t* order, int64_t n, const int32_t* jmax, const double* vmax, int64_t m, int64_t g,
+                  double iou_min, const int64_t* order_left, int64_t* pairs, int64_t* n_pairs);
+/* get_iou_matches (monoloco/utils/iou.py:44-64) [+ reorder_matches] in one host call: ml_iou_best_host + ml_iou_greedy. */
+int ml_iou_matches_host(const double* boxes, int64_t m, int64_t ldb, const double* gt, int64_t g, int64_t ldg,
+                        const int64_t* order, double iou_min, const int64_t* order_left, int64_t* pairs, int64_t* n_pairs,
+                        int32_t* zero_div);
+const char* ml_matching_last_error(void);
+
 /* ---- measurement: per-launch timing of the dense (MFMA) kernel ----------------------- */
 /* After ml_loco_profile_begin, every dense-kernel launch made through this handle is bracketed by
  * a pair of HIP events recorded on the launch stream (up to max_launches launches).

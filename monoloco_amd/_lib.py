@@ -101,6 +101,13 @@ SIGNATURES = {
                                 POINTER(c_double), POINTER(c_double), POINTER(c_int64)]),
     'ml_kitti_txt_format': (c_int, [c_int64] + [POINTER(c_double)] * 10 + [c_double, _P, c_int64, POINTER(c_int64)]),
     'ml_formats_last_error': (c_char_p, []),
+    'ml_iou_best': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, _P, _P]),
+    'ml_iou_best_host': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, _P]),
+    'ml_iou_matrix': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, _P]),
+    'ml_iou_matrix_host': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P]),
+    'ml_iou_greedy': (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_double, _P, _P, _P]),
+    'ml_iou_matches_host': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_double, _P, _P, _P, _P]),
+    'ml_matching_last_error': (c_char_p, []),
     'ml_loco_profile_begin': (c_int, [_P, c_int]),
     'ml_loco_profile_end': (c_int, [_P, POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_int]),
     'ml_debug_linear': (c_int, [_P, c_int64, c_int, POINTER(c_float), POINTER(c_float), c_int, c_int, _P, _P,

@@ -17,7 +17,8 @@ import numpy as np
 import torch
 
 from .. import engine
-from ..utils import get_iou_matches, reorder_matches, xyz_from_distance
+from ..utils import xyz_from_distance
+from ..utils.iou import get_iou_matches, get_iou_matches_ordered
 from .architectures import LocoModel, MonolocoModel
 from .process import extract_outputs_mono, packed_to_dict, unnormalize_bi
 
@@ -65,6 +66,26 @@ def _pyhost():
                 lib = None
         _PYHOST[0] = lib
     return _PYHOST[0]
+
+
+# from this many matches on, the matched centres go through ml_xyz_from_distance on the device in one launch; below it the
+# three fp32 operations per value are done where the (m,12) geometry block already is (the host: it was fetched for the
+# dictionary), which is what the reference does too -- its xy_centers are CPU tensors.  IEEE fp32 multiply, divide and
+# square root are correctly rounded on both sides, so the two routes give the same bits (tests/test_gpu_matching.py).
+XYZ_REAL_DEVICE_MIN = 512
+
+
+def _xyz_real(dds_real, xy_centers, idx_m):
+    """[xyz_from_distance(dd, xy_centers[idx]).squeeze().tolist() for the matches] (reference net.py:242-247,
+    camera.py:161-177): centre * fp32(dd) / sqrt(1 + x^2 + y^2) in fp32, as nested Python lists."""
+    k = len(idx_m)
+    if k >= XYZ_REAL_DEVICE_MIN:
+        dd = torch.tensor(dds_real, dtype=torch.float64).to(torch.float32)   # (a Python float rounds to fp32 once, like torch.tensor(dd))
+        return xyz_from_distance(dd, xy_centers[idx_m]).tolist()
+    c = (xy_centers.numpy() if isinstance(xy_centers, torch.Tensor) else np.asarray(xy_centers, dtype=np.float32))[idx_m]
+    dd = np.asarray(dds_real, dtype=np.float64).astype(np.float32)[:, None]
+    x, y = c[:, 0:1], c[:, 1:2]
+    return (c * dd / np.sqrt(1 + x * x + y * y)).tolist()
 
 
 class _LocoOut(dict):
@@ -284,13 +305,15 @@ class Loco:
         if dic_gt:
             boxes_gt = dic_gt['boxes']
             dds_gt = [ys[3] for ys in dic_gt['ys']]
-            matches = get_iou_matches(boxes, boxes_gt, iou_min=iou_min)
+            # all m x g IoUs, the greedy pass by confidence and (when `reorder`) the left-to-right order in one native call
+            matches = (get_iou_matches_ordered if reorder else get_iou_matches)(boxes, boxes_gt, iou_min=iou_min)
         if verbose:
             print("found {} matches with ground-truth".format(len(matches)) if dic_gt else "NO ground-truth associated")
-        taken = {pair[0] for pair in matches}
-        not_matches = [idx for idx in range(len(boxes)) if idx not in taken]
-        if reorder and matches:
-            matches = reorder_matches(matches, boxes, mode='left_right')
+        if matches:
+            taken = {pair[0] for pair in matches}
+            not_matches = [idx for idx in range(len(boxes)) if idx not in taken]
+        else:
+            not_matches = list(range(len(boxes)))
         all_idxs = [pair[0] for pair in matches] + not_matches
         dic_out['gt'] = [True] * len(matches) + [False] * len(not_matches)
 
@@ -352,12 +375,13 @@ class Loco:
                 columns.append(('aux', pick(_f64_list(dic_in['aux'])) if has_aux else []))
             for key, values in columns:
                 dic_out[key] = values
-        for idx, idx_gt in matches:
-            dd_real = dds_gt[idx_gt]
-            xyz_real = xyz_from_distance(float(dd_real), xy_centers[idx])
-            dic_out['dds_real'].append(dd_real)
-            dic_out['boxes_gt'].append(boxes_gt[idx_gt])
-            dic_out['xyz_real'].append(xyz_real.squeeze().tolist())
+        if matches:
+            # the ground-truth side of every match at once (the reference calls xyz_from_distance per match, net.py:242-247)
+            idx_m = [pair[0] for pair in matches]
+            dds_real = [dds_gt[pair[1]] for pair in matches]
+            dic_out['dds_real'] = dds_real
+            dic_out['boxes_gt'] = [boxes_gt[pair[1]] for pair in matches]
+            dic_out['xyz_real'] = _xyz_real(dds_real, xy_centers, idx_m)
         return dic_out
 
     @staticmethod

@@ -748,3 +748,50 @@ def golden_wb1024():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'wb1024':
     golden_wb1024()
+
+
+def golden_matching():
+    """Ground-truth association on images with many boxes: the reference's get_iou_matches / reorder_matches / get_iou_matrix
+    (monoloco/utils/iou.py:31-100) and the 'gt' / 'dds_real' / 'xyz_real' side of its post_process (net.py:170-190, 242-247) on
+    seeded box sets (synth.make_boxes: 16, 256 and 2048 detections, with confidence ties, IoU ties, duplicated boxes).  The
+    boxes are regenerated from the seed at test time; stored are the reference's results and the two np.argsort orders it saw
+    (tie order of an unstable sort may depend on the CPU's SIMD dispatch: a test that meets a different order on its
+    machine compares against the oracle, which calls the same np.argsort, and says so)."""
+    from monoloco.utils.iou import get_iou_matches, get_iou_matches_matrix, get_iou_matrix, reorder_matches
+    cases = []
+    for m, g, seed, ties, iou_min in ((16, 16, 11, True, 0.3), (16, 5, 12, False, 0.3), (5, 40, 13, True, 0.5), (256, 256, 14, True, 0.3),
+                                      (256, 300, 15, False, 0.3), (2048, 2048, 16, True, 0.3), (2048, 1500, 17, False, 0.45)):
+        boxes, gt = synth.make_boxes(m, g, seed, ties=ties)
+        matches = get_iou_matches(boxes, gt, iou_min=iou_min)
+        ordered = reorder_matches(matches, boxes, mode='left_right')
+        case = dict(m=m, g=g, seed=seed, ties=ties, iou_min=iou_min, matches=[list(p) for p in matches],
+                    ordered=[list(p) for p in ordered],
+                    argsort_conf=np.argsort([b[4] for b in boxes]).tolist(), argsort_left=np.argsort([b[0] for b in boxes]).tolist())
+        if m <= 256:
+            mat = get_iou_matrix(boxes, gt)
+            case['iou_sum'] = float(mat.sum())
+            case['iou_row3'] = mat[3].tolist()
+            case['matches_matrix'] = [[int(a), int(b)] for a, b in get_iou_matches_matrix(boxes, gt, iou_min)]
+        cases.append(case)
+        print('matching %4d x %4d: %d matches' % (m, g, len(matches)))
+    # post_process with ground truth at 256 persons: network outputs are stand-ins (post_process only reads d, bi, epi, yaw)
+    m, g = 256, 200
+    boxes, gt = synth.make_boxes(m, g, 21, ties=True)
+    kps = synth.make_poses(m, 22)
+    rng = np.random.default_rng(23)
+    dic_in = {'d': torch.tensor(rng.uniform(2, 40, (m, 1)).astype(np.float32)), 'bi': torch.tensor(rng.uniform(0.1, 2, (m, 1)).astype(np.float32)),
+              'epi': [0.] * m, 'yaw': (torch.tensor(rng.uniform(-3, 3, (m, 1)).astype(np.float32)),
+                                       torch.tensor(rng.uniform(-3, 3, (m, 1)).astype(np.float32)))}
+    dic_gt = {'boxes': gt, 'ys': [[0, 0, 0, 3.0 + 0.173 * j] for j in range(g)]}
+    post = {}
+    for reorder in (True, False):
+        out = Loco.post_process(dic_in, copy.deepcopy(boxes), kps.tolist(), synth.KITTI_K, dic_gt=dic_gt, reorder=reorder)
+        post['reorder_%d' % reorder] = {k: out[k] for k in ('gt', 'dds_real', 'xyz_real', 'boxes_gt', 'dds_pred', 'confs', 'xyz_pred',
+                                                             'uv_centers', 'angles')}
+        post['reorder_%d' % reorder]['boxes_x1'] = [b[0] for b in out['boxes']]
+    json.dump({'cases': cases, 'post_256': post}, open(os.path.join(OUT, 'golden_matching.json'), 'w'))
+    print('golden_matching.json %.1f KiB' % (os.path.getsize(os.path.join(OUT, 'golden_matching.json')) / 1024))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'matching':
+    golden_matching()

@@ -97,3 +97,38 @@ def big_train_batch(x, y, m, seed):
     idx = rng.integers(0, x.shape[0], size=m)
     xb = x[idx] + rng.normal(0, 0.01, size=(m, x.shape[1])).astype(np.float32)
     return xb.astype(np.float32), y[idx].astype(np.float32)
+
+
+def make_boxes(m, g, seed, ties=True, width=1238, height=374):
+    """Detection boxes [x1, y1, x2, y2, conf] (m) and ground-truth boxes [x1, y1, x2, y2] (g) as nested Python lists, from
+    Python's own Mersenne Twister (random.Random(seed): the same doubles on every machine).  About 70 % of the ground-truth
+    boxes are jittered copies of a detection; with `ties` there are repeated confidences (argsort ties), exact copies of
+    detection boxes (IoU 1.0 several times over), duplicated ground-truth boxes (np.argmax ties) and duplicated left edges
+    (reorder ties).  The same function feeds oracle/make_golden.py (reference run) and the tests."""
+    import random
+    rnd = random.Random(seed)
+    boxes = []
+    for _ in range(m):
+        x, y = rnd.uniform(0, width - 120), rnd.uniform(0, height - 220)
+        conf = rnd.choice([0.25, 0.5, 0.75]) if ties and rnd.random() < 0.4 else rnd.random()
+        boxes.append([x, y, x + rnd.uniform(20, 100), y + rnd.uniform(40, 200), conf])
+    if ties and m > 8:
+        boxes[5][0] = boxes[2][0]      # equal left edges
+        boxes[7] = list(boxes[1])      # a detection listed twice (same box, same confidence)
+    gt = []
+    for i in range(g):
+        if m and rnd.random() < 0.7:
+            b = boxes[i % m]
+            if ties and rnd.random() < 0.3:
+                gt.append(list(b[:4]))
+            else:
+                gt.append([b[0] + rnd.uniform(-10, 10), b[1] + rnd.uniform(-10, 10), b[2] + rnd.uniform(-10, 10),
+                           b[3] + rnd.uniform(-10, 10)])
+        else:
+            x, y = rnd.uniform(0, width - 120), rnd.uniform(0, height - 220)
+            gt.append([x, y, x + rnd.uniform(20, 100), y + rnd.uniform(40, 200)])
+    rnd.shuffle(gt)
+    if ties and g > 4:
+        gt[3] = list(gt[1])
+        gt[-1] = list(gt[0])
+    return boxes, gt

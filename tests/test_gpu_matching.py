@@ -1,0 +1,122 @@
+"""Ground-truth association on the GPU: the fp64 IoU kernels of csrc/matching.hip against the REAL reference's
+matches on 256 / 2048 boxes (tests/golden/golden_matching.json), against the native host routines (same source, same bits)
+and against the oracle; Loco.post_process with ground truth at 256 persons against the reference's own output; the matched
+xyz_real on the device and on the host."""
+import copy
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from monoloco_amd.network import Loco
+from monoloco_amd.network import net as N
+from monoloco_amd.utils import iou as I
+from oracle import monoloco_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+GOLD = json.load(open(os.path.join(G, 'golden_matching.json')))
+CASES = GOLD['cases']
+IDS = ['%dx%d%s' % (c['m'], c['g'], '_ties' if c['ties'] else '') for c in CASES]
+
+
+def pairs(lst):
+    return [tuple(p) for p in lst]
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_device_matching_is_the_references(hip_lib, cuda_device, monkeypatch, case):
+    boxes, gt = synth.make_boxes(case['m'], case['g'], case['seed'], ties=case['ties'])
+    monkeypatch.setattr(I, 'DEVICE_MIN_PAIRS', 1)      # every size through the kernels
+    dev_matches = I.get_iou_matches(boxes, gt, case['iou_min'])
+    dev_ordered = I.get_iou_matches_ordered(boxes, gt, case['iou_min'])
+    dev_mat = I.get_iou_matrix(boxes, gt) if case['m'] <= 256 else None
+    monkeypatch.setattr(I, 'DEVICE_MIN_PAIRS', 1 << 62)  # ... and through the host loops
+    assert dev_matches == I.get_iou_matches(boxes, gt, case['iou_min'])
+    assert dev_ordered == I.get_iou_matches_ordered(boxes, gt, case['iou_min'])
+    same_sort = (np.argsort([b[4] for b in boxes]).tolist() == case['argsort_conf']
+                 and np.argsort([b[0] for b in boxes]).tolist() == case['argsort_left'])
+    if same_sort:
+        assert dev_matches == pairs(case['matches']) and dev_ordered == pairs(case['ordered'])
+    elif case['m'] <= 256:
+        assert dev_matches == O.get_iou_matches(boxes, gt, case['iou_min'])
+    if dev_mat is not None:
+        assert np.array_equal(dev_mat, I.get_iou_matrix(boxes, gt))          # host loops: same bits
+        assert float(dev_mat.sum()) == case['iou_sum'] and dev_mat[3].tolist() == case['iou_row3']
+        assert np.array_equal(dev_mat, O.get_iou_matrix(boxes, gt))
+
+
+def test_device_best_rows_bits_and_edges(hip_lib, cuda_device, monkeypatch):
+    """Per-row arg-max and maximum: device == host bit for bit, with NaN rows, duplicate maxima beyond one wavefront's stride,
+    g not a multiple of 64, strides 4 and 5; zero unions raise."""
+    rng = np.random.default_rng(3)
+    for m, g in ((1, 1), (3, 63), (5, 64), (7, 65), (129, 1000), (1000, 129)):
+        boxes, gt = synth.make_boxes(m, g, 100 + m, ties=True)
+        b, q = I._boxes_f64(boxes), I._boxes_f64(gt)
+        if g > 70:
+            q[g - 1] = q[2]           # the same maximum twice, in different lanes and iterations: the first index must win
+            q[66] = q[2]
+        if m > 2:
+            b[1, 2] = np.nan          # a row of NaN IoUs
+        if g > 3 and m > 4:
+            q[3, 0] = np.nan          # a NaN column: np.argmax takes the FIRST NaN
+        monkeypatch.setattr(I, 'DEVICE_MIN_PAIRS', 1)
+        j_d, v_d = I._best_rows(b, q)
+        monkeypatch.setattr(I, 'DEVICE_MIN_PAIRS', 1 << 62)
+        j_h, v_h = I._best_rows(b, q)
+        assert np.array_equal(j_d, j_h), (m, g)
+        assert np.array_equal(v_d.view(np.int64), v_h.view(np.int64)), (m, g)
+        mat = O.get_iou_matrix(b.tolist(), q.tolist())
+        assert j_h.tolist() == [int(np.argmax(row)) for row in mat]
+    monkeypatch.setattr(I, 'DEVICE_MIN_PAIRS', 1)
+    with pytest.raises(ZeroDivisionError):
+        I.get_iou_matches([[5., 5., 5., 5., 0.9], [0., 0., 1., 1., 0.5]], [[0., 0., 1., 1.], [5., 5., 5., 5.]])
+    with pytest.raises(ZeroDivisionError):
+        I.get_iou_matrix([[5., 5., 5., 5., 0.9], [0., 0., 1., 1., 0.5]], [[0., 0., 1., 1.], [5., 5., 5., 5.]])
+
+
+def test_post_process_with_ground_truth_256_persons(hip_lib, cuda_device):
+    """Loco.post_process(dic_gt=...) at 256 persons x 200 ground-truth boxes == the reference's own output (its per-person
+    loop), both orders: which detections are matched, their order, the ground-truth distances / boxes handed through and
+    xyz_real (fp32 values, bit for bit)."""
+    m, g = 256, 200
+    boxes, gt = synth.make_boxes(m, g, 21, ties=True)
+    kps = synth.make_poses(m, 22)
+    rng = np.random.default_rng(23)
+    dic_in = {'d': torch.tensor(rng.uniform(2, 40, (m, 1)).astype(np.float32)), 'bi': torch.tensor(rng.uniform(0.1, 2, (m, 1)).astype(np.float32)),
+              'epi': [0.] * m, 'yaw': (torch.tensor(rng.uniform(-3, 3, (m, 1)).astype(np.float32)),
+                                       torch.tensor(rng.uniform(-3, 3, (m, 1)).astype(np.float32)))}
+    dic_gt = {'boxes': gt, 'ys': [[0, 0, 0, 3.0 + 0.173 * j] for j in range(g)]}
+    for reorder in (True, False):
+        ref = GOLD['post_256']['reorder_%d' % reorder]
+        matches, _, all_idxs = O.associate(boxes, gt, 0.3, reorder)
+        if [boxes[i][0] for i in all_idxs] != ref['boxes_x1']:
+            pytest.skip("np.argsort breaks ties differently on this CPU than where the golden was made")
+        for route_min in (1 << 62, 1):     # the matched centres on the host / through ml_xyz_from_distance
+            old = N.XYZ_REAL_DEVICE_MIN
+            N.XYZ_REAL_DEVICE_MIN = route_min
+            try:
+                out = Loco.post_process(dic_in, copy.deepcopy(boxes), kps.tolist(), synth.KITTI_K, dic_gt=dic_gt, reorder=reorder)
+            finally:
+                N.XYZ_REAL_DEVICE_MIN = old
+            assert out['gt'] == ref['gt'] and sum(out['gt']) == len(matches)
+            assert [b[0] for b in out['boxes']] == ref['boxes_x1']
+            assert out['dds_real'] == ref['dds_real'] and out['boxes_gt'] == ref['boxes_gt']
+            assert out['xyz_real'] == ref['xyz_real']                      # exact: fp32 values as Python floats
+            assert out['dds_pred'] == ref['dds_pred'] and out['angles'] == ref['angles'] and out['uv_centers'] == ref['uv_centers']
+            np.testing.assert_allclose(np.asarray(out['xyz_pred']), np.asarray(ref['xyz_pred']), rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(np.asarray(out['confs']), np.asarray(ref['confs']), rtol=2e-6)
+
+
+def test_matching_cost_on_the_gpu_box(hip_lib, cuda_device):
+    """VERDICT round 4's bars: matching at 2048 x 2048 boxes <= 20 ms (the reference: 5.4 s)."""
+    boxes, gt = synth.make_boxes(2048, 2048, 5)
+    I.get_iou_matches_ordered(boxes, gt)
+    t0 = time.perf_counter()
+    found = I.get_iou_matches_ordered(boxes, gt)
+    dt = time.perf_counter() - t0
+    assert len(found) > 1000 and dt < 0.02, dt

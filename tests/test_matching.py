@@ -1,0 +1,106 @@
+"""Ground-truth association (the batched half of post_process) on the CPU: the oracle's restatement and the
+product's native host routines (csrc/matching.hip, host entry points -- no GPU involved) against results of the REAL
+reference on seeded box sets with 16 / 256 / 2048 detections (tests/golden/golden_matching.json, oracle/make_golden.py
+`matching`), ties included.  The device kernels of the same file are checked in tests/test_gpu_matching.py."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+import synth
+from monoloco_amd.utils import iou as I
+from oracle import monoloco_oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+GOLD = json.load(open(os.path.join(G, 'golden_matching.json')))
+CASES = GOLD['cases']
+IDS = ['%dx%d%s' % (c['m'], c['g'], '_ties' if c['ties'] else '') for c in CASES]
+
+
+def same_sort_as_golden(case, boxes):
+    """True when this machine's np.argsort gives the order the golden run saw (an unstable sort's tie order may depend on
+    the CPU's SIMD dispatch; without ties it always does)."""
+    return (np.argsort([b[4] for b in boxes]).tolist() == case['argsort_conf']
+            and np.argsort([b[0] for b in boxes]).tolist() == case['argsort_left'])
+
+
+def pairs(lst):
+    return [tuple(p) for p in lst]
+
+
+@pytest.fixture
+def host_only(monkeypatch):
+    """Every size through the host entry points (the CPU suite has no device; the arithmetic is the same source)."""
+    monkeypatch.setattr(I, 'DEVICE_MIN_PAIRS', 1 << 62)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c['m'] <= 256], ids=[i for c, i in zip(CASES, IDS) if c['m'] <= 256])
+def test_oracle_matching_is_the_references(case):
+    boxes, gt = synth.make_boxes(case['m'], case['g'], case['seed'], ties=case['ties'])
+    if not same_sort_as_golden(case, boxes):
+        pytest.skip("np.argsort breaks ties differently on this CPU than where the golden was made")
+    matches = O.get_iou_matches(boxes, gt, case['iou_min'])
+    assert matches == pairs(case['matches'])
+    assert O.reorder_matches(matches, boxes) == pairs(case['ordered'])
+    mat = O.get_iou_matrix(boxes, gt)
+    assert float(mat.sum()) == case['iou_sum'] and mat[3].tolist() == case['iou_row3']
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_host_matching_is_the_references(hip_lib, host_only, case):
+    boxes, gt = synth.make_boxes(case['m'], case['g'], case['seed'], ties=case['ties'])
+    matches = I.get_iou_matches(boxes, gt, case['iou_min'])
+    ordered = I.get_iou_matches_ordered(boxes, gt, case['iou_min'])
+    assert all(type(v) is int for p in matches for v in p) and all(type(p) is tuple for p in matches)
+    assert I.reorder_matches(matches, boxes, mode='left_right') == ordered
+    if same_sort_as_golden(case, boxes):
+        assert matches == pairs(case['matches'])
+        assert ordered == pairs(case['ordered'])
+    elif case['m'] <= 256:   # another tie order on this CPU: the oracle makes the same np.argsort calls here
+        assert matches == O.get_iou_matches(boxes, gt, case['iou_min'])
+        assert ordered == O.reorder_matches(matches, boxes)
+    if 'iou_sum' in case:
+        mat = I.get_iou_matrix(boxes, gt)
+        assert mat.dtype == np.float64 and mat.shape == (case['m'], case['g'])
+        assert float(mat.sum()) == case['iou_sum'] and mat[3].tolist() == case['iou_row3']
+        assert [(int(a), int(b)) for a, b in I.get_iou_matches_matrix(boxes, gt, case['iou_min'])] == pairs(case['matches_matrix'])
+
+
+def test_matching_edge_cases(hip_lib):
+    boxes, gt = synth.make_boxes(12, 9, 3)
+    assert I.get_iou_matches([], gt) == [] and I.get_iou_matches(boxes, []) == [] and I.get_iou_matches_ordered([], []) == []
+    assert I.get_iou_matrix([], gt).shape == (0, 9) and I.get_iou_matrix(boxes, []).shape == (12, 0)
+    # ground-truth rows of unequal length (a trailing field on some): only x1, y1, x2, y2 are read
+    ragged = [row + [1.0] if i % 2 else row for i, row in enumerate(gt)]
+    assert I.get_iou_matches(boxes, ragged) == I.get_iou_matches(boxes, gt) == O.get_iou_matches(boxes, gt)
+    # a zero union is the reference's ZeroDivisionError (iou.py:25), not a silent nan
+    with pytest.raises(ZeroDivisionError):
+        I.get_iou_matches([[5., 5., 5., 5., 0.9]], [[5., 5., 5., 5.]])
+    with pytest.raises(ZeroDivisionError):
+        O.get_iou_matches([[5., 5., 5., 5., 0.9]], [[5., 5., 5., 5.]])
+    with pytest.raises(ZeroDivisionError):
+        I.get_iou_matrix([[5., 5., 5., 5., 0.9]], [[5., 5., 5., 5.]])
+    # a NaN IoU is np.argmax's first choice and never passes `>= iou_min`
+    nan_gt = [[float('nan'), 0., 10., 10.], [0., 0., 10., 10.]]
+    assert I.get_iou_matches([[0., 0., 10., 10., 0.5]], nan_gt) == O.get_iou_matches([[0., 0., 10., 10., 0.5]], nan_gt)
+    # threshold is inclusive; iou exactly 1.0
+    assert I.get_iou_matches([[0., 0., 10., 10., 0.5]], [[0., 0., 10., 10.]], iou_min=1.0) == [(0, 0)]
+    # reorder_matches on lists the greedy pass cannot produce: an index twice (first match wins), indices outside the boxes
+    weird = [(3, 1), (0, 2), (3, 7), (40, 0), (-1, 5), (2, 2)]
+    assert I.reorder_matches(weird, boxes, mode='left_right') == O.reorder_matches(weird, boxes)
+    assert I.reorder_matches([], boxes, mode='left_right') == []
+    with pytest.raises(AssertionError):
+        I.reorder_matches(weird, boxes, mode='left_rigth')   # the reference's default value is a typo its own assert rejects
+
+
+def test_host_matching_cost(hip_lib, host_only):
+    """The quadratic Python of the reference took 0.5 ms at 16 boxes and 5.4 s at 2048: bounds far above what
+    the native pass needs, far below that."""
+    for m, bound in ((16, 2e-3), (2048, 0.5)):
+        boxes, gt = synth.make_boxes(m, m, 5)
+        I.get_iou_matches_ordered(boxes, gt)
+        t0 = time.perf_counter()
+        I.get_iou_matches_ordered(boxes, gt)
+        assert time.perf_counter() - t0 < bound
