@@ -12,6 +12,10 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
+/* PY_VERSION_HEX of the headers this file was compiled against: the loader refuses the library when the running interpreter is
+ * another one (the list / float accessors below are struct-layout macros). */
+long ml_py_version_hex(void) { return (long)PY_VERSION_HEX; }
+
 int ml_py_fill_kps(PyObject* list, float* dst, long m) {
     if (!list || !dst || !PyList_CheckExact(list) || PyList_GET_SIZE(list) != m) return 1;
     for (long i = 0; i < m; ++i) {

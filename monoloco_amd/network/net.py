@@ -32,11 +32,12 @@ def _f64_list(t):
 def _lists_to_f32(keypoints):
     """[m][3][17] nested Python lists (preprocess_pifpaf's keypoints) -> one (m, 3, 17) float32 array.  np.fromiter over the
     flattened lists is ~1.5x faster than np.asarray on nested lists (the per-frame host cost the reference's list API implies);
-    anything that is not a plain list of [3][17] lists takes np.asarray (which also raises on ragged input)."""
+    anything that is not a plain list of [3][17] lists -- checked person by person -- takes np.asarray, which raises ValueError on
+    ragged input like the reference's torch.tensor(keypoints)."""
     m = len(keypoints)
-    first = keypoints[0]
-    if (type(keypoints) is list and type(first) is list and len(first) == 3 and type(first[0]) is list and len(first[0]) == 17
-            and type(keypoints[-1]) is list and len(keypoints[-1]) == 3 and len(keypoints[-1][2]) == 17):
+    # every person is checked: rows of 16 / 18 / 17 values would also sum to 51 per person and be reshaped silently
+    if type(keypoints) is list and all(type(p) is list and len(p) == 3 and type(p[0]) is list
+                                       and len(p[0]) == len(p[1]) == len(p[2]) == 17 for p in keypoints):
         it = _chain(_chain(keypoints))
         try:
             arr = np.fromiter(it, dtype=np.float32, count=m * 51)
@@ -59,7 +60,11 @@ def _pyhost():
         path = os.path.join(os.path.dirname(engine._lib.LIB_PATH), 'libmonoloco_pyhost.so')
         if os.path.exists(path):
             try:
+                import sys
                 lib = ctypes.PyDLL(path)
+                lib.ml_py_version_hex.restype = ctypes.c_long
+                if (lib.ml_py_version_hex() >> 16) != (sys.hexversion >> 16):   # built against another CPython (major.minor): numpy route
+                    raise OSError("libmonoloco_pyhost.so was compiled for another Python")
                 lib.ml_py_fill_kps.restype = ctypes.c_int
                 lib.ml_py_fill_kps.argtypes = [ctypes.py_object, ctypes.c_void_p, ctypes.c_long]
             except (OSError, AttributeError):

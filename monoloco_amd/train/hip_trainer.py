@@ -19,7 +19,7 @@ class HipTrainer:
     """Parameters, Adam state and the training step live in the library; tensors cross by state_dict key."""
 
     def __init__(self, state_dict, p_dropout=0.2, lr=0.002, sched_gamma=0.98, sched_step=30, seed=1, device=None,
-                 auto_tune_mtl=False, lambdas=None, route='auto', fast_rows=None):
+                 auto_tune_mtl=False, lambdas=None, route='auto', fast_rows=None, dw_layout=None):
         self._h = None
         lib = _lib.load()
         self.device = _require_cuda(device)
@@ -35,6 +35,11 @@ class HipTrainer:
             self._h = h
             self.load_state_dict(state_dict)
         self.set_route(route, fast_rows)
+        if dw_layout is None:   # MONOLOCO_TRAIN_DW_LAYOUT=0|1|2 picks it without touching the caller (the reference's Trainer has no such argument)
+            import os
+            dw_layout = os.environ.get('MONOLOCO_TRAIN_DW_LAYOUT')
+        if dw_layout is not None:
+            self.set_dw_layout(int(dw_layout))
         self.last_plain = None
         self.auto_tune_mtl = bool(auto_tune_mtl)
         if self.auto_tune_mtl:   # AutoTuneMultiTaskLoss (reference train/losses.py:17-43)
@@ -48,6 +53,14 @@ class HipTrainer:
         """Which GEMM route the steps of THIS trainer take (ml_trainer_set_route): 'auto' (>= fast_rows rows, default 4096:
         the large-batch 3-product kernels; below: the mid route of csrc/train_mid.h; else exact fp32), 'exact', 'mid', 'fast'."""
         check(_lib.load().ml_trainer_set_route(self._h, ROUTES[route], -1 if fast_rows is None else int(fast_rows)), train=True)
+
+    def set_dw_layout(self, dw_layout):
+        """Large-batch route (>= fast_rows rows) only.  1 (the default): the residual stream, the stages' inner activations and dz exist
+        between kernels as fp16 hi+lo lines only (~22 significant bits, re-rounded once per stage; dz scaled by a bound of its column
+        maxima) -- 1.5 ms faster per 65536-row step; the parity numbers of tests/test_gpu_train.py are for this layout.  0 / 2: those
+        tensors stay fp32 between kernels like the reference's (0 = transposed operand copies, 2 = reduction-major operands; same bits)."""
+        assert int(dw_layout) in (0, 1, 2)
+        check(_lib.load().ml_trainer_set_tuning(self._h, 0, -1, int(dw_layout)), train=True)
 
     @property
     def last_route(self):

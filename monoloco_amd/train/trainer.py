@@ -146,7 +146,8 @@ class Trainer:
         self.auto_tune_mtl = bool(getattr(args, 'auto_tune_mtl', False))
         self.hip = HipTrainer(self.model.state_dict(), p_dropout=args.dropout, lr=args.lr, sched_gamma=args.sched_gamma,
                               sched_step=int(args.sched_step), seed=args.r_seed, device=self.device,
-                              auto_tune_mtl=self.auto_tune_mtl, lambdas=self.lambdas[:len(self.tasks)])
+                              auto_tune_mtl=self.auto_tune_mtl, lambdas=self.lambdas[:len(self.tasks)],
+                              dw_layout=getattr(args, 'dw_layout', None))   # (None: library default / MONOLOCO_TRAIN_DW_LAYOUT)
         self.epoch_losses = defaultdict(lambda: defaultdict(list))
         self._eval_eng, self._eval_version = None, -1
 

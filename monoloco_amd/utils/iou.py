@@ -38,7 +38,7 @@ def _boxes_f64(boxes):
     if arr is None or arr.ndim != 2:
         arr = np.asarray([box[:4] for box in boxes], dtype=np.float64)
     assert arr.ndim == 2 and arr.shape[1] >= 4, "boxes must be rows of x1, y1, x2, y2[, ...]"
-    return np.ascontiguousarray(arr)
+    return arr if arr.flags.c_contiguous else np.ascontiguousarray(arr)
 
 
 def _raise_zero_div(flag):
@@ -131,8 +131,9 @@ def _matches(boxes, boxes_gt, iou_min, left_to_right):
     b, gt = _boxes_f64(boxes), _boxes_f64(boxes_gt)
     m, g = b.shape[0], gt.shape[0]
     # the reference's own sort calls on the same doubles (iou.py:51-53, :97): ties come out in numpy's order
-    order = np.argsort(b[:, 4].copy())[::-1].copy()
-    left = np.argsort(b[:, 0].copy()) if left_to_right else None
+    # (argsort of a strided column sorts a contiguous copy of it: the same call on the same values)
+    order = np.argsort(b[:, 4])[::-1].copy()
+    left = np.argsort(b[:, 0]) if left_to_right else None
     p_left = left.ctypes.data if left_to_right else None
     out = np.empty((2 * min(m, g) + 2,), dtype=np.int64)   # pairs | n_pairs | zero-division flag
     p_out = out.ctypes.data

@@ -31,3 +31,22 @@ def test_bench_line_contract(hip_lib, cuda_device):
     assert rf['traffic'] is None and rf['traffic_source'].startswith('none')      # (the committed PMC passes cover the 65536-row line only)
     assert d['parity']['max_abs_xyzds'] <= d['parity']['tolerance'] == 1e-4
     assert d['ranks_seen'] == 1 and d['ranks'][0]['rank'] == 0 and 'uuid' in d['ranks'][0]['device'].lower() or 'pci' in d['ranks'][0]['device'].lower()
+
+
+def test_bench_line_carries_live_counters(hip_lib, cuda_device):
+    """The headline configuration: roofline.traffic / mfma_busy / hbm_gbps are measured by THIS run (child runs under rocprofv3,
+    bench.live_counters) and agree with the passes committed under profiles/ (kept beside them as *_replayed)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '6', '--warmup', '2', '--no-extra', '--cpu-seconds', '0', '--no-parity'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, "exactly one line on stdout"
+    rf = json.loads(r.stdout)['roofline']
+    assert rf['counters_source'].startswith('live'), rf['counters_source']
+    assert rf['traffic'] == rf['traffic_live'] and rf['traffic_source'].startswith('live')
+    assert rf['algorithmic_bytes_per_launch'] <= rf['traffic_live'] <= 1.6 * rf['algorithmic_bytes_per_launch']
+    assert 0.3 < rf['mfma_busy_live'] < 1.0 and 500 < rf['hbm_gbps_live'] < 8000
+    assert 'dense_kernel_w4' in rf['dominant_kernel_live'] and 200 < rf['dominant_kernel_avg_us_live'] < 600
+    if rf.get('traffic_replayed'):
+        assert abs(rf['traffic_live'] / rf['traffic_replayed'] - 1) < 0.10
+        assert abs(rf['mfma_busy_live'] / rf['mfma_busy_replayed'] - 1) < 0.10
