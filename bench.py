@@ -52,6 +52,22 @@ def cpu_model():
     return 'unknown'
 
 
+def host_threads():
+    """Threads worth giving torch on this box: the cores this process may run on, capped by the container's cgroup CPU quota
+    (a box can show 256 cores and grant 16: torch's default of one thread per visible core then runs several times slower)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(sd, kps_np, kk, budget_s):
     """The CPU path timed on this box's host cores (BASELINE.md section 3 protocol: thread sweep, >= 3 warm-ups,
     >= 5 repetitions, median): the oracle -- the reference itself does not exist on the GPU box -- a
@@ -347,6 +363,8 @@ def parity_of_timed_run(sd, kps, conf, xyzds, raw, kk, packed=None, chunk=8192, 
     m = kps.shape[0]
     sd_t = {k: torch.tensor(v) for k, v in sd.items()}
     sd_64 = {k: v.double() for k, v in sd_t.items()}
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(host_threads())
     kps_h, conf_h, xyzds_h, raw_h = kps.cpu()[::every], conf.cpu()[::every], xyzds.cpu()[::every], raw.cpu()[::every]
     z_h = packed[:, 2].cpu()[::every] if packed is not None else None
     m = kps_h.shape[0]
@@ -371,6 +389,7 @@ def parity_of_timed_run(sd, kps, conf, xyzds, raw, kk, packed=None, chunk=8192, 
             if ok.any():
                 e_z64 = max(e_z64, (z_h[lo:hi][sub].double() - r64)[ok].abs().max().item())
                 ref_z64 = max(ref_z64, (z_ref[sub].double() - r64)[ok].abs().max().item())
+    torch.set_num_threads(prev_threads)
     res = {"max_abs_xyzds": float('%.3e' % e_par), "max_abs_raw": float('%.3e' % e_raw), "rows_checked": int(m),
            "tolerance": 1e-4, "against": "oracle/monoloco_oracle.forward_mono (torch CPU fp32) on %s of the final timed step's "
            "outputs (%.1f s)" % ("EVERY row" if every == 1 else "every %d-th row" % every, time.perf_counter() - t0)}

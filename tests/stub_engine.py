@@ -35,6 +35,10 @@ class StubEngine:
         assert not self.closed
         assert kps.shape[0] <= self.reserved, "forward on more rows than were reserved"
         self.calls += 1
+        # fault injection for the launch-contract test: this rank dies (no clean-up, like a crashed process) at its n-th call
+        import os
+        if os.environ.get('ML_STUB_DIE_RANK') == os.environ.get('RANK', '0') and self.calls == int(os.environ.get('ML_STUB_DIE_AT_CALL', '0')):
+            os._exit(17)
         if xyzds is not None:   # rows stay identifiable: the gathered block can be checked against the shards
             xyzds.copy_(kps[:, 0, :5])
         if raw is not None:

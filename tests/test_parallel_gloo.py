@@ -205,8 +205,8 @@ def _check_world2_line(d, rows_per_rank):
     assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['data'] == 'stub'
     assert [r['rank'] for r in d['ranks']] == [0, 1] and d['ranks'][0]['device'] != d['ranks'][1]['device']
     assert d['ms_per_step_min_rank'] <= d['ms_per_step_max_rank'] <= d['ms_per_step'] * 1.0001 + 1e-3
-    assert d['gather_ms'] > 0 and d['gather_check'] == {'ok': True, 'shards': 2, 'rows': 2 * rows_per_rank,
-                                                         'distinct_shards': 2}
+    gc = d['gather_check']
+    assert d['gather_ms'] > 0 and (gc['ok'], gc['shards'], gc['rows'], gc['distinct_shards']) == (True, 2, 2 * rows_per_rank, 2)
     assert d['scaling'] == 'weak' and d['config']['rows_per_gpu'] == rows_per_rank
     assert abs(d['value'] - 2 * rows_per_rank / d['ms_per_step'] * 1e3) <= 2e-3 * d['value']   # whole-job aggregate
     c4 = d['config4_strong']                                   # BASELINE configs[3] rides in the same launch
@@ -237,6 +237,25 @@ def test_bench_main_strong_world2():
     assert [r['rows'] for r in d['ranks']] == [501, 500]                       # ragged shards: point-to-point gather
     assert d['gather_check']['ok'] and d['gather_check']['rows'] == 1001
     assert 'config4_strong' not in d
+
+
+@pytest.mark.parametrize("launcher", ['self', 'torchrun'])
+def test_a_rank_that_dies_mid_run_ends_the_launch(launcher):
+    """Pre-flight for the driver's 8-GPU lease: when one rank crashes between two steps (the survivors are then parked in the next
+    barrier / gather), the launcher must come back NON-ZERO within a bounded time and without a JSON line -- not hang."""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(ML_STUB_DIE_RANK='1', ML_STUB_DIE_AT_CALL='3')
+    tail = ['bench.py', '--gpus', '2', '--stub-engine', '--steps', '4', '--warmup', '1', '--batch', '256']
+    cmd = tail if launcher == 'self' else ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                                           '127.0.0.1', '--master-port', str(_free_port())] + tail
+    t0 = time.time()
+    r = subprocess.run([sys.executable] + cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    assert time.time() - t0 < 120
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')], "a failed launch must not print a result line"
 
 
 def test_bench_gpus_mismatch_is_an_error():
