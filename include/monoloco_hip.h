@@ -404,6 +404,13 @@ long long ml_debug_frames_without_copies(void);
 #define ML_ROUTE_HALF 4    /* dense_kernel_w4 with its half-size 256 x 128 tile for the long-K layers (dense_mid_kernel for the input layer) */
 #define ML_ROUTE_TILE 5    /* the persistent 256 x 256-tile kernels (dense_kernel_w4 / dense_kernel_pp) with fused heads */
 int ml_loco_route(const ml_loco* h, int64_t rows);
+/* The launch plan of a forward of `rows` network rows on this handle, as text -- the very plan the forward executes (one
+ * make_plan in the library decides, run_network only walks it): "route=<family>; L<i> <kernel>[+fin8|+fin9][+aux][+dropout]
+ * [ heads<n>] ...; end=<tail_mono | reduce | heads_pair[+post] | heads_small[+post] | heads>".  +fin / +aux: that head leaves the
+ * layer's epilogue as partial sums (its activation is never re-read); heads<n>: a head launched on its own behind that layer.
+ * mc_dropout != 0: the plan of a stochastic (MC-dropout) pass; with_post != 0: as called from ml_loco_forward_mono (the
+ * post-process may ride in the last launch).  Tests assert the fusion state per row count with it. */
+int ml_loco_plan(const ml_loco* h, int64_t rows, int mc_dropout, int with_post, char* text, int64_t cap);
 /* Path selection of ONE handle, for tests / A-B runs that compare the paths (negative = leave unchanged; defaults 512 / 128 /
  * 0 / 4): rows <= small_rows take the small-row dense kernels, above small32_rows those use 32x32 tiles; chunk_rows > 0 walks
  * the batch in row chunks of that size through all layers; tile_kernel: 4 = dense_kernel_w4 for the long-K layers,

@@ -43,12 +43,8 @@
 #define ML_L_ORDER 0   // 1: in an L phase the fragment reads are issued before the DMA instructions
 #endif
 
-// bring-up / ablation bits are compiled out of release builds (make EXTRA=-DML_BRINGUP brings them back)
-#ifdef ML_BRINGUP
-#define ML_DBG(p, bit) (((p).debug & (bit)) != 0)
-#else
+// (the run-time bring-up / ablation bits of rounds 1-2 are gone; the timing ablations that remain are compile-time, ML_W4_ABL)
 #define ML_DBG(p, bit) (0)
-#endif
 
 namespace mlk {
 

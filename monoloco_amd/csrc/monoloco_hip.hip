@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -186,6 +187,7 @@ struct ml_loco {
     int32_t* d_rowidx = nullptr;
     float* d_part = nullptr;    // fused-head partial sums [2*hidden/256][cap_rows][16] ...
     float* d_part_aux = nullptr;  // ... and, behind them, the fused w_aux head's [2*hidden/256][cap_rows] (same allocation)
+    double* d_mc = nullptr;     // MC-dropout: running (sum, sum of squares) per person + per-(pass, person) partials: 4 doubles per row
     int64_t cap_side = 0;
     int64_t dev_bytes = 0;
     // optional per-launch timing of the dense kernel (ml_loco_profile_*): HIP events recorded on
@@ -348,6 +350,8 @@ int free_workspace(ml_loco* h) {
     dev_free(h->d_raw);
     dev_free(h->d_rowidx);
     dev_free(h->d_part);
+    dev_free(h->d_mc);
+    h->d_mc = nullptr;
     h->d_xf32 = h->d_centre = h->d_raw = h->d_part = h->d_part_aux = nullptr;
     h->d_rowidx = nullptr;
     h->cap_rows = 0;
@@ -369,6 +373,7 @@ int ensure_rows(ml_loco* h, int64_t rows) {
     if ((rc = dev_alloc(h, &h->d_rowidx, need * 4))) return rc;
     if ((rc = dev_alloc(h, &h->d_part, (int64_t)(2 * h->hidden / 256) * need * 17 * 4))) return rc;
     h->d_part_aux = h->d_part + (int64_t)(2 * h->hidden / 256) * need * 16;
+    if ((rc = dev_alloc(h, &h->d_mc, need * 4 * (int64_t)sizeof(double)))) return rc;
     h->cap_rows = need;
     return ML_OK;
 }
@@ -394,31 +399,6 @@ mlk::Kinv make_kinv(const float* k) {
     return ki;
 }
 
-// ---- bring-up knobs.  Release builds have none: no getenv in a hot call, no debug branch in the kernels, no
-// first-generation kernel.  `make EXTRA=-DML_BRINGUP` compiles them back in (tools/gpu_exp1.sh, trace_summary.py).
-#ifdef ML_BRINGUP
-int dense_debug_bits() {
-    static int bits = -1;
-    if (bits < 0) {
-        const char* e = getenv("ML_DENSE_DEBUG");
-        bits = e ? atoi(e) : 0;
-    }
-    return bits;
-}
-int dense_variant() {
-    // ML_DENSE_VARIANT=1 selects the first-generation kernel (one tile per workgroup, one barrier per k-step)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("ML_DENSE_VARIANT");
-        v = e ? atoi(e) : 2;
-    }
-    return v;
-}
-#else
-constexpr int dense_debug_bits() { return 0; }
-constexpr int dense_variant() { return 2; }
-#endif
-
 int num_cus() {
     static int n = 0;
     if (!n) {
@@ -431,32 +411,14 @@ int num_cus() {
     return n;
 }
 
-#ifdef ML_BRINGUP
-// ML_DENSE_TRACE=<file>: every pp dense launch records per-wave s_memtime stamps, which are appended
-// to the file after a stream sync (bring-up tool; serialises the stream).
-int trace_after_launch(unsigned long long* buf, size_t n, int grid, const mlk::DenseParams& p, hipStream_t st) {
-    HIP_TRY(hipStreamSynchronize(st));
-    std::vector<unsigned long long> host(n);
-    HIP_TRY(hipMemcpy(host.data(), buf, n * 8, hipMemcpyDeviceToHost));
-    FILE* f = fopen(getenv("ML_DENSE_TRACE"), "ab");
-    if (f) {
-        long long hdr[8] = {0x54524143, grid, p.M_pad, p.N, p.K, p.res ? 1 : 0, (long long)n, 0};
-        fwrite(hdr, 8, 8, f);
-        fwrite(host.data(), 8, n, f);
-        fclose(f);
-    }
-    return ML_OK;
-}
-
-#endif
 
 bool use_small_path(const Tuning& tu, int precision, int64_t rows) {
     // (the bf16 comparison mode exists on the tile path only)
-    return dense_variant() != 1 && !dense_debug_bits() && precision != ML_PREC_BF16 && rows <= tu.small_rows;
+    return precision != ML_PREC_BF16 && rows <= tu.small_rows;
 }
 
 bool use_mid_path(const Tuning& tu, int precision, int64_t rows) {
-    return dense_variant() != 1 && !dense_debug_bits() && precision != ML_PREC_BF16 && rows > tu.small_rows && rows <= tu.mid_rows;
+    return precision != ML_PREC_BF16 && rows > tu.small_rows && rows <= tu.mid_rows;
 }
 
 // does the tile path run dense_kernel_w4 for a layer with this K (and fused head width)?
@@ -474,7 +436,7 @@ bool use_half_tile(const Tuning& tu, int precision, int64_t rows) {
 int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0, int64_t rows = -1,
                  int mid = 0) {
     mlk::DenseParams p = p_in;
-    p.debug = dense_debug_bits();
+    p.debug = 0;
     p.trace = nullptr;
 
     if (mid) {  // the caller chose the mid-size path (no fused heads there)
@@ -557,27 +519,7 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
 
     const int tiles = (p.M_pad / mlk::BM) * (p.N / mlk::BN);
     if (head_nh == -1 && !w4_runs(tu, p.K, 0)) return fail(ML_ERR_STATE, "fused aux head needs dense_kernel_w4");
-#ifdef ML_BRINGUP
-    if (dense_variant() == 1) {
-        if (precision == ML_PREC_F16X2)
-            hipLaunchKernelGGL(mlk::dense_kernel<3>, dim3(tiles), dim3(mlk::DENSE_THREADS), 0, st, p);
-        else
-            hipLaunchKernelGGL(mlk::dense_kernel<1>, dim3(tiles), dim3(mlk::DENSE_THREADS), 0, st, p);
-        HIP_TRY(hipGetLastError());
-        return ML_OK;
-    }
-    static unsigned long long* trace_buf = nullptr;
-    const size_t trace_n = (size_t)num_cus() * 8 * 64;
-    if (getenv("ML_DENSE_TRACE")) {
-        if (!trace_buf) HIP_TRY(hipMalloc((void**)&trace_buf, trace_n * 8));
-        HIP_TRY(hipMemsetAsync(trace_buf, 0, trace_n * 8, st));
-        p.trace = trace_buf;
-    }
-#endif
     int grid = tiles < num_cus() ? tiles : num_cus();
-#ifdef ML_BRINGUP
-    if (getenv("ML_GRID_CAP") && atoi(getenv("ML_GRID_CAP")) > 0 && grid > atoi(getenv("ML_GRID_CAP"))) grid = atoi(getenv("ML_GRID_CAP"));
-#endif
     // dense_kernel_w4 for the long-K layers; the short input layer (K <= 128: two or four k-steps per tile, all epilogue)
     // and the layer with the fused output head stay on dense_kernel_pp, whose two waves per SIMD overlap those
     // VALU-heavy epilogues (measured: 0.063 vs 0.077 ms and 0.351 vs 0.381 ms per layer at 65536 rows)
@@ -605,9 +547,6 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
         else ML_W4_NS(0);
 #undef ML_W4_NS
 #undef ML_W4
-#ifdef ML_BRINGUP
-        if (p.trace) return trace_after_launch(trace_buf, trace_n, grid, p, st);
-#endif
         HIP_TRY(hipGetLastError());
         return ML_OK;
     }
@@ -630,10 +569,30 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
     else ML_PP_NS(0);  // ML_PREC_BF16
 #undef ML_PP_NS
 #undef ML_PP
-#ifdef ML_BRINGUP
-    if (p.trace) return trace_after_launch(trace_buf, trace_n, grid, p, st);
-#endif
     HIP_TRY(hipGetLastError());
+    return ML_OK;
+}
+
+// The heads kernels keep their weights in dynamic LDS (nh x hidden floats; heads_pair_kernel: both heads): beyond 64 KiB a kernel
+// needs its limit raised once -- done at ml_loco_finalize for the widths this model will launch, not on the hot calls.
+int set_head_lds_limits(const ml_loco* h) {
+    auto raise = [](const void* fn, size_t lds) -> hipError_t {
+        return lds > 65536 ? hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
+    };
+    int pair = 0;
+    for (const Head& hd : h->heads) {
+        const size_t lds = (size_t)hd.nh * h->hidden * 4;
+        switch (hd.nh) {
+            case 1: HIP_TRY(raise((const void*)mlk::heads_kernel<1>, lds)); break;
+            case 2: HIP_TRY(raise((const void*)mlk::heads_kernel<2>, lds)); break;
+            case 8: HIP_TRY(raise((const void*)mlk::heads_kernel<8>, lds)); pair = 8; break;
+            case 9: HIP_TRY(raise((const void*)mlk::heads_kernel<9>, lds)); pair = 9; break;
+            case 10: HIP_TRY(raise((const void*)mlk::heads_kernel<10>, lds)); break;
+            default: break;
+        }
+    }
+    if (pair == 8) HIP_TRY(raise((const void*)mlk::heads_pair_kernel<8>, (size_t)9 * h->hidden * 4));
+    if (pair == 9) HIP_TRY(raise((const void*)mlk::heads_pair_kernel<9>, (size_t)10 * h->hidden * 4));
     return ML_OK;
 }
 
@@ -646,9 +605,7 @@ int launch_heads(const Head& hd, const char* act, int H, float* raw, int raw_str
     if (grid < 1) grid = 1;
 #define ML_HEADS(NH)                                                                                 \
     case NH:                                                                                         \
-        if (lds > 65536)                                                                             \
-            HIP_TRY(hipFuncSetAttribute((const void*)mlk::heads_kernel<NH>,                          \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        /* (dynamic LDS above 64 KiB: raised once at ml_loco_finalize, set_head_lds_limits) */         \
         hipLaunchKernelGGL(mlk::heads_kernel<NH>, dim3(grid), dim3(256), lds, st, act, H, hd.d_w,    \
                            hd.d_b, raw, raw_stride, hd.col0, m, bf16);                               \
         break;
@@ -693,13 +650,146 @@ struct TailMono {
     bool geo_done = false;
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The route plan of one forward: WHICH launches a call of `rows` network rows consists of on this handle (its precision and
+// tuning), decided in one place by plain predicates -- run_network below only executes it, ml_loco_plan prints it (so tests can
+// assert the fusion state per row count), ml_loco_route reports its family.
+//   per dense layer: the kernel family and what rides in its epilogue (the w_fin head's partial sums, the w_aux head's, none);
+//   after which layer a head still needs its own launch; where the top-level MC-dropout masks are applied;
+//   how the call ends: everything inside the last dense launches + tail_mono_kernel (both reductions + post-process), the
+//   mid-size pair kernel, a single image's one-launch heads, or plain reductions / heads launches.
+enum DenseFamily { FAM_SMALL16, FAM_SMALL32, FAM_MID64, FAM_MID128, FAM_HALF, FAM_W4, FAM_PP };
+enum HeadsEnd { END_SEPARATE, END_SMALL_ONE, END_PAIR };
+
+struct LayerStep {
+    int family = FAM_PP;
+    const Head* fused_fin = nullptr;   // w_fin (8 | 9 outputs) as partial sums out of this layer's epilogue
+    const Head* fused_aux = nullptr;   // w_aux (1 output) as partial sums out of this layer's store epilogue
+    bool dropout_after = false;        // MC-dropout: masks on this layer's output
+    std::vector<const Head*> heads_after;   // heads launched on their own behind this layer (END_SEPARATE only)
+};
+
+struct RoutePlan {
+    int route = ML_ROUTE_TILE;   // family of the long-K layers (ml_loco_route)
+    bool small = false, mid = false;
+    int mid_mode = 0;            // launch_dense's `mid` argument: 0 | 1 dense_mid_kernel | 2 with the half-size w4 tile
+    int heads_end = END_SEPARATE;
+    const Head *pair_fin = nullptr, *pair_aux = nullptr;   // END_PAIR
+    std::vector<LayerStep> layers;
+};
+
+int route_family(const ml_loco* h, int64_t rows) {
+    if (use_small_path(h->tune, h->precision, rows)) return rows > h->tune.small32_rows ? ML_ROUTE_SMALL32 : ML_ROUTE_SMALL16;
+    if (use_mid_path(h->tune, h->precision, rows)) {
+        const int64_t m_pad = round_up64(rows, 256);
+        if (use_half_tile(h->tune, h->precision, rows)) return ML_ROUTE_HALF;
+        if (h->tune.mid_tile == 64 || h->tune.mid_tile == 128) return h->tune.mid_tile == 64 ? ML_ROUTE_MID64 : ML_ROUTE_MID128;
+        return (m_pad / 128) * (h->hidden / mlk::MID_TN) >= num_cus() ? ML_ROUTE_MID128 : ML_ROUTE_MID64;
+    }
+    return ML_ROUTE_TILE;
+}
+
+RoutePlan make_plan(const ml_loco* h, int64_t rows, bool mc_on) {
+    RoutePlan pl;
+    pl.route = route_family(h, rows);
+    pl.small = use_small_path(h->tune, h->precision, rows);   // decided on the whole call, not per chunk
+    pl.mid = use_mid_path(h->tune, h->precision, rows);       // (heads as their own launches, like the small path)
+    pl.mid_mode = pl.mid ? (use_half_tile(h->tune, h->precision, rows) ? 2 : 1) : 0;
+    const bool tile = !pl.small && !pl.mid;
+    // how the call ends
+    if (pl.mid && !mc_on && h->heads.size() == 2 && h->precision != ML_PREC_BF16) {
+        // the mid-size path: both heads (+ the mono post-process) in one launch behind the last layer, when the model has the
+        // LocoModel pair (w_fin: 8 | 9 outputs in columns 0.., w_aux: the last column)
+        const Head *pf = nullptr, *pa = nullptr;
+        for (const Head& hd : h->heads) {
+            if ((hd.nh == 8 || hd.nh == 9) && hd.col0 == 0) pf = &hd;
+            else if (hd.nh == 1) pa = &hd;
+        }
+        if (pf && pa && pa->col0 == pf->nh && h->out_f == pf->nh + 1) {
+            pl.heads_end = END_PAIR;
+            pl.pair_fin = pf;
+            pl.pair_aux = pa;
+        }
+    }
+    // a single image's worth of rows: all heads in ONE launch after the last dense layer (their source buffers are both still
+    // intact there), one workgroup per row
+    if (pl.heads_end == END_SEPARATE && pl.small && rows <= 128 && !mc_on && h->heads.size() <= 2) pl.heads_end = END_SMALL_ONE;
+    pl.layers.resize(h->layers.size());
+    for (size_t li = 0; li < h->layers.size(); ++li) {
+        const DenseLayer& L = h->layers[li];
+        LayerStep& s = pl.layers[li];
+        // the w_fin head rides in the epilogue of the layer that feeds it (persistent kernel, relu, no residual)
+        for (const Head& hd : h->heads)
+            if (hd.after_layer == (int)li && (hd.nh == 8 || hd.nh == 9) && L.relu && L.res < 0 && !mc_on && tile) s.fused_fin = &hd;
+        // the one-output w_aux head rides in the store epilogue of the layer that produces its input (w4 kernel: residual+relu
+        // layer when w3*w2 are merged, the plain w2 layer otherwise); its partials have their own region behind the w_fin head's
+        if (!s.fused_fin && tile && !mc_on && w4_runs(h->tune, L.kpad, 0) && ((L.relu && L.res >= 0) || (!L.relu && L.res < 0)))
+            for (const Head& hd : h->heads)
+                if (hd.after_layer == (int)li && hd.nh == 1 && hd.src == L.dst) s.fused_aux = &hd;
+        // the kernel family launch_dense picks for this layer
+        if (pl.mid) {
+            const bool half = pl.mid_mode == 2 && h->precision == ML_PREC_F16X2 && L.kpad > 128 && L.kpad % 64 == 0 && L.n % 256 == 0;
+            s.family = half ? FAM_HALF : (pl.route == ML_ROUTE_MID64 ? FAM_MID64 : (pl.route == ML_ROUTE_MID128 ? FAM_MID128 :
+                       ((round_up64(rows, 256) / 128) * (L.n / mlk::MID_TN) >= num_cus() ? FAM_MID128 : FAM_MID64)));
+        } else if (pl.small) {
+            s.family = rows > h->tune.small32_rows ? FAM_SMALL32 : FAM_SMALL16;
+        } else {
+            s.family = w4_runs(h->tune, L.kpad, s.fused_fin ? s.fused_fin->nh : (s.fused_aux ? -1 : 0)) ? FAM_W4 : FAM_PP;
+        }
+        // top-level dropout sites only (reference net.py:141): after relu(bn1) = output of layer 0, and after relu(bn3) = the
+        // input of the w_fin head
+        if (mc_on) {
+            s.dropout_after = (li == 0);
+            for (const Head& hd : h->heads)
+                if (hd.after_layer == (int)li && hd.mc_site) s.dropout_after = true;
+        }
+        if (pl.heads_end == END_SEPARATE)
+            for (const Head& hd : h->heads)
+                if (hd.after_layer == (int)li && &hd != s.fused_fin && &hd != s.fused_aux) s.heads_after.push_back(&hd);
+    }
+    return pl;
+}
+
+// "route=tile; L0 pp; L1 w4; ...; L6 w4+aux; L7 pp+fin8; end=tail_mono" -- the plan as text (ml_loco_plan)
+std::string plan_text(const ml_loco* h, const RoutePlan& pl, bool with_tail) {
+    static const char* fam[] = {"small16", "small32", "mid64", "mid128", "half", "w4", "pp"};
+    static const char* rt[] = {"small16", "small32", "mid64", "mid128", "half", "tile"};
+    std::string s = std::string("route=") + rt[pl.route];
+    char tmp[64];
+    const Head *fin = nullptr, *aux = nullptr;
+    for (size_t li = 0; li < pl.layers.size(); ++li) {
+        const LayerStep& st = pl.layers[li];
+        snprintf(tmp, sizeof(tmp), "; L%zu %s", li, fam[st.family]);
+        s += tmp;
+        if (st.fused_fin) {
+            snprintf(tmp, sizeof(tmp), "+fin%d", st.fused_fin->nh);
+            s += tmp;
+            fin = st.fused_fin;
+        }
+        if (st.fused_aux) {
+            s += "+aux";
+            aux = st.fused_aux;
+        }
+        if (st.dropout_after) s += "+dropout";
+        for (const Head* hd : st.heads_after) {
+            snprintf(tmp, sizeof(tmp), " heads%d", hd->nh);
+            s += tmp;
+        }
+    }
+    const bool fuse_tail = fin && aux && fin->col0 == 0 && aux->col0 == fin->nh && h->out_f == fin->nh + 1;
+    if (pl.heads_end == END_PAIR) s += with_tail ? "; end=heads_pair+post" : "; end=heads_pair";
+    else if (pl.heads_end == END_SMALL_ONE) s += with_tail ? "; end=heads_small+post" : "; end=heads_small";
+    else if (fin || aux) s += (with_tail && fuse_tail) ? "; end=tail_mono" : "; end=reduce";
+    else s += "; end=heads";
+    return s;
+}
+
 int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass mc = McPass(), TailMono* tail = nullptr) {
     const int64_t m_pad_all = round_up64(rows, 256);
     // (row chunking is an inference experiment knob; the batched MC-dropout passes index their masks by global row)
     const int64_t chunk_rows = h->tune.chunk_rows / 256 * 256;
     const int64_t chunk = (chunk_rows > 0 && mc.p <= 0.f) ? chunk_rows : m_pad_all;
-    const bool small = use_small_path(h->tune, h->precision, rows);  // decided on the whole call, not per chunk
-    const bool mid = use_mid_path(h->tune, h->precision, rows);      // (heads as their own launches, like the small path)
+    const RoutePlan pl = make_plan(h, rows, mc.p > 0.f);
     const bool defer = tail && chunk == m_pad_all;   // head reductions wait for the end of the (single) chunk
     const Head *def_fin = nullptr, *def_aux = nullptr;
     const int nparts = 2 * h->hidden / 256;
@@ -714,9 +804,11 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
     for (int64_t r0 = 0; r0 < m_pad_all; r0 += chunk) {
         const int64_t m_pad = (m_pad_all - r0 < chunk) ? (m_pad_all - r0) : chunk;
         const int64_t rows_here = (rows - r0 < m_pad) ? (rows - r0) : m_pad;
+        auto at = [&](int b) { return h->buf[b] + r0 * (int64_t)(b == 0 ? h->k0pad : h->hidden) * 4; };
         for (size_t li = 0; li < h->layers.size(); ++li) {
             const DenseLayer& L = h->layers[li];
-            auto at = [&](int b) { return h->buf[b] + r0 * (int64_t)(b == 0 ? h->k0pad : h->hidden) * 4; };
+            const LayerStep& step = pl.layers[li];
+            const bool last = li + 1 == h->layers.size();
             mlk::DenseParams p;
             p.x = at(L.src);
             p.w = L.d_w;
@@ -734,139 +826,93 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             p.trace = nullptr;
             p.head_w = nullptr;
             p.head_part = nullptr;
-            // the w_fin head rides in the epilogue of the layer that feeds it (persistent kernel, relu, no residual)
-            const Head* fused = nullptr;
-            for (const Head& hd : h->heads)
-                if (hd.after_layer == (int)li && (hd.nh == 8 || hd.nh == 9) && dense_variant() != 1 && L.relu && L.res < 0 &&
-                    !dense_debug_bits() && mc.p <= 0.f && !small && !mid)
-                    fused = &hd;
-            if (fused) {
-                p.head_w = fused->d_w;
-                p.head_part = h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16;
-            }
-            // the one-output w_aux head rides in the store epilogue of the layer that produces its input (w4 kernel:
-            // residual+relu layer when w3*w2 are merged, the plain w2 layer otherwise); its partials have their own region
-            // behind the w_fin head's
-            const Head* fused_aux = nullptr;
-            if (!fused && !small && !mid && mc.p <= 0.f && !dense_debug_bits() && dense_variant() != 1 && w4_runs(h->tune, L.kpad, 0) &&
-                ((L.relu && L.res >= 0) || (!L.relu && L.res < 0)))
-                for (const Head& hd : h->heads)
-                    if (hd.after_layer == (int)li && hd.nh == 1 && hd.src == L.dst) fused_aux = &hd;
-            if (fused_aux) {
-                p.head_w = fused_aux->d_w;
+            if (step.fused_fin) {
+                p.head_w = step.fused_fin->d_w;
+                p.head_part = h->d_part + r0 * (int64_t)nparts * 16;
+            } else if (step.fused_aux) {
+                p.head_w = step.fused_aux->d_w;
                 p.head_part = h->d_part_aux + r0 * (int64_t)nparts;
             }
             const bool timed = h->profiling && (h->ev_used + 1) * 2 <= h->ev_pool.size();
             if (timed) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2], st));
-            int rc = launch_dense(h->tune, h->precision, p, st, fused ? fused->nh : (fused_aux ? -1 : 0), small ? rows_here : -1,
-                                  mid ? (use_half_tile(h->tune, h->precision, rows) ? 2 : 1) : 0);
+            int rc = launch_dense(h->tune, h->precision, p, st, step.fused_fin ? step.fused_fin->nh : (step.fused_aux ? -1 : 0),
+                                  pl.small ? rows_here : -1, pl.mid_mode);
             if (rc) return rc;
             if (timed) {
                 HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used * 2 + 1], st));
                 h->ev_layer[h->ev_used] = (int)li;
                 h->ev_used++;
             }
-            if (fused && rows_here > 0 && defer) def_fin = fused;
-            else if (fused && rows_here > 0) {
+            if (rows_here <= 0) continue;
+            // partial sums of a fused head: reduced at the end of the call (one chunk + a tail), or right here
+            if (step.fused_fin && defer) def_fin = step.fused_fin;
+            else if (step.fused_fin) {
                 hipLaunchKernelGGL(mlk::head_reduce_kernel, dim3((unsigned)((rows_here * 16 + 255) / 256)), dim3(256), 0, st,
-                                   (const float*)(h->d_part + r0 * (int64_t)(2 * h->hidden / 256) * 16), 2 * h->hidden / 256, m_pad,
-                                   rows_here, fused->nh,
-                                   (const float*)fused->d_b, raw_out + r0 * h->out_f, h->out_f, fused->col0);
+                                   (const float*)(h->d_part + r0 * (int64_t)nparts * 16), nparts, m_pad, rows_here, step.fused_fin->nh,
+                                   (const float*)step.fused_fin->d_b, raw_out + r0 * h->out_f, h->out_f, step.fused_fin->col0);
                 HIP_TRY(hipGetLastError());
             }
-            if (fused_aux && rows_here > 0 && defer) def_aux = fused_aux;
-            else if (fused_aux && rows_here > 0) {
+            if (step.fused_aux && defer) def_aux = step.fused_aux;
+            else if (step.fused_aux) {
                 hipLaunchKernelGGL(mlk::aux_reduce_kernel, dim3((unsigned)((rows_here + 255) / 256)), dim3(256), 0, st,
-                                   (const float*)(h->d_part_aux + r0 * (int64_t)nparts), nparts, m_pad,
-                                   rows_here, (const float*)fused_aux->d_b, raw_out + r0 * h->out_f, h->out_f, fused_aux->col0);
+                                   (const float*)(h->d_part_aux + r0 * (int64_t)nparts), nparts, m_pad, rows_here,
+                                   (const float*)step.fused_aux->d_b, raw_out + r0 * h->out_f, h->out_f, step.fused_aux->col0);
                 HIP_TRY(hipGetLastError());
             }
-            if (mc.p > 0.f) {
-                // top-level dropout sites only (reference net.py:141): after relu(bn1) = output of layer 0, and
-                // after relu(bn3) = the input of the w_fin head
-                bool site = (li == 0);
-                for (const Head& hd : h->heads)
-                    if (hd.after_layer == (int)li && hd.mc_site) site = true;
-                if (site) {
-                    const int64_t groups = m_pad * (L.n / 8);
-                    hipLaunchKernelGGL(mlk::dropout_lines_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
-                                       at(L.dst), m_pad, L.n, mc.p, mc.seed, (uint32_t)li, mc.m_per > 0 ? mc.m_per : m_pad_all);
-                    HIP_TRY(hipGetLastError());
-                }
+            if (step.dropout_after) {
+                const int64_t groups = m_pad * (L.n / 8);
+                hipLaunchKernelGGL(mlk::dropout_lines_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, at(L.dst), m_pad,
+                                   L.n, mc.p, mc.seed, (uint32_t)li, mc.m_per > 0 ? mc.m_per : m_pad_all);
+                HIP_TRY(hipGetLastError());
             }
-            // a single image's worth of rows: all heads in ONE launch after the last dense layer (their source
-            // buffers are both still intact there), one workgroup per row
-            const bool one_launch = small && rows <= 128 && mc.p <= 0.f && h->heads.size() <= 2;
-            // the mid-size path: both heads (+ the mono post-process) in one launch behind the last layer, when the model has the
-            // LocoModel pair (w_fin: 8 | 9 outputs in columns 0.., w_aux: the last column)
-            const Head *pf = nullptr, *pa = nullptr;
-            if (mid && mc.p <= 0.f && h->heads.size() == 2 && h->precision != ML_PREC_BF16) {
-                for (const Head& hd : h->heads) {
-                    if ((hd.nh == 8 || hd.nh == 9) && hd.col0 == 0) pf = &hd;
-                    else if (hd.nh == 1) pa = &hd;
-                }
-                if (!pf || !pa || pa->col0 != pf->nh || h->out_f != pf->nh + 1) pf = pa = nullptr;
-            }
-            if (pf) {
-                if (li + 1 == h->layers.size() && rows_here > 0) {
-                    const size_t lds = (size_t)(pf->nh + 1) * h->hidden * 4;
-                    int grid = (int)((((rows_here + 1) / 2) + 3) / 4);   // 4 waves per workgroup, 2 rows per wave and pass (heads_pair_kernel's RW)
-                    if (grid > 2048) grid = 2048;
-                    const bool with_post = defer;
-                    float* raw_dst = with_post ? tail->raw : raw_out + r0 * h->out_f;
+            if (pl.heads_end == END_PAIR && last) {
+                const Head *pf = pl.pair_fin, *pa = pl.pair_aux;
+                const size_t lds = (size_t)(pf->nh + 1) * h->hidden * 4;
+                int grid = (int)((((rows_here + 1) / 2) + 3) / 4);   // 4 waves per workgroup, 2 rows per wave and pass (heads_pair_kernel's RW)
+                if (grid > 2048) grid = 2048;
+                const bool with_post = defer;
+                float* raw_dst = with_post ? tail->raw : raw_out + r0 * h->out_f;
 #define ML_PAIR(NH)                                                                                                          \
-    do {                                                                                                                     \
-        if (lds > 65536)                                                                                                     \
-            HIP_TRY(hipFuncSetAttribute((const void*)mlk::heads_pair_kernel<NH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        (int)lds));                                                                          \
-        hipLaunchKernelGGL(mlk::heads_pair_kernel<NH>, dim3(grid), dim3(256), lds, st, (const char*)at(pf->src),             \
-                           (const char*)at(pa->src), h->hidden, (const float*)pf->d_w, (const float*)pf->d_b,                \
-                           (const float*)pa->d_w, (const float*)pa->d_b, raw_dst, rows_here,                                 \
-                           with_post ? tail->centre : (const float*)nullptr, with_post ? tail->ki : mlk::Kinv{},             \
-                           with_post ? tail->box_conf : (const float*)nullptr, with_post ? tail->out : (float*)nullptr,      \
-                           with_post ? tail->xyzds : (float*)nullptr);                                                       \
-    } while (0)
-                    if (pf->nh == 8) ML_PAIR(8);
-                    else ML_PAIR(9);
+    hipLaunchKernelGGL(mlk::heads_pair_kernel<NH>, dim3(grid), dim3(256), lds, st, (const char*)at(pf->src),                 \
+                       (const char*)at(pa->src), h->hidden, (const float*)pf->d_w, (const float*)pf->d_b,                    \
+                       (const float*)pa->d_w, (const float*)pa->d_b, raw_dst, rows_here,                                     \
+                       with_post ? tail->centre : (const float*)nullptr, with_post ? tail->ki : mlk::Kinv{},                 \
+                       with_post ? tail->box_conf : (const float*)nullptr, with_post ? tail->out : (float*)nullptr,          \
+                       with_post ? tail->xyzds : (float*)nullptr)
+                if (pf->nh == 8) ML_PAIR(8);   // (dynamic LDS above 64 KiB: the attribute was set once, at ml_loco_finalize)
+                else ML_PAIR(9);
 #undef ML_PAIR
-                    HIP_TRY(hipGetLastError());
-                    if (with_post) tail->done = true;
+                HIP_TRY(hipGetLastError());
+                if (with_post) tail->done = true;
+            } else if (pl.heads_end == END_SMALL_ONE && last) {
+                mlk::SmallHeads hp = {};
+                int k = 0;
+                for (const Head& hd : h->heads) {
+                    hp.act[k] = at(hd.src);
+                    hp.w[k] = hd.d_w;
+                    hp.b[k] = hd.d_b;
+                    hp.nh[k] = hd.nh;
+                    hp.col0[k] = hd.col0;
+                    ++k;
                 }
-            } else if (one_launch) {
-                if (li + 1 == h->layers.size() && rows_here > 0) {
-                    mlk::SmallHeads hp = {};
-                    int k = 0;
-                    for (const Head& hd : h->heads) {
-                        hp.act[k] = at(hd.src);
-                        hp.w[k] = hd.d_w;
-                        hp.b[k] = hd.d_b;
-                        hp.nh[k] = hd.nh;
-                        hp.col0[k] = hd.col0;
-                        ++k;
-                    }
-                    // (a mono forward of a single image ends here: the post-process rides in the same launch)
-                    const bool with_post = defer && h->out_f <= 16 && hp.col0[0] + hp.nh[0] <= 16 && hp.col0[1] + hp.nh[1] <= 16;
-                    if (with_post) {
-                        hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden, tail->raw,
-                                           h->out_f, rows_here, tail->centre, tail->ki, tail->box_conf, tail->out, tail->xyzds,
-                                           tail->geo_kps, tail->geo_out);
-                        tail->done = true;
-                        tail->geo_done = tail->geo_out != nullptr;
-                    } else {
-                        hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden,
-                                           raw_out + r0 * h->out_f, h->out_f, rows_here, (const float*)nullptr, mlk::Kinv{},
-                                           (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr,
-                                           (float*)nullptr);
-                    }
-                    HIP_TRY(hipGetLastError());
+                // (a mono forward of a single image ends here: the post-process rides in the same launch)
+                const bool with_post = defer && h->out_f <= 16 && hp.col0[0] + hp.nh[0] <= 16 && hp.col0[1] + hp.nh[1] <= 16;
+                if (with_post) {
+                    hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden, tail->raw,
+                                       h->out_f, rows_here, tail->centre, tail->ki, tail->box_conf, tail->out, tail->xyzds,
+                                       tail->geo_kps, tail->geo_out);
+                    tail->done = true;
+                    tail->geo_done = tail->geo_out != nullptr;
+                } else {
+                    hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden,
+                                       raw_out + r0 * h->out_f, h->out_f, rows_here, (const float*)nullptr, mlk::Kinv{},
+                                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, (float*)nullptr);
                 }
-            } else if (rows_here > 0) {
-                for (const Head& hd : h->heads)
-                    if (hd.after_layer == (int)li && &hd != fused && &hd != fused_aux) {
-                        rc = launch_heads(hd, at(hd.src), h->hidden, raw_out + r0 * h->out_f, h->out_f, rows_here, st,
-                                          h->precision == ML_PREC_BF16);
-                        if (rc) return rc;
-                    }
+                HIP_TRY(hipGetLastError());
+            }
+            for (const Head* hd : step.heads_after) {
+                rc = launch_heads(*hd, at(hd->src), h->hidden, raw_out + r0 * h->out_f, h->out_f, rows_here, st, h->precision == ML_PREC_BF16);
+                if (rc) return rc;
             }
         }
     }
@@ -1058,6 +1104,7 @@ int ml_loco_finalize(ml_loco* h, int precision, int flags) {
         HIP_TRY(hipMemcpy(hd.d_b, hd.b.data(), hd.b.size() * 4, hipMemcpyHostToDevice));
     }
     h->tensors.clear();
+    if ((rc = set_head_lds_limits(h))) return rc;
     h->finalized = true;
     return ML_OK;
 }
@@ -1196,8 +1243,23 @@ int ml_preprocess_rows(const float* kps_dev, const float* kps_r_dev, int64_t m, 
     hipStream_t st = (hipStream_t)stream;
     std::vector<mlk::Kinv> table((size_t)nk);
     for (int i = 0; i < nk; ++i) table[i] = make_kinv(kinv_table_host + (size_t)i * 9);
-    mlk::Kinv* d_table = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&d_table, (size_t)nk * sizeof(mlk::Kinv), st));
+    // the device copy of the table lives in a grow-only per-device cache (this entry point has no handle to hang a workspace on):
+    // an allocation only when a call brings more matrices than any call before it on this device
+    static std::mutex table_mu;
+    static std::map<int, std::pair<mlk::Kinv*, int>> table_cache;
+    std::lock_guard<std::mutex> lock(table_mu);
+    int dev_id = 0;
+    HIP_TRY(hipGetDevice(&dev_id));
+    auto& slot = table_cache[dev_id];
+    if (slot.second < nk) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (slot.first) (void)hipFree(slot.first);
+        slot = {nullptr, 0};
+        const int cap = nk < 64 ? 64 : nk;
+        HIP_TRY(hipMalloc((void**)&slot.first, (size_t)cap * sizeof(mlk::Kinv)));
+        slot.second = cap;
+    }
+    mlk::Kinv* d_table = slot.first;
     // `table` lives on this stack frame: wait for the upload before returning (dataset preparation is not a
     // latency-critical call)
     hipError_t e = hipMemcpyAsync(d_table, table.data(), (size_t)nk * sizeof(mlk::Kinv), hipMemcpyHostToDevice, st);
@@ -1207,7 +1269,7 @@ int ml_preprocess_rows(const float* kps_dev, const float* kps_r_dev, int64_t m, 
                            k_index_dev, z_met, x_dev);
         e = hipGetLastError();
     }
-    (void)hipFreeAsync(d_table, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);   // (the cached table may be overwritten by the next call)
     if (e != hipSuccess) return fail(ML_ERR_HIP, "ml_preprocess_rows: %s", hipGetErrorString(e));
     return ML_OK;
 }
@@ -1395,9 +1457,9 @@ static int epistemic_impl(ml_loco* h, const float* kps_dev, const float* kinv_ho
     if (per_chunk < 1) per_chunk = 1;
     if (per_chunk > n_dropout) per_chunk = n_dropout;
     if ((rc = ensure_rows(h, per_chunk * m))) return rc;
-    double* acc = nullptr;
-    // acc: running (sum, sum of squares) per person, then per-(pass, person) partials of one chunk
-    HIP_TRY(hipMallocAsync((void**)&acc, (size_t)(m * 2 + per_chunk * m * 2) * sizeof(double), st));
+    // acc: running (sum, sum of squares) per person, then per-(pass, person) partials of one chunk -- in the workspace
+    // ml_loco_reserve / ensure_rows sized (4 doubles per row >= 2 m + 2 per_chunk m): no allocation on this call
+    double* acc = h->d_mc;
     HIP_TRY(hipMemsetAsync(acc, 0, (size_t)m * 2 * sizeof(double), st));
     double* part = acc + m * 2;
     const mlk::Kinv ki = x_dev ? mlk::Kinv() : make_kinv(kinv_host);
@@ -1416,14 +1478,12 @@ static int epistemic_impl(ml_loco* h, const float* kps_dev, const float* kinv_ho
                                h->buf[0], h->k0pad, mp);
         } else if ((rc = launch_prep(st, kps_dev, m, ki, 10.0f, (float*)nullptr, (float*)nullptr, h->buf[0], h->k0pad,
                                      round_up64(m, 256), (h->legacy && h->out_f == 2) ? 1 : 0))) {
-            (void)hipFreeAsync(acc, st);
             return rc;
         }
         if (pc > 1) {
             const int64_t n16 = line_bytes / 16 * (pc - 1);
             hipLaunchKernelGGL(mlk::replicate_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, h->buf[0], line_bytes, pc);
         }
-        // every error exit of the loop goes through the hipFreeAsync(acc) below
         auto hip_rc = [&](hipError_t e, const char* what) {
             return e == hipSuccess ? ML_OK : fail(ML_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
         };
@@ -1451,7 +1511,6 @@ static int epistemic_impl(ml_loco* h, const float* kps_dev, const float* kinv_ho
                            m, (double)n_dropout * (double)n_samples, epi_dev);
         if (hipGetLastError() != hipSuccess) rc = fail(ML_ERR_HIP, "mc kernel launch failed");
     }
-    (void)hipFreeAsync(acc, st);
     return rc;
 }
 
@@ -1491,14 +1550,17 @@ int ml_loco_route(const ml_loco* h, int64_t rows) {
     // which dense kernel family a forward of `rows` network rows takes on this handle (its precision and tuning); the mid window's
     // long-K layers: 64- / 128-row dense_mid_kernel tiles or dense_kernel_w4's half-size tile
     if (!h || rows < 0) return -1;
-    if (use_small_path(h->tune, h->precision, rows)) return rows > h->tune.small32_rows ? ML_ROUTE_SMALL32 : ML_ROUTE_SMALL16;
-    if (use_mid_path(h->tune, h->precision, rows)) {
-        const int64_t m_pad = round_up64(rows, 256);
-        if (use_half_tile(h->tune, h->precision, rows)) return ML_ROUTE_HALF;
-        if (h->tune.mid_tile == 64 || h->tune.mid_tile == 128) return h->tune.mid_tile == 64 ? ML_ROUTE_MID64 : ML_ROUTE_MID128;
-        return (m_pad / 128) * (h->hidden / mlk::MID_TN) >= num_cus() ? ML_ROUTE_MID128 : ML_ROUTE_MID64;
-    }
-    return ML_ROUTE_TILE;
+    return route_family(h, rows);
+}
+
+int ml_loco_plan(const ml_loco* h, int64_t rows, int mc_dropout, int with_post, char* text, int64_t cap) {
+    // the launch plan run_network executes for such a call, as text (the same make_plan: nothing is decided anywhere else)
+    if (!h || rows < 0 || !text || cap <= 0) return fail(ML_ERR_ARG, "ml_loco_plan: bad argument");
+    if (!h->finalized) return fail(ML_ERR_STATE, "model not finalized");
+    const std::string s = plan_text(h, make_plan(h, rows, mc_dropout != 0), with_post != 0);
+    if ((int64_t)s.size() + 1 > cap) return fail(ML_ERR_ARG, "ml_loco_plan: the text needs %zu bytes", s.size() + 1);
+    memcpy(text, s.c_str(), s.size() + 1);
+    return ML_OK;
 }
 
 int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel, int mid_rows, int mid_tile) {

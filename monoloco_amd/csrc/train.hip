@@ -168,13 +168,7 @@ int gemm(ml_trainer* t, hipStream_t st, const float* a, long sai, long sak, cons
          float* c, int ldc, int M, int N, int K, int accumulate) {
     const int tiles = ((N + mlt::GBN - 1) / mlt::GBN) * ((M + mlt::GBM - 1) / mlt::GBM);
     int splits = 1;
-#ifdef ML_BRINGUP
-    static const int exp_maxwg = getenv("ML_GEMM_MAXWG") ? atoi(getenv("ML_GEMM_MAXWG")) : 512;
-    static const int exp_mink = getenv("ML_GEMM_MINK") ? atoi(getenv("ML_GEMM_MINK")) : 128;
-    while (splits < 32 && tiles * splits < exp_maxwg && K / (splits * 2) >= exp_mink) splits *= 2;
-#else
     while (splits < 32 && tiles * splits < 512 && K / (splits * 2) >= 128) splits *= 2;
-#endif
     if ((size_t)splits * M * ldc > t->splitk_cap) splits = 1;
     int kchunk = K;
     if (splits > 1) {

@@ -407,6 +407,14 @@ class LocoEngine:
         code = int(_lib.load().ml_loco_route(self._h, int(rows)))
         return self.ROUTES[code] if 0 <= code < len(self.ROUTES) else 'unknown'
 
+    def plan_for_rows(self, rows, mc_dropout=False, with_post=True):
+        """The launch plan of a forward of `rows` network rows (ml_loco_plan): 'route=tile; L0 pp; L1 w4; ...; L6 w4+aux;
+        L7 pp+fin8; end=tail_mono' -- per dense layer its kernel family and which head rides in its epilogue, then how the
+        call ends.  The library executes exactly this plan."""
+        buf = ctypes.create_string_buffer(1024)
+        check(_lib.load().ml_loco_plan(self._h, int(rows), int(bool(mc_dropout)), int(bool(with_post)), buf, 1024))
+        return buf.value.decode()
+
     # -- measurement
     def profile_begin(self, max_launches=65536):
         check(_lib.load().ml_loco_profile_begin(self._h, int(max_launches)))

@@ -280,3 +280,35 @@ def test_pyhost_list_walk_matches_numpy():
     assert ph.ml_py_fill_kps(bad, dst.ctypes.data, 16) == 1
     assert ph.ml_py_fill_kps(tuple(kp), dst.ctypes.data, 16) == 1   # not a list: numpy's job
     assert np.array_equal(N._lists_to_f32(kp), np.asarray(kp, dtype=np.float32))
+
+
+def test_route_plan_per_row_count(hip_lib):
+    """ml_loco_plan: the launch plan the forward executes (one make_plan in the library), asserted per row count -- which kernel family
+    every dense layer takes and where the heads are fused."""
+    sd = synth.make_state_dict(1, 34, 9, 1024)
+    h = _host_model(hip_lib, sd, 34, 9, 1024, _lib.ML_FLAG_MERGE_W2W3)
+
+    def plan(rows, mc=0, post=1):
+        buf = ctypes.create_string_buffer(1024)
+        _lib.check(hip_lib.ml_loco_plan(h, rows, mc, post, buf, 1024))
+        return buf.value.decode()
+    try:
+        # the batch path: every head inside a dense epilogue, one tail launch
+        assert plan(65536) == "route=tile; L0 pp; L1 w4; L2 w4; L3 w4; L4 w4; L5 w4; L6 w4+aux; L7 pp+fin8; end=tail_mono"
+        assert plan(8193) == plan(65536) and plan(65536, post=0).endswith("end=reduce")
+        # a single image: small tiles, both heads + post-process in the last launch
+        assert plan(16) == "route=small16; " + "; ".join("L%d small16" % i for i in range(8)) + "; end=heads_small+post"
+        assert plan(128).endswith("end=heads_small+post") and "small32" in plan(129) and plan(129).endswith("L6 small32 heads1; L7 small32 heads8; end=heads")
+        # the mid window: dense_mid_kernel, from 4097 rows the half-size w4 tile for the long-K layers; the pair kernel ends the call
+        assert plan(2048).startswith("route=mid64; L0 mid64; L1 mid64") and plan(2048).endswith("end=heads_pair+post")
+        assert plan(4096).startswith("route=mid128; L0 mid128; L1 mid128")
+        assert plan(8192) == "route=half; L0 mid128; " + "; ".join("L%d half" % i for i in range(1, 8)) + "; end=heads_pair+post"
+        # a stochastic pass: no head fusion, masks behind layer 0 and in front of w_fin (reference net.py:141)
+        assert plan(65536, mc=1, post=0) == "route=tile; L0 pp+dropout; L1 w4; L2 w4; L3 w4; L4 w4; L5 w4; L6 w4 heads1; L7 w4+dropout heads8; end=heads"
+        assert hip_lib.ml_loco_route(h, 8192) == 4 and hip_lib.ml_loco_route(h, 8193) == 5
+        # tuning moves the plan, nothing else does
+        _lib.check(hip_lib.ml_loco_set_tuning(h, -1, -1, -1, 2, -1, -1))     # dense_kernel_pp everywhere: the aux head cannot ride
+        assert plan(65536) == "route=tile; " + "; ".join("L%d pp" % i for i in range(6)) + "; L6 pp heads1; L7 pp+fin8; end=reduce"
+        assert hip_lib.ml_loco_plan(h, 16, 0, 1, ctypes.create_string_buffer(8), 8) == 1   # ML_ERR_ARG: buffer too small
+    finally:
+        hip_lib.ml_loco_destroy(h)
