@@ -117,6 +117,7 @@ SIGNATURES = {
                                    POINTER(c_int)]),
     'ml_debug_num_layers': (c_int, [_P]),
     'ml_loco_route': (c_int, [_P, c_int64]),
+    'ml_loco_set_option': (c_int, [_P, c_char_p, c_int]),
     'ml_loco_plan': (c_int, [_P, c_int64, c_int, c_int, ctypes.c_char_p, c_int64]),
     'ml_loco_set_tuning': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int]),
     'ml_debug_get_packed': (c_int, [_P, c_int, POINTER(c_uint16), c_int64]),

@@ -34,6 +34,13 @@
 #define ML_W4_ABL 0
 #endif
 #define W4_DBG(bit) (((ML_W4_ABL) & (bit)) != 0)
+// swizzle of the per-wave epilogue scratch (32 rows x 128 B per pass): the 16-byte chunk of row r is XOR-ed with
+//   0: r & 7        (rounds 2-4) -- the 8-byte MFMA-layout accesses of rows r, r+8, r+16, r+24 meet in the same banks (4-way)
+//   1: (r >> 1) & 7 -- rows that share banks (same r & 1: a row is 32 of the 64 banks) spread over all 8 chunks (2-way: the floor
+//                      for 8-byte accesses that use one half of every chunk); the 16-byte store-layout side is a permutation either way
+#ifndef ML_W4_ESWZ
+#define ML_W4_ESWZ 1
+#endif
 
 namespace mlk {
 
@@ -176,7 +183,7 @@ template <int NSPLIT, bool RELU, bool RES, int HEAD, bool TRANS = false, int NJ 
 __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_kernel_w4(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[W4_LDS];
     static_assert(!TRANS || HEAD == -3, "reduction-major operands: the split-K weight-gradient variant only");
-    static_assert(NJ == 4 || (NJ == 2 && !TRANS && HEAD == 0), "half-size tile: plain / residual layers only");
+    static_assert(NJ == 4 || (NJ == 2 && !TRANS && HEAD >= -1), "half-size tile: inference layers only (plain / residual, fused w_aux, fused w_fin)");
     constexpr int BMT = 64 * NJ;   // rows (m) of a workgroup tile
     constexpr int NQ = 4 + NJ;     // fragment quarters = DMA instructions per wave and slot: 4 of W, NJ of X
     constexpr bool SPLIT = NSPLIT == 3;
@@ -540,8 +547,12 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         asm volatile("" : "+v"(elane));   // lane-dependent epilogue addresses are derived here, per tile (not hoisted)
         const int eml = elane & 31, eh = elane >> 5;
         const unsigned st_off = (unsigned)((elane >> 3) * (int)yrowb + ((elane & 7) * 16));
-        const int scr_row = eml * LINE + eh * 8;                       // + ((chunk ^ (eml & 7)) * 16)
-        const int rd_off = (elane >> 3) * LINE + (((elane & 7) ^ ((elane >> 3) & 7)) * 16);  // + qq * 1024
+        const int scr_row = eml * LINE + eh * 8;                       // + ((chunk ^ esw) * 16)
+        const int esw = ML_W4_ESWZ ? ((eml >> 1) & 7) : (eml & 7);
+        // store-layout side: row 8 qq + lane / 8, chunk lane % 8 -> + qq * 1024; ESWZ 1: the row's swizzle is (4 (qq & 1) + lane / 16) & 7,
+        // i.e. the offset below with bit 6 flipped for odd qq (RDX)
+        const int rd_off = (elane >> 3) * LINE + (((elane & 7) ^ (ML_W4_ESWZ ? (elane >> 4) : ((elane >> 3) & 7))) * 16);
+#define RDX(qq) ((ML_W4_ESWZ && ((qq) & 1)) ? 64 : 0)
         // addresses of a pass = one wave-uniform 64-bit tile base + a 32-bit offset (kept as a running, opaque value so
         // that hipcc does not pre-compute 16 + 16 address pairs into SGPRs and spill them)
         const size_t tile_off = (size_t)mbase * yrowb + (size_t)nbase * 4 + (SPLITK ? (size_t)ks0 * p.M_pad * yrowb : 0);
@@ -661,12 +672,12 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     }
                     if (RES && !F32OUT) {
 #pragma unroll
-                        for (int qq = 0; qq < 4; ++qq) *(f32x4*)(buf + rd_off + qq * 1024) = rq[pass][qq];
+                        for (int qq = 0; qq < 4; ++qq) *(f32x4*)(buf + (rd_off ^ RDX(qq)) + qq * 1024) = rq[pass][qq];
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            rh[g] = *(const u32x2*)(buf + scr_row + ((g ^ (eml & 7)) * 16));
-                            rl[g] = *(const u32x2*)(buf + scr_row + (((g + 4) ^ (eml & 7)) * 16));
+                            rh[g] = *(const u32x2*)(buf + scr_row + ((g ^ esw) * 16));
+                            rl[g] = *(const u32x2*)(buf + scr_row + (((g + 4) ^ esw) * 16));
                         }
                     }
                     u32x2 oh[4], ol[4];
@@ -727,16 +738,16 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     for (int g = 0; g < 4; ++g) {
                         if (F32OUT) {   // 4 consecutive floats of this person = 16-byte chunk 2g + (lane half) of its 128-byte row
                             u32x4 q4 = {oh[g][0], ol[g][0], oh[g][1], ol[g][1]};
-                            *(u32x4*)(buf + eml * LINE + (((2 * g + eh) ^ (eml & 7)) * 16)) = q4;
+                            *(u32x4*)(buf + eml * LINE + (((2 * g + eh) ^ esw) * 16)) = q4;
                         } else {
-                            *(u32x2*)(buf + scr_row + ((g ^ (eml & 7)) * 16)) = oh[g];
-                            *(u32x2*)(buf + scr_row + (((g + 4) ^ (eml & 7)) * 16)) = ol[g];
+                            *(u32x2*)(buf + scr_row + ((g ^ esw) * 16)) = oh[g];
+                            *(u32x2*)(buf + scr_row + (((g + 4) ^ esw) * 16)) = ol[g];
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
-                        d[qq] = *(const f32x4*)(buf + rd_off + qq * 1024);
+                        d[qq] = *(const f32x4*)(buf + (rd_off ^ RDX(qq)) + qq * 1024);
                         if (F32OUT && RES) d[qq] += rq[pass][qq];   // fp32 accumulate: the residual is fp32 in store layout already
                     }
                     if (F32OUT && !RES && !SPLITK && NJ == 4) {
@@ -793,6 +804,7 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             }
         }
 
+#undef RDX
         stamp(11);
 #ifdef ML_DENSE_TRACE
         ++ttile;

@@ -160,6 +160,7 @@ struct Tuning {
     int tile_kernel = 4, tile_all = 0;
     int mid_rows = 8192, mid_tile = 0;
     int half_from = 4096;   // mid window, rows above this: the long-K layers on dense_kernel_w4's half-size tile (mid_tile 256 forces it)
+    int half_heads = 1;     // ... with both heads riding in that tile's epilogues + tail_mono_kernel (0: heads_pair_kernel behind the last layer, rounds 3-4)
 };
 
 struct ml_loco {
@@ -439,8 +440,8 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
     p.debug = 0;
     p.trace = nullptr;
 
-    if (mid) {  // the caller chose the mid-size path (no fused heads there)
-        if (head_nh != 0 || p.N % mlk::MID_TN != 0) return fail(ML_ERR_STATE, "dense_mid_kernel: no fused head, N %% 128 == 0");
+    if (mid) {  // the caller chose the mid-size path (fused heads only on the half-size w4 tile)
+        if (p.N % mlk::MID_TN != 0) return fail(ML_ERR_STATE, "dense_mid_kernel: N %% 128 == 0");
         // the upper part of the window: dense_kernel_w4 with its HALF-SIZE tile (256 n x 128 m, NJ = 2) for the long-K layers --
         // one wave per SIMD, AGPR accumulators, the LDS-DMA ring: half the LDS traffic per MFMA of dense_mid_kernel's 64 x 64 wave
         // tiles, and (rows / 128) * (N / 256) tiles where the full-size kernel has half as many (8192 rows: 256 instead of 128)
@@ -448,18 +449,28 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
         if (half) {
             const int htiles = (p.M_pad / 128) * (p.N / mlk::BN);
             const dim3 hgrid((unsigned)(htiles < num_cus() ? htiles : num_cus()));
-#define ML_HALF(RL, RS) hipLaunchKernelGGL((mlk::dense_kernel_w4<3, RL, RS, 0, false, 2>), hgrid, dim3(mlk::W4_THREADS), 0, st, p)
-            if (p.relu) {
-                if (p.res) ML_HALF(true, true);
-                else ML_HALF(true, false);
+#define ML_HALF(RL, RS, HD) hipLaunchKernelGGL((mlk::dense_kernel_w4<3, RL, RS, HD, false, 2>), hgrid, dim3(mlk::W4_THREADS), 0, st, p)
+            // round 5: the heads ride in the half-size tile's epilogues exactly as in the full-size tile's (HEAD = -1: w_aux in the
+            // store epilogue of the layer that produces its input; HEAD = 8 | 9: w_fin's partial sums instead of the activation tile)
+            if (head_nh == -1) {
+                if (p.relu && p.res) ML_HALF(true, true, -1);
+                else if (!p.relu && !p.res) ML_HALF(false, false, -1);
+                else return fail(ML_ERR_STATE, "fused aux head: unsupported layer form");
+            } else if (head_nh == 8) ML_HALF(true, false, 8);
+            else if (head_nh == 9) ML_HALF(true, false, 9);
+            else if (head_nh != 0) return fail(ML_ERR_STATE, "half-size tile: unsupported fused head %d", head_nh);
+            else if (p.relu) {
+                if (p.res) ML_HALF(true, true, 0);
+                else ML_HALF(true, false, 0);
             } else {
-                if (p.res) ML_HALF(false, true);
-                else ML_HALF(false, false);
+                if (p.res) ML_HALF(false, true, 0);
+                else ML_HALF(false, false, 0);
             }
 #undef ML_HALF
             HIP_TRY(hipGetLastError());
             return ML_OK;
         }
+        if (head_nh != 0) return fail(ML_ERR_STATE, "dense_mid_kernel: no fused head");
         const int tiles128 = (p.M_pad / 128) * (p.N / mlk::MID_TN);
         const int tm = (tu.mid_tile == 64 || tu.mid_tile == 128) ? tu.mid_tile : (tiles128 >= num_cus() ? 128 : 64);   // (measured: 4096 rows 256 vs 266 us)
         const int tiles = (p.M_pad / tm) * (p.N / mlk::MID_TN);
@@ -696,8 +707,33 @@ RoutePlan make_plan(const ml_loco* h, int64_t rows, bool mc_on) {
     pl.mid = use_mid_path(h->tune, h->precision, rows);       // (heads as their own launches, like the small path)
     pl.mid_mode = pl.mid ? (use_half_tile(h->tune, h->precision, rows) ? 2 : 1) : 0;
     const bool tile = !pl.small && !pl.mid;
+    // may this layer carry a head in its epilogue?  The persistent tile kernels, and (round 5) dense_kernel_w4's half-size tile in
+    // the upper mid window when Tuning::half_heads is on
+    auto fusable = [&](const DenseLayer& L) {
+        return tile || (pl.mid_mode == 2 && h->tune.half_heads && h->precision == ML_PREC_F16X2 && L.kpad > 128 && L.kpad % 64 == 0 &&
+                        L.n % 256 == 0);
+    };
+    pl.layers.resize(h->layers.size());
+    int n_fused = 0;
+    for (size_t li = 0; li < h->layers.size(); ++li) {
+        const DenseLayer& L = h->layers[li];
+        LayerStep& s = pl.layers[li];
+        // the w_fin head rides in the epilogue of the layer that feeds it (persistent kernel, relu, no residual)
+        for (const Head& hd : h->heads)
+            if (hd.after_layer == (int)li && (hd.nh == 8 || hd.nh == 9) && L.relu && L.res < 0 && !mc_on && fusable(L)) s.fused_fin = &hd;
+        // the one-output w_aux head rides in the store epilogue of the layer that produces its input (w4 kernel: residual+relu
+        // layer when w3*w2 are merged, the plain w2 layer otherwise); its partials have their own region behind the w_fin head's
+        if (!s.fused_fin && fusable(L) && !mc_on && (pl.mid || w4_runs(h->tune, L.kpad, 0)) && ((L.relu && L.res >= 0) || (!L.relu && L.res < 0)))
+            for (const Head& hd : h->heads)
+                if (hd.after_layer == (int)li && hd.nh == 1 && hd.src == L.dst) s.fused_aux = &hd;
+        n_fused += (s.fused_fin ? 1 : 0) + (s.fused_aux ? 1 : 0);
+    }
+    // the mid window fuses every head or none: a single fused head would leave the pair kernel half a job
+    if (pl.mid && n_fused != (int)h->heads.size())
+        for (LayerStep& s : pl.layers) s.fused_fin = s.fused_aux = nullptr;
+    const bool mid_fused = pl.mid && n_fused == (int)h->heads.size() && n_fused > 0;
     // how the call ends
-    if (pl.mid && !mc_on && h->heads.size() == 2 && h->precision != ML_PREC_BF16) {
+    if (pl.mid && !mid_fused && !mc_on && h->heads.size() == 2 && h->precision != ML_PREC_BF16) {
         // the mid-size path: both heads (+ the mono post-process) in one launch behind the last layer, when the model has the
         // LocoModel pair (w_fin: 8 | 9 outputs in columns 0.., w_aux: the last column)
         const Head *pf = nullptr, *pa = nullptr;
@@ -714,18 +750,9 @@ RoutePlan make_plan(const ml_loco* h, int64_t rows, bool mc_on) {
     // a single image's worth of rows: all heads in ONE launch after the last dense layer (their source buffers are both still
     // intact there), one workgroup per row
     if (pl.heads_end == END_SEPARATE && pl.small && rows <= 128 && !mc_on && h->heads.size() <= 2) pl.heads_end = END_SMALL_ONE;
-    pl.layers.resize(h->layers.size());
     for (size_t li = 0; li < h->layers.size(); ++li) {
         const DenseLayer& L = h->layers[li];
         LayerStep& s = pl.layers[li];
-        // the w_fin head rides in the epilogue of the layer that feeds it (persistent kernel, relu, no residual)
-        for (const Head& hd : h->heads)
-            if (hd.after_layer == (int)li && (hd.nh == 8 || hd.nh == 9) && L.relu && L.res < 0 && !mc_on && tile) s.fused_fin = &hd;
-        // the one-output w_aux head rides in the store epilogue of the layer that produces its input (w4 kernel: residual+relu
-        // layer when w3*w2 are merged, the plain w2 layer otherwise); its partials have their own region behind the w_fin head's
-        if (!s.fused_fin && tile && !mc_on && w4_runs(h->tune, L.kpad, 0) && ((L.relu && L.res >= 0) || (!L.relu && L.res < 0)))
-            for (const Head& hd : h->heads)
-                if (hd.after_layer == (int)li && hd.nh == 1 && hd.src == L.dst) s.fused_aux = &hd;
         // the kernel family launch_dense picks for this layer
         if (pl.mid) {
             const bool half = pl.mid_mode == 2 && h->precision == ML_PREC_F16X2 && L.kpad > 128 && L.kpad % 64 == 0 && L.n % 256 == 0;
@@ -1579,6 +1606,16 @@ int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_r
     if (chunk_rows >= 0) h->tune.chunk_rows = chunk_rows;
     if (mid_rows >= 0) h->tune.mid_rows = mid_rows;
     if (mid_tile >= 0) h->tune.mid_tile = mid_tile;
+    return ML_OK;
+}
+
+int ml_loco_set_option(ml_loco* h, const char* name, int value) {
+    // named per-handle switches of the route plan (A/B runs and tests; results stay within the route-invariance bars)
+    if (!h || !name) return fail(ML_ERR_ARG, "null argument");
+    const std::string n(name);
+    if (n == "half_heads") h->tune.half_heads = value ? 1 : 0;
+    else if (n == "half_from") h->tune.half_from = value;
+    else return fail(ML_ERR_ARG, "unknown option '%s'", name);
     return ML_OK;
 }
 

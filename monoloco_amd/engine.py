@@ -407,6 +407,10 @@ class LocoEngine:
         code = int(_lib.load().ml_loco_route(self._h, int(rows)))
         return self.ROUTES[code] if 0 <= code < len(self.ROUTES) else 'unknown'
 
+    def set_option(self, name, value):
+        """Named switches of the route plan (ml_loco_set_option): 'half_heads', 'half_from'."""
+        check(_lib.load().ml_loco_set_option(self._h, name.encode(), int(value)))
+
     def plan_for_rows(self, rows, mc_dropout=False, with_post=True):
         """The launch plan of a forward of `rows` network rows (ml_loco_plan): 'route=tile; L0 pp; L1 w4; ...; L6 w4+aux;
         L7 pp+fin8; end=tail_mono' -- per dense layer its kernel family and which head rides in its epilogue, then how the
