@@ -411,10 +411,10 @@ int ml_loco_route(const ml_loco* h, int64_t rows);
  * mc_dropout != 0: the plan of a stochastic (MC-dropout) pass; with_post != 0: as called from ml_loco_forward_mono (the
  * post-process may ride in the last launch).  Tests assert the fusion state per row count with it. */
 int ml_loco_plan(const ml_loco* h, int64_t rows, int mc_dropout, int with_post, char* text, int64_t cap);
-/* Named switches of the route plan of ONE handle (A/B runs, tests): "half_heads" (default 1): in the upper mid window both heads
- * ride in the epilogues of dense_kernel_w4's half-size tile and tail_mono_kernel ends the call, 0 = heads_pair_kernel behind the
- * last layer (rounds 3-4); "half_from" (default 4096): the half-size tile takes the long-K layers of calls with more rows than
- * this (inside the mid window). */
+/* Named switches of the route plan of ONE handle (A/B runs, tests): "mid_heads" (default 1; alias "half_heads"): in the mid window
+ * both heads ride in the dense epilogues (dense_mid_kernel's, or the half-size dense_kernel_w4 tile's) and tail_mono_kernel ends the
+ * call; 0 = heads_pair_kernel behind the last layer (rounds 3-4); "half_from" (default 4096): the half-size tile takes the long-K
+ * layers of calls with more rows than this (inside the mid window). */
 int ml_loco_set_option(ml_loco* h, const char* name, int value);
 /* Path selection of ONE handle, for tests / A-B runs that compare the paths (negative = leave unchanged; defaults 512 / 128 /
  * 0 / 4): rows <= small_rows take the small-row dense kernels, above small32_rows those use 32x32 tiles; chunk_rows > 0 walks

@@ -22,7 +22,10 @@
 //   epilogue per 32x32 MFMA tile as in dense_kernel_pp: bias rides in the accumulators, * 2^-e, ReLU, + residual, split
 //           to fp16 hi|lo, transposed through a private 4 KiB LDS scratch, four 16-byte stores per lane (whole 128-byte
 //           lines); the residual comes straight from global memory in the accumulator layout (8-byte loads).
-// The heads run as their own launches behind the last layer (launch_heads), as on the small-row path.
+// HEAD (round 5): the heads ride in this kernel's epilogues as in the tile kernels' -- 8 | 9: w_fin's partial sums over this wave's
+// 64 columns instead of the activation tile (the layer that feeds w_fin is never stored); -1: w_aux's partial sums beside the
+// stored tile (of the stored hi + lo values); head_part holds N/64 slices per head here (the tile kernels: N/128), tail_mono_kernel /
+// head_reduce_kernel add them in slice order.  0: no head (heads_pair_kernel or launch_heads behind the last layer).
 #pragma once
 #include "dense_kernel_pp.h"
 
@@ -40,10 +43,12 @@ struct MidCfg {
     static constexpr int LDS = 2 * STAGE;
 };
 
-template <int NSPLIT, bool RELU, bool RES, int TM>
+template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0>
 __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p) {
     typedef MidCfg<TM> C;
     constexpr int NB = C::NB, XL = C::XL;
+    constexpr bool AUX = HEAD == -1;
+    static_assert(HEAD == 0 || HEAD == -1 || ((HEAD == 8 || HEAD == 9) && RELU && !RES), "fused head: w_aux (-1) or w_fin (8 | 9) behind relu, no residual");
     __shared__ __attribute__((aligned(16))) char smem[C::LDS];
 
     const int tid = threadIdx.x;
@@ -179,14 +184,63 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
     const size_t yrowb = (size_t)p.N * 4;
     const float lim = 65504.0f / descale;
     const int eml = r, eh = q;
+    const int nbase = n0 + wn * 64;            // this wave's 64 weight rows = head slice nbase / 64
+    const int mbase = m0 + wm * (TM / 2);
+    if (HEAD > 0) {
+        // the activation tile is not stored: the wave multiplies its relu'd 64-column slice with the HEAD x 64 slice of the head
+        // weights (staged in its scratch) and leaves one partial sum per person and output
+        float* hw = (float*)scr;
+        for (int idx = lane; idx < HEAD * 16; idx += 64) {
+            const int o = idx >> 4, c4 = idx & 15;
+            *(f32x4*)(hw + o * 64 + c4 * 4) = *(const f32x4*)(p.head_w + (size_t)o * p.N + nbase + c4 * 4);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int slice = nbase >> 6;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            float part[HEAD > 0 ? HEAD : 1];
+#pragma unroll
+            for (int o = 0; o < HEAD; ++o) part[o] = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaxf(acc[a][c][g * 4 + e] * descale, 0.0f);
+#pragma unroll
+                    for (int o = 0; o < HEAD; ++o) {
+                        const f32x4 w4 = *(const f32x4*)(hw + o * 64 + a * 32 + g * 8 + eh * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) part[o] = __builtin_fmaf(v[e], w4[e], part[o]);
+                    }
+                }
+#pragma unroll
+            for (int o = 0; o < HEAD; ++o) part[o] += __shfl_xor(part[o], 32, 64);
+            if (eh == 0) {
+                float* dst = p.head_part + ((size_t)slice * p.M_pad + (mbase + c * 32 + eml)) * 16;
+#pragma unroll
+                for (int o4 = 0; o4 < (HEAD + 3) / 4; ++o4) {
+                    f32x4 q4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q4[e] = (o4 * 4 + e < HEAD) ? part[o4 * 4 + e] : 0.0f;
+                    *(f32x4*)(dst + o4 * 4) = q4;
+                }
+            }
+        }
+        return;
+    }
     const int scr_row = eml * LINE + eh * 8;
     const int rd_off = (lane >> 3) * LINE + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);
     const size_t st_off = (size_t)(lane >> 3) * yrowb + (size_t)((lane & 7) * 16);
+    float auxp[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) auxp[c] = 0.0f;
 #pragma unroll
     for (int c = 0; c < NB; ++c)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const size_t line0 = (size_t)(m0 + wm * (TM / 2) + c * 32) * yrowb + (size_t)(n0 + wn * 64 + a * 32) * 4;
+            const size_t line0 = (size_t)(mbase + c * 32) * yrowb + (size_t)(nbase + a * 32) * 4;
             u32x2 rh[4], rl[4];
             if (RES) {
                 const char* rb = p.res + line0 + (size_t)eml * yrowb + eh * 8;
@@ -198,7 +252,9 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
             }
             u32x2 oh[4], ol[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
+                f32x4 aw = {0.f, 0.f, 0.f, 0.f};
+                if (AUX) aw = *(const f32x4*)(p.head_w + nbase + a * 32 + 8 * g + 4 * eh);   // w_aux of this lane's 4 weight rows
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const float a0 = acc[a][c][g * 4 + 2 * e2], a1 = acc[a][c][g * 4 + 2 * e2 + 1];
@@ -207,7 +263,17 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
                     else split2_scaled<RELU>(a0, a1, descale, lim, hh, ll);
                     oh[g][e2] = hh;
                     ol[g][e2] = ll;
+                    if (AUX) {   // the stored value itself, hi + lo, times its head weight (dense_kernel_w4's statement)
+                        float y0, y1;
+                        asm("v_fma_mix_f32 %1, %3, 1.0, %4 op_sel_hi:[1,0,1]\n\t"
+                            "v_fma_mix_f32 %2, %3, 1.0, %4 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n\t"
+                            "v_fmac_f32 %0, %1, %5\n\t"
+                            "v_fmac_f32 %0, %2, %6"
+                            : "+v"(auxp[c]), "=&v"(y0), "=&v"(y1)
+                            : "v"(hh), "v"(ll), "v"(aw[2 * e2]), "v"(aw[2 * e2 + 1]));
+                    }
                 }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 *(u32x2*)(scr + scr_row + ((g ^ (eml & 7)) * 16)) = oh[g];
@@ -222,6 +288,14 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
+    if (AUX) {   // combine the two lane halves (weight rows 4 eh .. + 3 of every group of 8), one partial per person and 64-column slice
+        const int slice = nbase >> 6;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const float sum = auxp[c] + __shfl_xor(auxp[c], 32, 64);
+            if (eh == 0) p.head_part[(size_t)slice * p.M_pad + (mbase + c * 32 + eml)] = sum;
+        }
+    }
 }
 
 }  // namespace mlk

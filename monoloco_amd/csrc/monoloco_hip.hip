@@ -160,7 +160,8 @@ struct Tuning {
     int tile_kernel = 4, tile_all = 0;
     int mid_rows = 8192, mid_tile = 0;
     int half_from = 4096;   // mid window, rows above this: the long-K layers on dense_kernel_w4's half-size tile (mid_tile 256 forces it)
-    int half_heads = 1;     // ... with both heads riding in that tile's epilogues + tail_mono_kernel (0: heads_pair_kernel behind the last layer, rounds 3-4)
+    int half_heads = 1;     // the whole mid window: both heads ride in the dense epilogues (half-size w4 tile / dense_mid_kernel) + tail_mono_kernel
+                            // (option "mid_heads"; 0: heads_pair_kernel behind the last layer, rounds 3-4)
 };
 
 struct ml_loco {
@@ -188,6 +189,7 @@ struct ml_loco {
     int32_t* d_rowidx = nullptr;
     float* d_part = nullptr;    // fused-head partial sums [2*hidden/256][cap_rows][16] ...
     float* d_part_aux = nullptr;  // ... and, behind them, the fused w_aux head's [2*hidden/256][cap_rows] (same allocation)
+    int part_slices = 0;        // slices per head d_part / d_part_aux hold
     double* d_mc = nullptr;     // MC-dropout: running (sum, sum of squares) per person + per-(pass, person) partials: 4 doubles per row
     int64_t cap_side = 0;
     int64_t dev_bytes = 0;
@@ -372,8 +374,11 @@ int ensure_rows(ml_loco* h, int64_t rows) {
     if ((rc = dev_alloc(h, &h->d_centre, need * 2 * 4))) return rc;
     if ((rc = dev_alloc(h, &h->d_raw, need * (int64_t)h->out_f * 4))) return rc;
     if ((rc = dev_alloc(h, &h->d_rowidx, need * 4))) return rc;
-    if ((rc = dev_alloc(h, &h->d_part, (int64_t)(2 * h->hidden / 256) * need * 17 * 4))) return rc;
-    h->d_part_aux = h->d_part + (int64_t)(2 * h->hidden / 256) * need * 16;
+    // partial sums of the fused heads: 128-column slices from the tile kernels, 64-column slices from dense_mid_kernel (workspaces
+    // of up to 16384 rows, i.e. every size the mid window can be tuned to by default, hold the finer ones)
+    h->part_slices = need <= 16384 ? h->hidden / 64 : 2 * h->hidden / 256;
+    if ((rc = dev_alloc(h, &h->d_part, (int64_t)h->part_slices * need * 17 * 4))) return rc;
+    h->d_part_aux = h->d_part + (int64_t)h->part_slices * need * 16;
     if ((rc = dev_alloc(h, &h->d_mc, need * 4 * (int64_t)sizeof(double)))) return rc;
     h->cap_rows = need;
     return ML_OK;
@@ -470,27 +475,35 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
             HIP_TRY(hipGetLastError());
             return ML_OK;
         }
-        if (head_nh != 0) return fail(ML_ERR_STATE, "dense_mid_kernel: no fused head");
         const int tiles128 = (p.M_pad / 128) * (p.N / mlk::MID_TN);
         const int tm = (tu.mid_tile == 64 || tu.mid_tile == 128) ? tu.mid_tile : (tiles128 >= num_cus() ? 128 : 64);   // (measured: 4096 rows 256 vs 266 us)
         const int tiles = (p.M_pad / tm) * (p.N / mlk::MID_TN);
         const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
-#define ML_MID(NS, RL, RS)                                                                                                  \
-    do {                                                                                                                    \
-        if (tm == 128) hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, 128>), grid, dim3(mlk::MID_THREADS), 0, st, p); \
-        else hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, 64>), grid, dim3(mlk::MID_THREADS), 0, st, p);           \
+#define ML_MID(NS, RL, RS, HD)                                                                                                  \
+    do {                                                                                                                        \
+        if (tm == 128) hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, 128, HD>), grid, dim3(mlk::MID_THREADS), 0, st, p); \
+        else hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, 64, HD>), grid, dim3(mlk::MID_THREADS), 0, st, p);           \
     } while (0)
-#define ML_MID_NS(NS)                                  \
-    do {                                               \
-        if (p.relu) {                                  \
-            if (p.res) ML_MID(NS, true, true);         \
-            else ML_MID(NS, true, false);              \
-        } else {                                       \
-            if (p.res) ML_MID(NS, false, true);        \
-            else ML_MID(NS, false, false);             \
-        }                                              \
+#define ML_MID_NS(NS)                                     \
+    do {                                                  \
+        if (p.relu) {                                     \
+            if (p.res) ML_MID(NS, true, true, 0);         \
+            else ML_MID(NS, true, false, 0);              \
+        } else {                                          \
+            if (p.res) ML_MID(NS, false, true, 0);        \
+            else ML_MID(NS, false, false, 0);             \
+        }                                                 \
     } while (0)
-        if (precision == ML_PREC_F16X2) ML_MID_NS(3);
+        if (head_nh != 0) {   // round 5: the heads in dense_mid_kernel's epilogues (3-product mode; 64-column slices of partial sums)
+            if (precision != ML_PREC_F16X2) return fail(ML_ERR_STATE, "dense_mid_kernel: fused heads in the f16x2 mode only");
+            if (head_nh == -1) {
+                if (p.relu && p.res) ML_MID(3, true, true, -1);
+                else if (!p.relu && !p.res) ML_MID(3, false, false, -1);
+                else return fail(ML_ERR_STATE, "fused aux head: unsupported layer form");
+            } else if (head_nh == 8 && p.relu && !p.res) ML_MID(3, true, false, 8);
+            else if (head_nh == 9 && p.relu && !p.res) ML_MID(3, true, false, 9);
+            else return fail(ML_ERR_STATE, "dense_mid_kernel: unsupported fused head %d", head_nh);
+        } else if (precision == ML_PREC_F16X2) ML_MID_NS(3);
         else ML_MID_NS(1);
 #undef ML_MID_NS
 #undef ML_MID
@@ -685,6 +698,7 @@ struct RoutePlan {
     bool small = false, mid = false;
     int mid_mode = 0;            // launch_dense's `mid` argument: 0 | 1 dense_mid_kernel | 2 with the half-size w4 tile
     int heads_end = END_SEPARATE;
+    int nparts = 0;              // slices of partial sums per fused head (N / 128 from the tile kernels, N / 64 from dense_mid_kernel)
     const Head *pair_fin = nullptr, *pair_aux = nullptr;   // END_PAIR
     std::vector<LayerStep> layers;
 };
@@ -700,6 +714,14 @@ int route_family(const ml_loco* h, int64_t rows) {
     return ML_ROUTE_TILE;
 }
 
+// do `slices` slices of partial sums per head fit the workspace this call will run in (the current one, or the one ensure_rows
+// allocates when the call is larger than it)?
+bool part_fits(const ml_loco* h, int64_t rows, int slices) {
+    const int64_t m_pad = round_up64(rows > 0 ? rows : 1, 256);
+    if (m_pad > h->cap_rows) return slices <= (m_pad <= 16384 ? h->hidden / 64 : 2 * h->hidden / 256);
+    return (int64_t)slices * m_pad <= (int64_t)h->part_slices * h->cap_rows;
+}
+
 RoutePlan make_plan(const ml_loco* h, int64_t rows, bool mc_on) {
     RoutePlan pl;
     pl.route = route_family(h, rows);
@@ -709,12 +731,18 @@ RoutePlan make_plan(const ml_loco* h, int64_t rows, bool mc_on) {
     const bool tile = !pl.small && !pl.mid;
     // may this layer carry a head in its epilogue?  The persistent tile kernels, and (round 5) dense_kernel_w4's half-size tile in
     // the upper mid window when Tuning::half_heads is on
+    // (the mid window as a whole: Tuning::half_heads; the partial sums come in 128-column slices from the w4 tiles, in 64-column
+    // slices from dense_mid_kernel -- both heads of a call must agree, and the workspace must hold that many slices)
+    auto half_layer = [&](const DenseLayer& L) {
+        return pl.mid_mode == 2 && h->precision == ML_PREC_F16X2 && L.kpad > 128 && L.kpad % 64 == 0 && L.n % 256 == 0;
+    };
+    auto slices_of = [&](const DenseLayer& L) { return (tile || half_layer(L)) ? L.n / 128 : L.n / 64; };
     auto fusable = [&](const DenseLayer& L) {
-        return tile || (pl.mid_mode == 2 && h->tune.half_heads && h->precision == ML_PREC_F16X2 && L.kpad > 128 && L.kpad % 64 == 0 &&
-                        L.n % 256 == 0);
+        return tile || (pl.mid && h->tune.half_heads && h->precision == ML_PREC_F16X2 && L.n % 128 == 0 && part_fits(h, rows, slices_of(L)));
     };
     pl.layers.resize(h->layers.size());
     int n_fused = 0;
+    bool slices_differ = false;
     for (size_t li = 0; li < h->layers.size(); ++li) {
         const DenseLayer& L = h->layers[li];
         LayerStep& s = pl.layers[li];
@@ -727,10 +755,17 @@ RoutePlan make_plan(const ml_loco* h, int64_t rows, bool mc_on) {
             for (const Head& hd : h->heads)
                 if (hd.after_layer == (int)li && hd.nh == 1 && hd.src == L.dst) s.fused_aux = &hd;
         n_fused += (s.fused_fin ? 1 : 0) + (s.fused_aux ? 1 : 0);
+        if (s.fused_fin || s.fused_aux) {
+            if (pl.nparts && pl.nparts != slices_of(L)) slices_differ = true;
+            pl.nparts = slices_of(L);
+        }
     }
     // the mid window fuses every head or none: a single fused head would leave the pair kernel half a job
-    if (pl.mid && n_fused != (int)h->heads.size())
+    if (pl.mid && (n_fused != (int)h->heads.size() || slices_differ)) {
         for (LayerStep& s : pl.layers) s.fused_fin = s.fused_aux = nullptr;
+        n_fused = 0;
+    }
+    if (!pl.nparts || !n_fused) pl.nparts = 2 * h->hidden / 256;
     const bool mid_fused = pl.mid && n_fused == (int)h->heads.size() && n_fused > 0;
     // how the call ends
     if (pl.mid && !mid_fused && !mc_on && h->heads.size() == 2 && h->precision != ML_PREC_BF16) {
@@ -819,7 +854,7 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
     const RoutePlan pl = make_plan(h, rows, mc.p > 0.f);
     const bool defer = tail && chunk == m_pad_all;   // head reductions wait for the end of the (single) chunk
     const Head *def_fin = nullptr, *def_aux = nullptr;
-    const int nparts = 2 * h->hidden / 256;
+    const int nparts = pl.nparts;
     if (h->precision == ML_PREC_BF16) {
         // the pre-process kernels write fp16 hi|lo lines; the bf16 comparison mode re-rounds them once (hi + lo -> one
         // bf16 in the hi slot, 16 B per row chunk; 17 MB at 65536 rows -- < 0.5 % of a step, counted in its time)
@@ -1613,7 +1648,7 @@ int ml_loco_set_option(ml_loco* h, const char* name, int value) {
     // named per-handle switches of the route plan (A/B runs and tests; results stay within the route-invariance bars)
     if (!h || !name) return fail(ML_ERR_ARG, "null argument");
     const std::string n(name);
-    if (n == "half_heads") h->tune.half_heads = value ? 1 : 0;
+    if (n == "mid_heads" || n == "half_heads") h->tune.half_heads = value ? 1 : 0;
     else if (n == "half_from") h->tune.half_from = value;
     else return fail(ML_ERR_ARG, "unknown option '%s'", name);
     return ML_OK;

@@ -155,3 +155,40 @@ def test_mid_path_ten_output_model_through_the_mono_pipeline(hip_lib, cuda_devic
     assert (xyzds_mid - xyzds_tile).abs().max().item() <= 1e-4
     assert (out_mid.nan_to_num() - out_tile.nan_to_num()).abs().max().item() <= 1e-4
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["mono", "stereo"])
+@pytest.mark.parametrize("m", [513, 2049, 4096, 6000, 8192])
+def test_mid_fused_heads_match_the_pair_kernel(hip_lib, cuda_device, m, mode):
+    """Round 5: inside the mid window both heads ride in the dense epilogues (dense_mid_kernel<.., HEAD>, the half-size w4 tile with
+    HEAD = -1 / 8 / 9) and tail_mono_kernel / the reduce kernels end the call -- against heads_pair_kernel behind the last layer
+    (option mid_heads 0, rounds 3-4) and against fp64; the plan says which of the two ran."""
+    from monoloco_amd import engine
+    from oracle import monoloco_oracle as O
+    in_f, out_f = (34, 9) if mode == "mono" else (68, 10)
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(5, in_features=in_f, out_features=out_f).items()}
+    rng = np.random.default_rng(m + 1)
+    x = torch.tensor((rng.standard_normal((m, in_f)) * 3).astype(np.float32), device=cuda_device)
+    eng = engine.LocoEngine(sd, device=cuda_device)
+    fam = 'half' if m > 4096 else ('mid128' if m == 4096 else 'mid64')
+    assert eng.plan_for_rows(m, with_post=False).endswith("L6 %s+aux; L7 %s+fin%d; end=reduce" % (fam, fam, out_f - 1))
+    raw_fused = eng.forward_raw(x).cpu()
+    eng.set_option('mid_heads', 0)
+    assert eng.plan_for_rows(m, with_post=False).endswith("L7 %s; end=heads_pair" % fam)
+    raw_pair = eng.forward_raw(x).cpu()
+    ref64 = O.loco_forward(sd, x.cpu(), dtype=torch.float64)
+    scale = max(1.0, ref64.abs().max().item())
+    assert (raw_fused.double() - ref64).abs().max().item() <= 1e-4
+    assert (raw_fused - raw_pair).abs().max().item() <= 2e-6 * scale
+    if mode == "mono":   # the fused pipeline: the post-process rides in tail_mono_kernel / in the pair kernel
+        kps = torch.tensor(synth.make_poses(m, 9)).to(cuda_device)
+        kinv = engine.inverse_intrinsics(synth.KITTI_K)
+        conf = torch.rand(m, device=cuda_device)
+        out_p, xyz_p, raw_p = [t.clone() for t in eng.forward_mono(kps, kinv, box_conf=conf, want_raw=True)]
+        eng.set_option('mid_heads', 1)
+        assert eng.plan_for_rows(m).endswith("end=tail_mono")
+        out_f_, xyz_f, raw_f = eng.forward_mono(kps, kinv, box_conf=conf, want_raw=True)
+        assert (raw_f - raw_p).abs().max().item() <= 2e-6 * max(1.0, raw_p.abs().max().item())
+        assert (xyz_f - xyz_p).abs().max().item() <= 2e-5
+        assert (out_f_.nan_to_num() - out_p.nan_to_num()).abs().max().item() <= 1e-4
+    eng.close()

@@ -299,10 +299,15 @@ def test_route_plan_per_row_count(hip_lib):
         # a single image: small tiles, both heads + post-process in the last launch
         assert plan(16) == "route=small16; " + "; ".join("L%d small16" % i for i in range(8)) + "; end=heads_small+post"
         assert plan(128).endswith("end=heads_small+post") and "small32" in plan(129) and plan(129).endswith("L6 small32 heads1; L7 small32 heads8; end=heads")
-        # the mid window: dense_mid_kernel, from 4097 rows the half-size w4 tile for the long-K layers; the pair kernel ends the call
-        assert plan(2048).startswith("route=mid64; L0 mid64; L1 mid64") and plan(2048).endswith("end=heads_pair+post")
-        assert plan(4096).startswith("route=mid128; L0 mid128; L1 mid128")
-        assert plan(8192) == "route=half; L0 mid128; " + "; ".join("L%d half" % i for i in range(1, 8)) + "; end=heads_pair+post"
+        # the mid window: dense_mid_kernel, from 4097 rows the half-size w4 tile for the long-K layers; round 5: both heads in the epilogues
+        assert plan(2048) == "route=mid64; " + "; ".join("L%d mid64" % i for i in range(6)) + "; L6 mid64+aux; L7 mid64+fin8; end=tail_mono"
+        assert plan(4096).startswith("route=mid128; L0 mid128; L1 mid128") and plan(4096).endswith("L6 mid128+aux; L7 mid128+fin8; end=tail_mono")
+        assert plan(8192) == "route=half; L0 mid128; " + "; ".join("L%d half" % i for i in range(1, 6)) + "; L6 half+aux; L7 half+fin8; end=tail_mono"
+        assert plan(8192, post=0).endswith("end=reduce")
+        _lib.check(hip_lib.ml_loco_set_option(h, b"mid_heads", 0))          # rounds 3-4: the pair kernel behind the last layer
+        assert plan(2048).endswith("L6 mid64; L7 mid64; end=heads_pair+post") and plan(8192).endswith("L7 half; end=heads_pair+post")
+        _lib.check(hip_lib.ml_loco_set_option(h, b"mid_heads", 1))
+        assert hip_lib.ml_loco_set_option(h, b"no_such_option", 1) == 1
         # a stochastic pass: no head fusion, masks behind layer 0 and in front of w_fin (reference net.py:141)
         assert plan(65536, mc=1, post=0) == "route=tile; L0 pp+dropout; L1 w4; L2 w4; L3 w4; L4 w4; L5 w4; L6 w4 heads1; L7 w4+dropout heads8; end=heads"
         assert hip_lib.ml_loco_route(h, 8192) == 4 and hip_lib.ml_loco_route(h, 8193) == 5

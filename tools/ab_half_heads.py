@@ -1,5 +1,5 @@
-"""Round 5 A/B inside one process: the upper mid window (4097 .. 8192 rows) with both heads riding in the half-size w4 tile's epilogues +
-tail_mono_kernel (half_heads 1, the default) against heads_pair_kernel behind the last layer (half_heads 0, rounds 3-4); alternating
+"""Round 5 A/B inside one process: the mid window (513 .. 8192 rows) with both heads riding in the dense epilogues (dense_mid_kernel's /
+the half-size w4 tile's) + tail_mono_kernel (mid_heads 1, the default) against heads_pair_kernel behind the last layer (mid_heads 0, rounds 3-4); alternating
 blocks on one engine, the two routes' outputs compared.  Optional arguments: row counts."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,14 +10,14 @@ dev = torch.device('cuda', 0)
 sd = synth.make_state_dict(1, 34, 9, 1024)
 eng = engine.LocoEngine({k: torch.tensor(v) for k, v in sd.items()}, device=dev, reserve_rows=16384)
 kinv = engine.inverse_intrinsics(synth.KITTI_K)
-for m in [int(a) for a in (sys.argv[1:] or ['5120', '6144', '8192'])]:
+for m in [int(a) for a in (sys.argv[1:] or ['1024', '2048', '3072', '4096', '6144', '8192'])]:
     kps = torch.tensor(synth.make_poses(m, seed=1)).to(dev)
     conf = torch.rand(m, device=dev)
     outs = {}
     res = {0: [], 1: []}
     for rep in range(3):
         for hh in (0, 1):
-            eng.set_option('half_heads', hh)
+            eng.set_option('mid_heads', hh)
             out = torch.empty((m, 16), device=dev); xyzds = torch.empty((m, 5), device=dev); raw = torch.empty((m, 9), device=dev)
             for _ in range(200):
                 eng.forward_mono(kps, kinv, box_conf=conf, out=out, xyzds=xyzds)
