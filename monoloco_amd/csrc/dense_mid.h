@@ -43,8 +43,12 @@ struct MidCfg {
     static constexpr int LDS = 2 * STAGE;
 };
 
-template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0>
+// NSET (round 5): register sets of the loader = k-steps a request is ahead of its LDS store.  2 (rounds 3-4) is enough when two or
+// three workgroups share a CU; with ONE 128 x 64 tile per CU (<= 2048 rows at N = 1024) a step is ~0.5 us and two steps do not cover an
+// L2 miss into the Infinity Cache (the weight matrix is the whole of an XCD's L2): NSET = 3 requests three steps ahead.
+template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0, int NSET = 2>
 __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p) {
+    static_assert(NSET == 2 || NSET == 3, "two or three loader register sets");
     typedef MidCfg<TM> C;
     constexpr int NB = C::NB, XL = C::XL;
     constexpr bool AUX = HEAD == -1;
@@ -141,22 +145,24 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
             }
     };
 
-    Raw R0, R1;
+    Raw R0, R1, R2;
     gload(R0, 0);
     gload(R1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XL) : "memory");
+    if (NSET == 3) gload(R2, 2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSET - 1) * (4 + XL)) : "memory");
     lstore(R0, 0);
-    gload(R0, 2);
+    gload(R0, NSET);
     __syncthreads();
 
-    // step i: LDS stage i&1 holds k-step i; the set named `nxt` holds step i+1 (requested two steps ago), the other set
-    // step i+2 (requested one step ago, stays in flight across the wait).  Schedules measured against this one (us per forward
+    // step i: LDS stage i&1 holds k-step i; the set named `nxt` holds step i+1 (requested NSET steps ago), the other set(s)
+    // step i+2 (.. i+NSET; requested later, stay in flight across the wait).  Schedules measured against this one (us per forward
     // at 4096 / 8192 rows, 128-row tiles; this one: 256-259 / 403-406):
     //   * the barrier in the middle of the step's MFMAs, the next step's first fragments requested right behind it: 271 / 422;
     //   * the loader without a branch (the `if (i + 1 < nk)` below makes hipcc's own waitcnt insertion drain ALL requests,
     //     vmcnt(0), before every second LDS store; branch-free it waits for exactly the set it stores, vmcnt(8)): 256 / 428 --
     //     no gain with one workgroup per CU, a loss with two;
-    //   * three register sets (requests three steps ahead), loader unconditional, MFMAs of padded steps skipped: 267 / 425.
+    //   * three register sets (requests three steps ahead), loader unconditional, MFMAs of padded steps skipped: 267 / 425 at those
+    //     row counts (two workgroups per CU hide the latency already) -- kept as NSET = 3 for the 64-row tile with one workgroup per CU.
     // With two workgroups per CU the kernel is bound by the LDS pipe both of them feed through (reads + writes = the 768 MFMA
     // cycles of a step at 128 B/clk; profiles/r03_mid_pmc_rows8192.txt: matrix pipe 39-44 % busy, 16 % of the wave cycles waiting on
     // LDS, 3.5 % bank conflicts), not by request latency.
@@ -167,16 +173,27 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
         fread(f1, s, 1);
         mma_rows(f0, 0);
         mma_rows(f0, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XL) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSET - 1) * (4 + XL)) : "memory");
         if (i + 1 < nk) lstore(nxt, s ^ 1);
-        gload(nxt, i + 3);
+        gload(nxt, i + 1 + NSET);
         mma_rows(f1, 0);
         mma_rows(f1, 1);
         __syncthreads();
     };
-    for (int i = 0; i < nk; i += 2) {
-        step(R1, i);
-        if (i + 1 < nk) step(R0, i + 1);
+    if (NSET == 2) {
+        for (int i = 0; i < nk; i += 2) {
+            step(R1, i);
+            if (i + 1 < nk) step(R0, i + 1);
+        }
+    } else {   // the sets rotate with period 3, the stages with period 2
+        for (int i = 0; i < nk; i += 6) {
+            step(R1, i);
+            if (i + 1 < nk) step(R2, i + 1);
+            if (i + 2 < nk) step(R0, i + 2);
+            if (i + 3 < nk) step(R1, i + 3);
+            if (i + 4 < nk) step(R2, i + 4);
+            if (i + 5 < nk) step(R0, i + 5);
+        }
     }
 
     // ---- epilogue: the stage buffers are free behind the last barrier; wave w takes 4 KiB of them as its scratch

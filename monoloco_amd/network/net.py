@@ -10,6 +10,7 @@ import ctypes
 import logging
 from collections import defaultdict
 from itertools import chain as _chain_cls
+from operator import itemgetter as _itemgetter
 
 _chain = _chain_cls.from_iterable
 
@@ -359,7 +360,13 @@ class Loco:
             epi = dic_in['epi']
             epi_l = _f64_list(epi) if isinstance(epi, torch.Tensor) else [float(e) for e in epi]
             identity = all_idxs == list(range(len(all_idxs)))   # no ground truth: input order
-            pick = (lambda col: col[:len(all_idxs)]) if identity else (lambda col: [col[i] for i in all_idxs])
+            if identity:
+                pick = lambda col: col[:len(all_idxs)]
+            elif len(all_idxs) > 1:   # matched first: one C-level gather per column (operator.itemgetter), no Python loop
+                gather = _itemgetter(*all_idxs)
+                pick = lambda col: list(gather(col))
+            else:
+                pick = lambda col: [col[i] for i in all_idxs]
             columns = [
                 ('boxes', pick(list(boxes))),
                 ('confs', [0.035 * (boxes[i][-1]) / (bi_l[i] / dist_l[i]) for i in all_idxs]),

@@ -4,7 +4,7 @@
 TAG=${1:-run}; shift; EXTRA="$@"
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O; W=/tmp/prof_$TAG; mkdir -p $W
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --no-extra $EXTRA"
+B="python $R/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --no-extra --no-live-counters --no-parity $EXTRA"
 timeout 300 rocprofv3 --kernel-trace --stats -d $W/stats -o stats -- $B > $O/stats.log 2>&1
 python $R/tools/rocprof_summary.py $(find $W/stats -name "*.db" | head -1) > $O/kernel_stats.txt 2>&1
 pmc() { n=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $W/pmc_$n -o pmc -- $B --no-profile > $O/pmc_$n.log 2>&1; }
