@@ -43,12 +43,8 @@ struct MidCfg {
     static constexpr int LDS = 2 * STAGE;
 };
 
-// NSET (round 5): register sets of the loader = k-steps a request is ahead of its LDS store.  2 (rounds 3-4) is enough when two or
-// three workgroups share a CU; with ONE 128 x 64 tile per CU (<= 2048 rows at N = 1024) a step is ~0.5 us and two steps do not cover an
-// L2 miss into the Infinity Cache (the weight matrix is the whole of an XCD's L2): NSET = 3 requests three steps ahead.
-template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0, int NSET = 2>
+template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0>
 __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p) {
-    static_assert(NSET == 2 || NSET == 3, "two or three loader register sets");
     typedef MidCfg<TM> C;
     constexpr int NB = C::NB, XL = C::XL;
     constexpr bool AUX = HEAD == -1;
@@ -145,24 +141,28 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
             }
     };
 
-    Raw R0, R1, R2;
+    Raw R0, R1;
     gload(R0, 0);
     gload(R1, 1);
-    if (NSET == 3) gload(R2, 2);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSET - 1) * (4 + XL)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XL) : "memory");
     lstore(R0, 0);
-    gload(R0, NSET);
+    gload(R0, 2);
     __syncthreads();
 
-    // step i: LDS stage i&1 holds k-step i; the set named `nxt` holds step i+1 (requested NSET steps ago), the other set(s)
-    // step i+2 (.. i+NSET; requested later, stay in flight across the wait).  Schedules measured against this one (us per forward
+    // step i: LDS stage i&1 holds k-step i; the set named `nxt` holds step i+1 (requested two steps ago), the other set
+    // step i+2 (requested one step ago, stays in flight across the wait).  Schedules measured against this one (us per forward
     // at 4096 / 8192 rows, 128-row tiles; this one: 256-259 / 403-406):
     //   * the barrier in the middle of the step's MFMAs, the next step's first fragments requested right behind it: 271 / 422;
     //   * the loader without a branch (the `if (i + 1 < nk)` below makes hipcc's own waitcnt insertion drain ALL requests,
     //     vmcnt(0), before every second LDS store; branch-free it waits for exactly the set it stores, vmcnt(8)): 256 / 428 --
     //     no gain with one workgroup per CU, a loss with two;
-    //   * three register sets (requests three steps ahead), loader unconditional, MFMAs of padded steps skipped: 267 / 425 at those
-    //     row counts (two workgroups per CU hide the latency already) -- kept as NSET = 3 for the 64-row tile with one workgroup per CU.
+    //   * three register sets (requests three steps ahead), loader unconditional, MFMAs of padded steps skipped: 267 / 425;
+    //   * round 5, for ONE 128 x 64 tile per CU (<= 2048 rows): three register sets behind two stages (148 vs 150 us per forward at
+    //     1024 rows, 160 vs 161 at 2048: -1 %), and three LDS stages + three sets with the next step's first fragments read behind
+    //     this step's first MFMAs, branch-free groups of six steps so that hipcc's waits stay counted (vmcnt(12) in front of every
+    //     store, checked in the ISA): 150.7 vs 150.0 at 1024 rows, 158 vs 156 at 2048 -- neither the request latency nor the
+    //     fragment round trip is what a step waits for; the step is LDS-pipe time (12 reads + 6 writes of 1 KiB per wave and step)
+    //     plus a barrier.  Both removed again (profiles/r05_ablation.md section 5).
     // With two workgroups per CU the kernel is bound by the LDS pipe both of them feed through (reads + writes = the 768 MFMA
     // cycles of a step at 128 B/clk; profiles/r03_mid_pmc_rows8192.txt: matrix pipe 39-44 % busy, 16 % of the wave cycles waiting on
     // LDS, 3.5 % bank conflicts), not by request latency.
@@ -173,27 +173,16 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
         fread(f1, s, 1);
         mma_rows(f0, 0);
         mma_rows(f0, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSET - 1) * (4 + XL)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XL) : "memory");
         if (i + 1 < nk) lstore(nxt, s ^ 1);
-        gload(nxt, i + 1 + NSET);
+        gload(nxt, i + 3);
         mma_rows(f1, 0);
         mma_rows(f1, 1);
         __syncthreads();
     };
-    if (NSET == 2) {
-        for (int i = 0; i < nk; i += 2) {
-            step(R1, i);
-            if (i + 1 < nk) step(R0, i + 1);
-        }
-    } else {   // the sets rotate with period 3, the stages with period 2
-        for (int i = 0; i < nk; i += 6) {
-            step(R1, i);
-            if (i + 1 < nk) step(R2, i + 1);
-            if (i + 2 < nk) step(R0, i + 2);
-            if (i + 3 < nk) step(R1, i + 3);
-            if (i + 4 < nk) step(R2, i + 4);
-            if (i + 5 < nk) step(R0, i + 5);
-        }
+    for (int i = 0; i < nk; i += 2) {
+        step(R1, i);
+        if (i + 1 < nk) step(R0, i + 1);
     }
 
     // ---- epilogue: the stage buffers are free behind the last barrier; wave w takes 4 KiB of them as its scratch

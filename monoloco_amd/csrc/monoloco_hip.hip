@@ -160,7 +160,6 @@ struct Tuning {
     int tile_kernel = 4, tile_all = 0;
     int mid_rows = 8192, mid_tile = 0;
     int half_from = 4096;   // mid window, rows above this: the long-K layers on dense_kernel_w4's half-size tile (mid_tile 256 forces it)
-    int mid_sets = 0;       // dense_mid_kernel's loader register sets for the 64-row tile: 0 = 3 while the tiles are at most one per CU, else 2; 2 | 3 force
     int half_heads = 1;     // the whole mid window: both heads ride in the dense epilogues (half-size w4 tile / dense_mid_kernel) + tail_mono_kernel
                             // (option "mid_heads"; 0: heads_pair_kernel behind the last layer, rounds 3-4)
 };
@@ -480,13 +479,9 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
         const int tm = (tu.mid_tile == 64 || tu.mid_tile == 128) ? tu.mid_tile : (tiles128 >= num_cus() ? 128 : 64);   // (measured: 4096 rows 256 vs 266 us)
         const int tiles = (p.M_pad / tm) * (p.N / mlk::MID_TN);
         const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
-        // one 64-row tile per CU at most (and a k-loop long enough to matter): requests three k-steps ahead (dense_mid.h NSET)
-        const bool sets3 = tm == 64 && p.K >= 256 && (tu.mid_sets == 3 || (tu.mid_sets == 0 && tiles <= num_cus()));
 #define ML_MID(NS, RL, RS, HD)                                                                                                  \
     do {                                                                                                                        \
         if (tm == 128) hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, 128, HD>), grid, dim3(mlk::MID_THREADS), 0, st, p); \
-        else if (NS == 3 && sets3)                                                                                              \
-            hipLaunchKernelGGL((mlk::dense_mid_kernel<(NS == 3 ? 3 : 1), RL, RS, 64, HD, (NS == 3 ? 3 : 2)>), grid, dim3(mlk::MID_THREADS), 0, st, p); \
         else hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, 64, HD>), grid, dim3(mlk::MID_THREADS), 0, st, p);           \
     } while (0)
 #define ML_MID_NS(NS)                                     \
@@ -1655,7 +1650,6 @@ int ml_loco_set_option(ml_loco* h, const char* name, int value) {
     const std::string n(name);
     if (n == "mid_heads" || n == "half_heads") h->tune.half_heads = value ? 1 : 0;
     else if (n == "half_from") h->tune.half_from = value;
-    else if (n == "mid_sets" && (value == 0 || value == 2 || value == 3)) h->tune.mid_sets = value;
     else return fail(ML_ERR_ARG, "unknown option '%s'", name);
     return ML_OK;
 }
