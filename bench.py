@@ -119,13 +119,14 @@ def cpu_baseline(sd, kps_np, kk, budget_s):
     # the port against the REAL reference on the build container's CPU (tools/cpu_port_vs_reference.py: same threads, same batch,
     # outputs bit-identical): a committed calibration -- the reference itself does not exist on the GPU box
     pvr, pvr_src = None, None
-    for name in ('r04_port_vs_reference.json',):
+    for name in ('r05_port_vs_reference.json', 'r04_port_vs_reference.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             rec = json.load(open(path))
             pvr, pvr_src = rec.get("port_vs_reference"), "replayed:profiles/%s (%s, %s host cores; per thread count: %s)" % (
                 name, rec.get("cpu_model"), rec.get("host_cores"),
                 {k: v.get("port_vs_reference") for k, v in rec.get("by_threads", {}).items()})
+            break
     return {"value": round(results[best_t], 1), "unit": "persons/s", "cores": best_t, "kind": "port",
             "port_vs_reference": pvr, "port_vs_reference_source": pvr_src,
             "reference_estimate": round(results[best_t] / pvr, 1) if pvr else None,

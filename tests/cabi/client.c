@@ -128,6 +128,41 @@ int main(int argc, char** argv) {
                                              kernel family: same operands, another fp32 summation order -- a few ulps at 20-60 m) */
         hipHostFree(p_kps); hipHostFree(p_out); hipFree(d_stage); hipFree(d_buf);
     }
+    /* ground-truth association of post_process through the ABI (reference utils/iou.py:44-100): 4 detections x 3 ground-truth boxes,
+     * the host entry and the device kernel + host greedy pass must give the pairs a reading of the reference gives: box 3 (highest
+     * confidence) takes gt 0, box 0's best gt is then owned, box 1 takes gt 1; left to right: (3,0) comes after ... x1 = 1 > 0? --
+     * box 1 starts at x = 20, box 3 at x = 1: order (3,0), (1,1) */
+    {
+        const double boxes[4 * 5] = {0, 0, 10, 10, 0.9, 20, 0, 30, 10, 0.5, 100, 100, 120, 130, 0.7, 1, 1, 11, 11, 0.95};
+        const double gts[3 * 4] = {0, 0, 10, 10, 21, 0, 31, 10, 300, 300, 310, 310};
+        const int64_t by_conf[4] = {3, 0, 2, 1};     /* reversed(np.argsort(conf)) */
+        const int64_t by_left[4] = {0, 3, 1, 2};     /* np.argsort(x1) */
+        int64_t pairs[8], n_pairs = 0;
+        int32_t zero_div = 0;
+        ML(ml_iou_matches_host(boxes, 4, 5, gts, 3, 4, by_conf, 0.3, by_left, pairs, &n_pairs, &zero_div));
+        if (n_pairs != 2 || pairs[0] != 3 || pairs[1] != 0 || pairs[2] != 1 || pairs[3] != 1 || zero_div) DIE("host matching");
+        double *d_b, *d_g, *d_v, vmax[4];
+        int32_t *d_j, *d_z, jmax[4];
+        HIP(hipMalloc((void**)&d_b, sizeof(boxes)));
+        HIP(hipMalloc((void**)&d_g, sizeof(gts)));
+        HIP(hipMalloc((void**)&d_v, 4 * 8));
+        HIP(hipMalloc((void**)&d_j, 4 * 4));
+        HIP(hipMalloc((void**)&d_z, 4));
+        HIP(hipMemcpy(d_b, boxes, sizeof(boxes), hipMemcpyHostToDevice));
+        HIP(hipMemcpy(d_g, gts, sizeof(gts), hipMemcpyHostToDevice));
+        HIP(hipMemset(d_z, 0, 4));
+        ML(ml_iou_best(d_b, 4, 5, d_g, 3, 4, d_j, d_v, d_z, (void*)st));
+        HIP(hipStreamSynchronize(st));
+        HIP(hipMemcpy(jmax, d_j, 16, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(vmax, d_v, 32, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(&zero_div, d_z, 4, hipMemcpyDeviceToHost));
+        int64_t pairs_d[8], n_d = 0;
+        ML(ml_iou_greedy(by_conf, 4, jmax, vmax, 4, 3, 0.3, NULL, pairs_d, &n_d));   /* visiting order: (3,0), (1,1) */
+        if (zero_div || n_d != 2 || pairs_d[0] != 3 || pairs_d[1] != 0 || pairs_d[2] != 1 || pairs_d[3] != 1 || vmax[0] != 1.0)
+            DIE("device matching");
+        printf("c-abi client: ground-truth matching, host and device entries agree (2 pairs)\n");
+        hipFree(d_b); hipFree(d_g); hipFree(d_v); hipFree(d_j); hipFree(d_z);
+    }
     /* error behaviour: a hot call with a bad argument reports, it does not crash */
     if (ml_loco_forward_mono(h, NULL, m, kinv, NULL, NULL, d_out, d_xyzds, (void*)st) == ML_OK) DIE("null input accepted");
     ML(ml_loco_destroy(h));

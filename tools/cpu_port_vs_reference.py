@@ -4,7 +4,7 @@ GPU box, where the reference does not exist) against the REAL reference on the s
 Reference leg (SURVEY 8d "CPU baseline"): preprocess_monoloco -> LocoModel (eval, no_grad) -> extract_outputs on tensors
 (list marshalling skipped) -> the post_process geometry as tensors (get_keypoints, pixel_to_camera, xyz_from_distance).
 Oracle leg: oracle/monoloco_oracle.forward_mono.  3 warm-ups + 7 repetitions, median, per thread count.
-Writes profiles/r04_port_vs_reference.json; bench.py replays its ratio as cpu_baseline.port_vs_reference."""
+Writes profiles/r05_port_vs_reference.json; bench.py replays its ratio as cpu_baseline.port_vs_reference."""
 import json
 import os
 import statistics
@@ -79,7 +79,7 @@ def main():
            "port_vs_reference": round(statistics.median(ratios), 4),
            "note": "ratio < 1: the port is a little slower than the reference on this CPU (same arithmetic, bit-identical outputs; it builds a few more "
                    "intermediate tensors); reference persons/s on the GPU box = cpu_baseline.value / ratio"}
-    path = os.path.join(ROOT, 'profiles', 'r04_port_vs_reference.json')
+    path = os.path.join(ROOT, 'profiles', 'r05_port_vs_reference.json')
     json.dump(out, open(path, 'w'), indent=1)
     print("wrote", path, "ratio", out["port_vs_reference"])
 
