@@ -258,7 +258,7 @@ def test_bf16_comparison_mode(hip_lib, cuda_device, wb, gold):
 def test_reference_trained_weights_at_the_full_batch(hip_lib, cuda_device, gold, mode):
     """BASELINE configs[1] / [2] at their full sizes (65536 persons; 256 x 128 = 32768 pair rows) on the REFERENCE-TRAINED 1024-wide
     checkpoints (round-3 review, weak 1c: they had only met 500 / 556 rows): SURVEY 8d's parity set P -- the fixture's real poses tiled
-    to the batch with a per-row jitter (u, v += N(0, 0.5 px)) -- against the CPU oracle on a strided 512-row sample at the north-star
+    to the batch with a per-row jitter (u, v += N(0, 0.5 px)) -- against the CPU oracle on EVERY row (round 5) at the north-star
     tolerance, plus the size-independent property that every row equals the same row computed in a small batch of its own (another
     kernel family: small-row / mid-size path)."""
     from monoloco_amd import engine
@@ -275,12 +275,16 @@ def test_reference_trained_weights_at_the_full_batch(hip_lib, cuda_device, gold,
         kt = torch.tensor(kps).to(cuda_device)
         conf = torch.tensor(rng.random(m).astype(np.float32)).to(cuda_device)
         out, xyzds, raw = eng.forward_mono(kt, kinv, box_conf=conf, want_raw=True)
+        # round 5: EVERY row of the batch against the oracle (8192-row chunks, a few seconds), not a strided sample
+        raw_h, xyzds_h, conf_h = raw.cpu(), xyzds.cpu(), conf.cpu()
+        d_lo, d_hi = 1e9, 0.0
+        for lo in range(0, m, 8192):
+            ref = O.forward_mono(sd, torch.tensor(kps[lo:lo + 8192]), synth.KITTI_K, box_conf=conf_h[lo:lo + 8192])
+            assert (raw_h[lo:lo + 8192] - ref['raw']).abs().max().item() <= TOL, lo
+            assert (xyzds_h[lo:lo + 8192] - ref['xyzds']).abs().max().item() <= TOL, lo
+            d_lo, d_hi = min(d_lo, ref['raw'][:, 2].min().item()), max(d_hi, ref['raw'][:, 2].max().item())
+        assert d_lo > 0.3 and d_hi > 15.0                             # a trained net on real poses: metres, not noise
         idx = np.arange(0, m, m // 512)[:512]
-        ref = O.forward_mono(sd, torch.tensor(kps[idx]), synth.KITTI_K, box_conf=conf[idx].cpu())
-        assert (raw[idx].cpu() - ref['raw']).abs().max().item() <= TOL
-        assert (xyzds[idx].cpu() - ref['xyzds']).abs().max().item() <= TOL
-        d = ref['raw'][:, 2]
-        assert d.min() > 0.3 and d.max() > 15.0                       # a trained net on real poses: metres, not noise
         sub = idx[:300]
         out_s, xyzds_s, raw_s = eng.forward_mono(kt[sub], kinv, box_conf=conf[sub], want_raw=True)    # 300 rows: the small-row kernels
         assert (raw_s - raw[sub]).abs().max().item() <= 4e-6 * max(1.0, raw.abs().max().item())
@@ -294,9 +298,8 @@ def test_reference_trained_weights_at_the_full_batch(hip_lib, cuda_device, gold,
         raw_all = res['raw_all'].cpu()
         assert raw_all.shape == (ml * mr, 10)
         x, _ = O.preprocess_monstereo(torch.tensor(kl), torch.tensor(kr), synth.KITTI_K)
-        idx = np.arange(0, ml * mr, (ml * mr) // 512)[:512]
-        ref = O.loco_forward(sd, x[idx])
-        assert (raw_all[idx] - ref).abs().max().item() <= TOL
+        for lo in range(0, ml * mr, 8192):      # every pair row
+            assert (raw_all[lo:lo + 8192] - O.loco_forward(sd, x[lo:lo + 8192])).abs().max().item() <= TOL, lo
         # the per-left winner is the arg-max of the device's own aux logits
         best = res['best'].cpu().long()
         assert torch.equal(best, raw_all.view(ml, mr, 10)[:, :, -1].argmax(1))

@@ -104,3 +104,28 @@ def test_host_matching_cost(hip_lib, host_only):
         t0 = time.perf_counter()
         I.get_iou_matches_ordered(boxes, gt)
         assert time.perf_counter() - t0 < bound
+
+
+def test_matching_property_random_boxes_with_many_ties(hip_lib, host_only):
+    """Hypothesis: boxes on a coarse integer grid (IoU ties and 0 / 1 values galore), confidences from a 4-value set (argsort ties),
+    any iou_min -- the native pass equals the oracle's loops (same np.argsort calls, so the same tie order on this machine)."""
+    from hypothesis import given, settings, strategies as st
+
+    coord = st.integers(0, 12)
+
+    @st.composite
+    def box(draw, with_conf):
+        x1, y1 = draw(coord), draw(coord)
+        w, h = draw(st.integers(1, 6)), draw(st.integers(1, 6))
+        b = [float(x1), float(y1), float(x1 + w), float(y1 + h)]
+        return b + [draw(st.sampled_from([0.2, 0.5, 0.5, 0.9]))] if with_conf else b
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.lists(box(True), min_size=1, max_size=24), st.lists(box(False), min_size=1, max_size=24),
+           st.sampled_from([0.0, 0.25, 0.3, 0.5, 1.0]))
+    def check(boxes, gt, iou_min):
+        want = O.get_iou_matches(boxes, gt, iou_min)
+        assert I.get_iou_matches(boxes, gt, iou_min) == want
+        assert I.get_iou_matches_ordered(boxes, gt, iou_min) == O.reorder_matches(want, boxes)
+        assert np.array_equal(I.get_iou_matrix(boxes, gt), O.get_iou_matrix(boxes, gt))
+    check()
