@@ -167,6 +167,9 @@ def live_counters(args, budget_s=150.0):
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(exe):
         return {"source": "rocprofv3 unavailable: not on PATH, not under /opt/rocm/bin"}
+    if os.environ.get('ROCP_TOOL_LIBRARIES') or 'rocprofiler' in os.environ.get('LD_PRELOAD', ''):
+        # (this process is itself being profiled: a profiler inside a profiler would fight over the counters)
+        return {"source": "rocprofv3 unavailable: this run is already under a profiler (ROCP_TOOL_LIBRARIES / LD_PRELOAD)"}
     t_start = time.perf_counter()
     work = tempfile.mkdtemp(prefix='ml_live_', dir='/tmp')
     child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-extra', '--cpu-seconds', '0',

@@ -19,8 +19,6 @@ from .. import _lib
 # and a read-back cost more than the host loop: 256 IoUs of a 16 x 16 frame take ~1 us)
 DEVICE_MIN_PAIRS = 1 << 15
 
-_I32 = ctypes.POINTER(ctypes.c_int32)
-
 
 def _check(code):
     if code != 0:
