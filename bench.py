@@ -145,7 +145,7 @@ def traffic_from_profiles(args):
     committed measurement does not cover this configuration."""
     if args.workload != 'mono' or args.precision != 'f16x2' or args.batch != 65536 or args.no_merge or args.total_rows:
         return None
-    for name in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
+    for name in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             return json.load(open(path)), "replayed:profiles/" + name
