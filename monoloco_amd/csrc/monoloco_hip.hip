@@ -190,6 +190,8 @@ struct ml_loco {
     float* d_part = nullptr;    // fused-head partial sums [2*hidden/256][cap_rows][16] ...
     float* d_part_aux = nullptr;  // ... and, behind them, the fused w_aux head's [2*hidden/256][cap_rows] (same allocation)
     int part_slices = 0;        // slices per head d_part / d_part_aux hold
+    int tune_version = 0;       // bumped by ml_loco_set_tuning / ml_loco_set_option: cached route plans of older versions are stale
+    struct PlanCache* plans = nullptr;   // the route plans of the last few (rows, MC-dropout) calls (plan_for; freed in ml_loco_destroy)
     double* d_mc = nullptr;     // MC-dropout: running (sum, sum of squares) per person + per-(pass, person) partials: 4 doubles per row
     int64_t cap_side = 0;
     int64_t dev_bytes = 0;
@@ -846,12 +848,45 @@ std::string plan_text(const ml_loco* h, const RoutePlan& pl, bool with_tail) {
     return s;
 }
 
+}  // namespace
+
+// Plans are built once per (rows, MC-dropout, tuning version, workspace) and kept: a stream of calls with recurring row counts
+// (a video: a few distinct person counts; a batch job: one) walks a stored plan and builds nothing.
+struct PlanCache {
+    struct Entry {
+        int64_t rows, cap_rows;
+        int mc_on, version, part_slices;
+        RoutePlan plan;
+    };
+    std::vector<Entry> entries;
+    size_t next = 0;   // FIFO replacement once 16 plans are stored
+};
+
+namespace {
+
+const RoutePlan& plan_for(ml_loco* h, int64_t rows, bool mc_on) {
+    if (!h->plans) h->plans = new PlanCache();
+    for (const PlanCache::Entry& e : h->plans->entries)
+        if (e.rows == rows && e.mc_on == (int)mc_on && e.version == h->tune_version && e.cap_rows == h->cap_rows &&
+            e.part_slices == h->part_slices)
+            return e.plan;
+    PlanCache::Entry e{rows, h->cap_rows, (int)mc_on, h->tune_version, h->part_slices, make_plan(h, rows, mc_on)};
+    if (h->plans->entries.size() < 16) {
+        h->plans->entries.push_back(std::move(e));
+        return h->plans->entries.back().plan;
+    }
+    PlanCache::Entry& slot = h->plans->entries[h->plans->next];
+    h->plans->next = (h->plans->next + 1) % 16;
+    slot = std::move(e);
+    return slot.plan;
+}
+
 int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass mc = McPass(), TailMono* tail = nullptr) {
     const int64_t m_pad_all = round_up64(rows, 256);
     // (row chunking is an inference experiment knob; the batched MC-dropout passes index their masks by global row)
     const int64_t chunk_rows = h->tune.chunk_rows / 256 * 256;
     const int64_t chunk = (chunk_rows > 0 && mc.p <= 0.f) ? chunk_rows : m_pad_all;
-    const RoutePlan pl = make_plan(h, rows, mc.p > 0.f);
+    const RoutePlan& pl = plan_for(h, rows, mc.p > 0.f);
     const bool defer = tail && chunk == m_pad_all;   // head reductions wait for the end of the (single) chunk
     const Head *def_fin = nullptr, *def_aux = nullptr;
     const int nparts = pl.nparts;
@@ -1236,6 +1271,7 @@ int ml_loco_destroy(ml_loco* h) {
         dev_free(hd.d_w);
         dev_free(hd.d_b);
     }
+    delete h->plans;
     delete h;
     return ML_OK;
 }
@@ -1641,6 +1677,7 @@ int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_r
     if (chunk_rows >= 0) h->tune.chunk_rows = chunk_rows;
     if (mid_rows >= 0) h->tune.mid_rows = mid_rows;
     if (mid_tile >= 0) h->tune.mid_tile = mid_tile;
+    ++h->tune_version;
     return ML_OK;
 }
 
@@ -1651,6 +1688,7 @@ int ml_loco_set_option(ml_loco* h, const char* name, int value) {
     if (n == "mid_heads" || n == "half_heads") h->tune.half_heads = value ? 1 : 0;
     else if (n == "half_from") h->tune.half_from = value;
     else return fail(ML_ERR_ARG, "unknown option '%s'", name);
+    ++h->tune_version;
     return ML_OK;
 }
 
