@@ -27,7 +27,14 @@ def _require_cuda(device):
     return dev
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream(dev):
+    """The raw hipStream_t of torch's current stream on dev.  torch._C._cuda_getCurrentRawStream (what torch's own compiled-code
+    launchers call) answers in ~0.3 us; torch.cuda.current_stream(dev).cuda_stream builds a Stream object first (~5 us per frame)."""
+    if _RAW_STREAM is not None and dev.index is not None:
+        return ctypes.c_void_p(_RAW_STREAM(dev.index))
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 

@@ -268,9 +268,13 @@ class Loco:
             else:
                 assert kps.shape[1:] == (3, 17), "keypoints must be (m, 3, 17)"
                 np.copyto(st['np_in'], kps)
-            with torch.cuda.device(dev):
+            if torch.cuda.current_device() == dev.index:   # (the usual case: no device switch, no context manager around the call)
                 engine.check(lib.ml_loco_frame_mono(self.engine._h, st['p_pin_in'], m, kinv_p, st['p_in'], st['p_out'], st['p_xyzds'],
                                                     st['p_pin_out'], stream))
+            else:
+                with torch.cuda.device(dev):
+                    engine.check(lib.ml_loco_frame_mono(self.engine._h, st['p_pin_in'], m, kinv_p, st['p_in'], st['p_out'],
+                                                        st['p_xyzds'], st['p_pin_out'], stream))
         # the reference's dictionary (process.py:240-278) out of ONE fresh buffer: 7 single columns (h w l bi yaw yaw_ego d), then
         # ori (m,2), xyzd (m,4) and the (m,12) geometry block -- one gather of the pinned result through an index vector cached per
         # person count, one torch.from_numpy, every output a view of its own range
