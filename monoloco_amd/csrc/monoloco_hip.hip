@@ -190,6 +190,8 @@ struct ml_loco {
     float* d_part = nullptr;    // fused-head partial sums [2*hidden/256][cap_rows][16] ...
     float* d_part_aux = nullptr;  // ... and, behind them, the fused w_aux head's [2*hidden/256][cap_rows] (same allocation)
     int part_slices = 0;        // slices per head d_part / d_part_aux hold
+    const void* pinned_seen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ml_loco_frame_mono: host pointers verified to be pinned
+    int pinned_next = 0;
     int tune_version = 0;       // bumped by ml_loco_set_tuning / ml_loco_set_option: cached route plans of older versions are stale
     struct PlanCache* plans = nullptr;   // the route plans of the last few (rows, MC-dropout) calls (plan_for; freed in ml_loco_destroy)
     double* d_mc = nullptr;     // MC-dropout: running (sum, sum of squares) per person + per-(pass, person) partials: 4 doubles per row
@@ -1709,13 +1711,24 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
     int rc;
     // kernels may only dereference PINNED (device-mapped) host memory: anything else takes the staged route, where the runtime's
     // copies accept pageable memory as well (a wrong guess here would be a GPU page fault, not an error code)
-    auto pinned = [](const void* p) {
+    // (the verdict is remembered per handle for the last few pointers: a caller streams frames through the same staging buffers, and
+    //  the attribute query is a driver call per pointer and frame; pinned allocations live in their own address range, so a
+    //  remembered address does not come back as pageable memory)
+    auto pinned = [h](const void* p) {
+        if (h)
+            for (const void* q : h->pinned_seen)
+                if (q == p) return true;
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, p) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
-        return a.type == hipMemoryTypeHost;
+        if (a.type != hipMemoryTypeHost) return false;
+        if (h) {
+            h->pinned_seen[h->pinned_next] = p;
+            h->pinned_next = (h->pinned_next + 1) % 8;
+        }
+        return true;
     };
     if (m <= 128 && h && use_small_path(h->tune, h->precision, m) && pinned(kps_host) && pinned(out_host)) {
         bool geo_done = false;
