@@ -668,6 +668,16 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         t2 = time.perf_counter()
         res["loco_forward_us"] = round((t1 - t0) / n * 1e6, 1)
         res["post_process_us"] = round((t2 - t1) / n * 1e6, 1)
+        # the same frames with the host sleeping in hipStreamSynchronize instead of polling the frame's completion word (round 5)
+        from monoloco_amd import _lib as _l
+        _l.load().ml_debug_frame_spin(0)
+        for _ in range(30):
+            net.forward(kpl, kk1)
+        ts = time.perf_counter()
+        for _ in range(n):
+            net.forward(kpl, kk1)
+        res["loco_forward_us_stream_sync"] = round((time.perf_counter() - ts) / n * 1e6, 1)
+        res["frame_flag_timeouts"] = int(_l.load().ml_debug_frame_spin(1))
         # with ground truth, as GenerateKitti calls it on every image (reference eval/generate_kitti.py:114-132): IoU of all
         # detection x ground-truth pairs, greedy matching, left-to-right order and the matched xyz_real in batched calls
         dic_gt = {'boxes': [[b[0] + 3., b[1] - 2., b[2] + 1., b[3] + 4.] for b in boxes[::-1]],

@@ -395,6 +395,10 @@ int ml_debug_get_layer(const ml_loco* h, int layer, float* w_host, float* b_host
 int ml_debug_num_layers(const ml_loco* h);
 /* How many ml_loco_frame_mono calls of this process ran without any copy operation (pinned buffers, <= 128 persons). */
 long long ml_debug_frames_without_copies(void);
+/* ml_loco_frame_mono, single image in pinned buffers: the host learns of the frame's end from a word of pinned memory the last
+ * launch releases (busy-polled for at most 5 ms, then hipStreamSynchronize) instead of sleeping in the stream synchronisation.
+ * enable 0 / 1 turns that off / on for the process (< 0: unchanged); returns how many frames have timed out so far (expected 0). */
+long long ml_debug_frame_spin(int enable);
 /* Which dense kernel family a forward of `rows` network rows takes on this handle (its precision and tuning): one of the
  * ML_ROUTE_* codes below (-1: bad argument).  Reporting only (bench.py labels its per-batch-size lines with it). */
 #define ML_ROUTE_SMALL16 0 /* dense_small_kernel, 16 x 16 output tiles (a single image) */

@@ -549,13 +549,23 @@ __device__ __forceinline__ void post_geometry_person(const float* __restrict__ k
     o[11] = __fmul_rn(cz, dd) / nrm;
 }
 
+// "The frame is complete", told to a host that busy-polls a word of pinned memory instead of sleeping in hipStreamSynchronize
+// (ml_loco_frame_mono; one launch + its completion signal cost a host ~20 us on this stack, tools/exp_sync.py): every workgroup
+// makes its stores visible system-wide and checks in at `arrive`; the last one to arrive resets the counter and releases `seq`
+// into `flag`.  flag == nullptr: nothing of this happens.
+struct FrameDone {
+    int* arrive = nullptr;   // device counter, 0 between frames
+    int* flag = nullptr;     // device address of the pinned host word
+    int seq = 0;
+};
+
 // post_out != null: the row is post-processed here as well (post_person by thread 0: a single image's forward ends in this
 // launch); raw may then be null.  geo_out != null (with post_out): + the post_process geometry of the row (thread 64).
 __global__ __launch_bounds__(256) void heads_small_kernel(SmallHeads hp, int H, float* __restrict__ raw, int raw_stride,
                                                           int64_t m, const float* __restrict__ centre, Kinv ki,
                                                           const float* __restrict__ box_conf, float* __restrict__ post_out,
                                                           float* __restrict__ xyzds, const float* __restrict__ geo_kps,
-                                                          float* __restrict__ geo_out) {
+                                                          float* __restrict__ geo_out, FrameDone done = FrameDone()) {
     __shared__ float srow[16];
     const int64_t row = blockIdx.x;
     if (row >= m) return;
@@ -595,6 +605,17 @@ __global__ __launch_bounds__(256) void heads_small_kernel(SmallHeads hp, int H, 
         // geo_out != null: the geometry block post_process needs (distance = raw column 2, what post_person calls d) as well:
         // a frame then ends in this launch, and both blocks may lie in pinned host memory (ml_loco_frame_mono)
         if (geo_out && threadIdx.x == 64) post_geometry_person(geo_kps, row, ki, srow[2], geo_out);
+    }
+    if (done.flag) {   // (uniform; the grid is exactly m workgroups: no early return above)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (atomicAdd(done.arrive, 1) == (int)gridDim.x - 1) {
+                __hip_atomic_store(done.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -190,6 +191,12 @@ struct ml_loco {
     float* d_part = nullptr;    // fused-head partial sums [2*hidden/256][cap_rows][16] ...
     float* d_part_aux = nullptr;  // ... and, behind them, the fused w_aux head's [2*hidden/256][cap_rows] (same allocation)
     int part_slices = 0;        // slices per head d_part / d_part_aux hold
+    // ml_loco_frame_mono's completion word (pinned, coherent) + the arrival counter of the last launch's workgroups; frame_flag_req:
+    // the frame entry asks run_network to arm the flag in the launch that ends a single image's forward
+    int* h_done = nullptr;
+    int* d_arrive = nullptr;
+    int done_seq = 0;
+    bool frame_flag_req = false, frame_flag_armed = false;
     const void* pinned_seen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ml_loco_frame_mono: host pointers verified to be pinned
     int pinned_next = 0;
     int tune_version = 0;       // bumped by ml_loco_set_tuning / ml_loco_set_option: cached route plans of older versions are stale
@@ -997,15 +1004,23 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
                 // (a mono forward of a single image ends here: the post-process rides in the same launch)
                 const bool with_post = defer && h->out_f <= 16 && hp.col0[0] + hp.nh[0] <= 16 && hp.col0[1] + hp.nh[1] <= 16;
                 if (with_post) {
+                    mlk::FrameDone fd;
+                    if (h->frame_flag_req && tail->geo_out && h->h_done && h->d_arrive) {   // this launch ends a frame: arm the host's flag
+                        fd.arrive = h->d_arrive;
+                        fd.flag = h->h_done;
+                        fd.seq = ++h->done_seq;
+                        h->frame_flag_armed = true;
+                    }
                     hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden, tail->raw,
                                        h->out_f, rows_here, tail->centre, tail->ki, tail->box_conf, tail->out, tail->xyzds,
-                                       tail->geo_kps, tail->geo_out);
+                                       tail->geo_kps, tail->geo_out, fd);
                     tail->done = true;
                     tail->geo_done = tail->geo_out != nullptr;
                 } else {
                     hipLaunchKernelGGL(mlk::heads_small_kernel, dim3((unsigned)rows_here), dim3(256), 0, st, hp, h->hidden,
                                        raw_out + r0 * h->out_f, h->out_f, rows_here, (const float*)nullptr, mlk::Kinv{},
-                                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, (float*)nullptr);
+                                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                                       mlk::FrameDone());
                 }
                 HIP_TRY(hipGetLastError());
             }
@@ -1204,6 +1219,20 @@ int ml_loco_finalize(ml_loco* h, int precision, int flags) {
     }
     h->tensors.clear();
     if ((rc = set_head_lds_limits(h))) return rc;
+    // ml_loco_frame_mono's completion word (pinned, coherent: the host polls it while the last launch of a frame writes it) and the
+    // arrival counter of that launch's workgroups; without them a frame simply ends in hipStreamSynchronize
+    if (hipHostMalloc((void**)&h->h_done, 64, hipHostMallocCoherent) == hipSuccess) {
+        *h->h_done = 0;
+        if (hipMalloc((void**)&h->d_arrive, 64) != hipSuccess || hipMemset(h->d_arrive, 0, 64) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(h->h_done);
+            h->h_done = nullptr;
+            h->d_arrive = nullptr;
+        }
+    } else {
+        (void)hipGetLastError();
+        h->h_done = nullptr;
+    }
     h->finalized = true;
     return ML_OK;
 }
@@ -1273,6 +1302,8 @@ int ml_loco_destroy(ml_loco* h) {
         dev_free(hd.d_w);
         dev_free(hd.d_b);
     }
+    if (h->h_done) (void)hipHostFree(h->h_done);
+    dev_free(h->d_arrive);
     delete h->plans;
     delete h;
     return ML_OK;
@@ -1695,6 +1726,8 @@ int ml_loco_set_option(ml_loco* h, const char* name, int value) {
 }
 
 static std::atomic<long long> g_frames_without_copies{0};   // (test hook: ml_debug_frames_without_copies)
+static std::atomic<long long> g_frame_flag_timeouts{0};     // frames whose completion word did not arrive within 5 ms (expected: 0)
+static std::atomic<int> g_frame_spin{1};                    // ml_debug_frame_spin: 0 = always hipStreamSynchronize (the A/B reference)
 
 // One image through the mono pipeline in ONE call: pinned host keypoints in, [packed (m, 16) | post-process geometry (m, 12)] in
 // pinned host memory out, one stream synchronisation.  What Loco.forward does per frame (reference net.py:83-133 + the geometry
@@ -1732,13 +1765,32 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
     };
     if (m <= 128 && h && use_small_path(h->tune, h->precision, m) && pinned(kps_host) && pinned(out_host)) {
         bool geo_done = false;
-        if ((rc = forward_mono_impl(h, kps_host, m, kinv_host, nullptr, nullptr, out_host, xyzds_dev, stream,
-                                    out_host + (size_t)m * ML_OUT_STRIDE, &geo_done)))
-            return rc;
+        h->frame_flag_req = g_frame_spin.load(std::memory_order_relaxed) != 0;
+        h->frame_flag_armed = false;
+        rc = forward_mono_impl(h, kps_host, m, kinv_host, nullptr, nullptr, out_host, xyzds_dev, stream,
+                               out_host + (size_t)m * ML_OUT_STRIDE, &geo_done);
+        h->frame_flag_req = false;
+        if (rc) return rc;
         if (!geo_done &&   // (a model whose heads do not end in the one launch: the geometry as its own launch, still into host memory)
             (rc = ml_post_geometry_strided(kps_host, m, kinv_host, out_host + 3, ML_OUT_STRIDE, out_host + (size_t)m * ML_OUT_STRIDE, stream)))
             return rc;
-        HIP_TRY(hipStreamSynchronize(st));
+        bool seen = false;
+        if (h->frame_flag_armed && geo_done) {
+            // the last launch releases done_seq into the pinned word behind every store of the frame: poll it (the launches above are
+            // ~60 us of device time; a frame that has not reported after 5 ms falls back to the stream synchronisation)
+            const int want = h->done_seq;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0;; ++spins) {
+                if (__atomic_load_n(h->h_done, __ATOMIC_ACQUIRE) == want) {
+                    seen = true;
+                    break;
+                }
+                if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+                __builtin_ia32_pause();
+            }
+            if (!seen) g_frame_flag_timeouts.fetch_add(1, std::memory_order_relaxed);
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(st));
         g_frames_without_copies.fetch_add(1, std::memory_order_relaxed);   // counted once the frame has gone through
         return ML_OK;
     }
@@ -1752,6 +1804,13 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
 }
 
 long long ml_debug_frames_without_copies(void) { return g_frames_without_copies.load(std::memory_order_relaxed); }
+
+long long ml_debug_frame_spin(int enable) {
+    // enable 0 / 1 switches the completion-word polling of ml_loco_frame_mono off / on (process-wide; < 0 leaves it); returns the
+    // number of frames whose word did not arrive in time so far
+    if (enable >= 0) g_frame_spin.store(enable ? 1 : 0, std::memory_order_relaxed);
+    return g_frame_flag_timeouts.load(std::memory_order_relaxed);
+}
 
 int ml_debug_num_layers(const ml_loco* h) { return h ? (int)h->layers.size() : 0; }
 

@@ -167,3 +167,33 @@ def test_route_query_follows_the_tuning(hip_lib, cuda_device):
     bf = engine.LocoEngine(sd, device=cuda_device, precision='bf16')
     assert bf.route_for_rows(100) == 'tile'          # the bf16 comparison mode exists on the tile path only
     bf.close()
+
+
+def test_frame_completion_word(hip_lib, cuda_device):
+    """Round 5: a single image's forward tells the host it is done through a word of pinned memory (the last launch releases it behind
+    every store of the frame; ml_loco_frame_mono polls it) instead of hipStreamSynchronize.  2000 frames of changing content and
+    person counts: every dictionary equals the one the stream-synchronised route returns, no frame times out."""
+    import copy
+    import json
+    import os
+    from monoloco_amd.network import Loco, load_calibration, preprocess_pifpaf
+    from monoloco_amd.network.architectures import LocoModel
+    model = LocoModel(34, 9, 1024)
+    model.load_state_dict({k: torch.tensor(v) for k, v in synth.make_state_dict(2).items()})
+    net = Loco(model=model, mode='mono', device=cuda_device)
+    kk = synth.KITTI_K
+    t0 = hip_lib.ml_debug_frame_spin(1)
+    rng = np.random.default_rng(0)
+    frames = [synth.make_poses(int(rng.integers(1, 40)), seed=100 + i).tolist() for i in range(40)]
+    ref = []
+    hip_lib.ml_debug_frame_spin(0)                     # the reference: stream synchronisation
+    for kps in frames:
+        ref.append({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in net.forward(kps, kk).items()})
+    hip_lib.ml_debug_frame_spin(1)
+    for rep in range(50):
+        for kps, want in zip(frames, ref):
+            got = net.forward(kps, kk)
+            for key in ('xyzd', 'd', 'bi', 'h', 'w', 'l', 'ori'):
+                assert torch.equal(got[key], want[key]), (rep, key)
+            assert torch.equal(got['yaw'][0], want['yaw'][0]) and torch.equal(got['yaw'][1], want['yaw'][1])
+    assert hip_lib.ml_debug_frame_spin(-1) == t0       # no frame fell back to the stream synchronisation
