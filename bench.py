@@ -678,6 +678,19 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
             net.forward(kpl, kk1)
         res["loco_forward_us_stream_sync"] = round((time.perf_counter() - ts) / n * 1e6, 1)
         res["frame_flag_timeouts"] = int(_l.load().ml_debug_frame_spin(1))
+        # MonStereo's per-pair forward (16 left x 5 right persons = 80 pair rows), host side included (ml_loco_frame_stereo)
+        sd_s = synth.make_state_dict(3, 68, 10, 1024)
+        model_s = LocoModel(68, 10, 1024)
+        model_s.load_state_dict({k: torch.tensor(v) for k, v in sd_s.items()})
+        net_s = Loco(model=model_s, mode='stereo', device=dev)
+        kpr = [[[u - 12.0 for u in k[0]], k[1], k[2]] for k in kpl[:5]]
+        for _ in range(30):
+            net_s.forward(kpl, kk1, keypoints_r=kpr)
+        ts = time.perf_counter()
+        for _ in range(n):
+            net_s.forward(kpl, kk1, keypoints_r=kpr)
+        res["stereo_loco_forward_us"] = round((time.perf_counter() - ts) / n * 1e6, 1)
+        net_s.engine.close()
         # with ground truth, as GenerateKitti calls it on every image (reference eval/generate_kitti.py:114-132): IoU of all
         # detection x ground-truth pairs, greedy matching, left-to-right order and the matched xyz_real in batched calls
         dic_gt = {'boxes': [[b[0] + 3., b[1] - 2., b[2] + 1., b[3] + 4.] for b in boxes[::-1]],

@@ -188,6 +188,15 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
  * transfers.  xyzds_dev (m,5) or NULL. */
 int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float* kinv_host, float* kps_dev, float* buf_dev,
                        float* xyzds_dev, float* out_host, void* stream);
+/* One STEREO image pair in one call -- MonStereo's Loco.forward (monoloco/network/net.py:112-122: all-vs-all pairing, network,
+ * cluster_outputs / filter_outputs, extract_outputs) + the geometry block of post_process (net.py:195-215).  kps_l_host (ml,3,17),
+ * kps_r_host (mr,3,17) and out_host are HOST buffers; out_host receives ml * ML_OUT_STRIDE floats (packed rows of the per-left
+ * winners), ml * ML_POSTGEO_STRIDE floats (geometry), one int32 = number of left persons whose best aux logit is tied (the reference
+ * keeps every tied pair row: the caller re-does such a frame through ml_loco_forward_stereo + ml_stereo_tied_rows), ml int32 = the
+ * winning right index per left person.  Pinned (device-mapped) host buffers: no copy operation, the host polls the frame's completion
+ * word; pageable ones are staged through kps_dev ((ml + mr) * 51 floats) and buf_dev (same size as out_host).  xyzds_dev (ml, 5). */
+int ml_loco_frame_stereo(ml_loco* h, const float* kps_l_host, int64_t ml, const float* kps_r_host, int64_t mr,
+                         const float* kinv_host, float* kps_dev, float* buf_dev, float* xyzds_dev, float* out_host, void* stream);
 /* stereo (net.py:112-122, process.py:307-327): all left x right pairs, per-left arg-max of the
  * aux logit.  best_dev (ml) int32 receives the first arg-max right index; ties_dev (1) int32
  * receives the number of left persons with more than one maximal pair (the reference keeps

@@ -114,4 +114,28 @@ __global__ __launch_bounds__(256) void post_geometry_kernel(const float* __restr
     post_geometry_person(kps, i, ki, d ? d[i * d_stride] : 0.0f, out);
 }
 
+// ... as the LAST launch of a stereo frame (ml_loco_frame_stereo): the same rows, then the frame's completion word (FrameDone,
+// geom_kernels.h) for a host that polls pinned memory
+// (+ n_words 32-bit words carried from device memory into the output block: the arg-max indices and the tie count, which
+//  stereo_best_kernel keeps in device memory -- its atomics stay off the host link)
+__global__ __launch_bounds__(256) void post_geometry_done_kernel(const float* __restrict__ kps, int64_t m, Kinv ki,
+                                                                 const float* __restrict__ d, int64_t d_stride,
+                                                                 float* __restrict__ out, const int32_t* __restrict__ words_src,
+                                                                 int32_t* __restrict__ words_dst, int64_t n_words, FrameDone done) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) post_geometry_person(kps, i, ki, d ? d[i * d_stride] : 0.0f, out);
+    for (int64_t k = i; k < n_words; k += (int64_t)gridDim.x * 256) words_dst[k] = words_src[k];
+    if (done.flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (atomicAdd(done.arrive, 1) == (int)gridDim.x - 1) {
+                __hip_atomic_store(done.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
 }  // namespace mlk

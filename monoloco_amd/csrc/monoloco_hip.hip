@@ -1803,6 +1803,82 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
     return ML_OK;
 }
 
+// One STEREO image pair in one call (MonStereo's Loco.forward, reference net.py:112-122 + the geometry of :195-215): pinned host
+// keypoints of both views in; [packed (ml, 16) | geometry (ml, 12) | int32 ties | int32 best (ml)] in pinned host memory out.  With
+// pinned buffers no copy operation at all -- the pre-process kernels read the keypoints over the link, the post-process / arg-max /
+// geometry kernels write the pinned block, the last launch releases the completion word the host polls; otherwise staged copies.
+int ml_loco_frame_stereo(ml_loco* h, const float* kps_l_host, int64_t ml, const float* kps_r_host, int64_t mr, const float* kinv_host,
+                         float* kps_dev, float* buf_dev, float* xyzds_dev, float* out_host, void* stream) {
+    if (ml < 0 || mr <= 0 || !kinv_host || (ml > 0 && (!kps_l_host || !kps_r_host || !kps_dev || !buf_dev || !xyzds_dev || !out_host)))
+        return fail(ML_ERR_ARG, "bad argument");
+    if (ml == 0) return ML_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    auto pinned = [h](const void* p) {
+        if (h)
+            for (const void* q : h->pinned_seen)
+                if (q == p) return true;
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (a.type != hipMemoryTypeHost) return false;
+        if (h) {
+            h->pinned_seen[h->pinned_next] = p;
+            h->pinned_next = (h->pinned_next + 1) % 8;
+        }
+        return true;
+    };
+    const size_t n_packed = (size_t)ml * ML_OUT_STRIDE, n_geo = (size_t)ml * ML_POSTGEO_STRIDE;
+    const size_t words = n_packed + n_geo + 1 + (size_t)ml;
+    const bool direct = h && pinned(kps_l_host) && pinned(kps_r_host) && pinned(out_host);
+    const float* kl = kps_l_host;
+    const float* kr = kps_r_host;
+    float* blk = out_host;
+    if (!direct) {
+        HIP_TRY(hipMemcpyAsync(kps_dev, kps_l_host, (size_t)ml * 3 * mlk::NKP * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(kps_dev + (size_t)ml * 3 * mlk::NKP, kps_r_host, (size_t)mr * 3 * mlk::NKP * 4, hipMemcpyHostToDevice, st));
+        kl = kps_dev;
+        kr = kps_dev + (size_t)ml * 3 * mlk::NKP;
+        blk = buf_dev;
+    }
+    // the tie count and the arg-max indices are produced in DEVICE memory (stereo_best_kernel's atomics stay off the host link): the
+    // tail of buf_dev; the last launch carries them into the output block
+    int32_t* ties = (int32_t*)(buf_dev + n_packed + n_geo);
+    int32_t* best = ties + 1;
+    if ((rc = ml_loco_forward_stereo(h, kl, ml, kr, mr, kinv_host, nullptr, nullptr, blk, xyzds_dev, best, ties, stream))) return rc;
+    mlk::FrameDone fd;
+    const bool spin = direct && h->h_done && h->d_arrive && g_frame_spin.load(std::memory_order_relaxed) != 0;
+    if (spin) {
+        fd.arrive = h->d_arrive;
+        fd.flag = h->h_done;
+        fd.seq = ++h->done_seq;
+    }
+    hipLaunchKernelGGL(mlk::post_geometry_done_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, st, kl, ml, make_kinv(kinv_host),
+                       (const float*)(blk + 3), (int64_t)ML_OUT_STRIDE, blk + n_packed, (const int32_t*)ties,
+                       (int32_t*)(blk + n_packed + n_geo), direct ? (int64_t)(1 + ml) : (int64_t)0, fd);
+    HIP_TRY(hipGetLastError());
+    if (!direct) HIP_TRY(hipMemcpyAsync(out_host, buf_dev, words * 4, hipMemcpyDeviceToHost, st));
+    bool seen = false;
+    if (spin) {
+        const int want = fd.seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(h->h_done, __ATOMIC_ACQUIRE) == want) {
+                seen = true;
+                break;
+            }
+            if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+            __builtin_ia32_pause();
+        }
+        if (!seen) g_frame_flag_timeouts.fetch_add(1, std::memory_order_relaxed);
+    }
+    if (!seen) HIP_TRY(hipStreamSynchronize(st));
+    if (direct) g_frames_without_copies.fetch_add(1, std::memory_order_relaxed);
+    return ML_OK;
+}
+
 long long ml_debug_frames_without_copies(void) { return g_frames_without_copies.load(std::memory_order_relaxed); }
 
 long long ml_debug_frame_spin(int enable) {

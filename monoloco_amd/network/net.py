@@ -152,6 +152,17 @@ class Loco:
         if keypoints is None or len(keypoints) == 0:
             return None
         dev = self.device
+        kk_list = kk.tolist() if hasattr(kk, 'tolist') else kk
+        if self.net == 'monstereo' and not (isinstance(keypoints, torch.Tensor) and keypoints.is_cuda) \
+                and not (isinstance(keypoints_r, torch.Tensor) and keypoints_r.is_cuda):
+            # one stereo image pair from the host (the reference's call, predict.py:244-245): ONE foreign call, pinned buffers both ways
+            staged = self._forward_stereo_staged(keypoints, keypoints_r, engine.inverse_intrinsics(kk_list))
+            if staged is not None:   # (None: exact ties of the aux logit -- the rare frame takes the general route below)
+                dic_out, geo_host = staged
+                dic_out['epi'] = [0.] * len(keypoints)
+                dic_out = _LocoOut(dic_out)
+                dic_out._geo = (keypoints, kk_list, dic_out['d'], geo_host)
+                return dic_out
         if self.net == 'monoloco_pp' and not (isinstance(keypoints, torch.Tensor) and keypoints.is_cuda):
             # one image from the host (the reference's call, predict.py:231-249): lists -> ONE float32 array, staged below
             # (a plain list stays a list here: _forward_pp_staged walks it straight into the pinned staging buffer)
@@ -159,7 +170,6 @@ class Loco:
                 _lists_to_f32(keypoints) if not isinstance(keypoints, torch.Tensor) else keypoints.float().numpy())
         else:
             kps = engine._dev_f32(keypoints, dev)
-        kk_list = kk.tolist() if hasattr(kk, 'tolist') else kk
         kinv = engine.inverse_intrinsics(kk_list)
         geo_host = None
         if self.net == 'monoloco':
@@ -283,6 +293,68 @@ class Loco:
         h_, w_, l_, bi_, yaw_, yawe_, d_ = cols.view(7, m, 1).unbind(0)
         dic = {'h': h_, 'w': w_, 'l': l_, 'ori': ori.view(m, 2), 'bi': bi_, 'xyzd': xyzd.view(m, 4), 'd': d_, 'yaw': (yaw_, yawe_)}
         return dic, geo.view(m, 12), kps
+
+    def _forward_stereo_staged(self, keypoints, keypoints_r, kinv):
+        """MonStereo forward of one image pair with every buffer cached per (left, right) person count: both keypoint sets go
+        through pinned staging arrays the pre-process kernels read directly, the per-left winners' packed rows (ml,16), the
+        post-process geometry (ml,12), the tie count and the arg-max indices come back in one pinned block the last launch
+        completes (ml_loco_frame_stereo).  Returns (dictionary of fresh CPU tensors, fresh (ml,12) geometry tensor), or None when
+        some left person's best aux logit is tied (the reference keeps every tied pair row: the general route handles it)."""
+        lib = engine._lib.load()
+        dev = self.device
+        if keypoints_r is None or len(keypoints_r) == 0:
+            keypoints_r = keypoints[0:1]   # reference net.py:115-116: the first left pose stands in
+        ml, mr = len(keypoints), len(keypoints_r)
+        stride = engine._lib.ML_OUT_STRIDE
+        key = ('stereo', ml, mr)
+        st = self._stage.get(key)
+        if st is None:
+            if len(self._stage) >= 16:
+                self._stage.clear()
+            words = ml * (stride + 12) + 1 + ml
+            pin_l = torch.empty((ml, 3, 17), dtype=torch.float32).pin_memory()
+            pin_r = torch.empty((mr, 3, 17), dtype=torch.float32).pin_memory()
+            pin_out = torch.empty((words,), dtype=torch.float32).pin_memory()
+            st = dict(pin_l=pin_l, pin_r=pin_r, pin_out=pin_out, np_l=pin_l.numpy(), np_r=pin_r.numpy(), np_out=pin_out.numpy(),
+                      dev_in=torch.empty(((ml + mr) * 51,), dtype=torch.float32, device=dev),
+                      buf=torch.empty((words,), dtype=torch.float32, device=dev),
+                      xyzds=torch.empty((ml, engine._lib.ML_XYZDS_STRIDE), dtype=torch.float32, device=dev))
+            st['np_ties'] = st['np_out'][ml * (stride + 12):ml * (stride + 12) + 1].view(np.int32)
+            idx = np.arange(ml * stride).reshape(ml, stride)
+            # h w l bi yaw yaw_ego d aux as single columns, then ori (ml,2), xyzd (ml,4), the (ml,12) geometry block
+            st['perm'] = np.concatenate([idx[:, [8, 9, 10, 4, 5, 6, 3, 7]].T.reshape(-1), idx[:, 12:14].reshape(-1), idx[:, 0:4].reshape(-1),
+                                         np.arange(ml * stride, ml * (stride + 12))]).astype(np.intp)
+            st['sizes'] = [8 * ml, 2 * ml, 4 * ml, 12 * ml]
+            for name, t in (('p_l', pin_l), ('p_r', pin_r), ('p_out', pin_out), ('p_in', st['dev_in']), ('p_buf', st['buf']),
+                            ('p_xyzds', st['xyzds'])):
+                st[name] = ctypes.c_void_p(t.data_ptr())
+            self._stage[key] = st
+        ph = _pyhost()
+        for src, n, np_dst, p_dst in ((keypoints, ml, st['np_l'], st['p_l']), (keypoints_r, mr, st['np_r'], st['p_r'])):
+            if type(src) is list:
+                if ph is None or ph.ml_py_fill_kps(src, p_dst, n) != 0:
+                    np.copyto(np_dst, _lists_to_f32(src))
+            else:
+                arr = src.float().numpy() if isinstance(src, torch.Tensor) else np.asarray(src, dtype=np.float32)
+                assert arr.shape[1:] == (3, 17), "keypoints must be (m, 3, 17)"
+                np.copyto(np_dst, arr)
+        kinv_p = engine.kinv_ptr(kinv)
+        stream = engine._stream(dev)
+        call = lambda: engine.check(lib.ml_loco_frame_stereo(self.engine._h, st['p_l'], ml, st['p_r'], mr, kinv_p, st['p_in'], st['p_buf'],
+                                                             st['p_xyzds'], st['p_out'], stream))
+        if torch.cuda.current_device() == dev.index:
+            call()
+        else:
+            with torch.cuda.device(dev):
+                call()
+        if int(st['np_ties'][0]) != 0:
+            return None
+        t = torch.from_numpy(st['np_out'].take(st['perm']))
+        cols, ori, xyzd, geo = t.split_with_sizes(st['sizes'])
+        h_, w_, l_, bi_, yaw_, yawe_, d_, aux_ = cols.view(8, ml, 1).unbind(0)
+        dic = {'h': h_, 'w': w_, 'l': l_, 'ori': ori.view(ml, 2), 'aux': aux_, 'bi': bi_, 'xyzd': xyzd.view(ml, 4), 'd': d_,
+               'yaw': (yaw_, yawe_)}
+        return dic, geo.view(ml, 12)
 
     def _packed_buffers(self, m):
         """One device allocation for the packed (m,16) network result and the (m,12) post-process geometry."""

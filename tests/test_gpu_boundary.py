@@ -197,3 +197,38 @@ def test_frame_completion_word(hip_lib, cuda_device):
                 assert torch.equal(got[key], want[key]), (rep, key)
             assert torch.equal(got['yaw'][0], want['yaw'][0]) and torch.equal(got['yaw'][1], want['yaw'][1])
     assert hip_lib.ml_debug_frame_spin(-1) == t0       # no frame fell back to the stream synchronisation
+
+
+def test_stereo_frame_entry_matches_the_general_route(hip_lib, cuda_device):
+    """Round 5: MonStereo's Loco.forward on host keypoints goes through ml_loco_frame_stereo (one call, pinned buffers, completion
+    word) -- same dictionary and geometry block as the general route (device tensors in: ml_loco_forward_stereo +
+    ml_post_geometry_strided + copies), for lists / numpy, with and without right keypoints; a frame with tied aux logits falls back
+    and keeps every tied pair row like the reference (process.py:325-326)."""
+    from monoloco_amd.network import Loco
+    from monoloco_amd.network.architectures import LocoModel
+    model = LocoModel(68, 10, 1024)
+    model.load_state_dict({k: torch.tensor(v) for k, v in synth.make_state_dict(3, 68, 10, 1024).items()})
+    net = Loco(model=model, mode='stereo', device=cuda_device)
+    kk = synth.KITTI_K
+    t0 = hip_lib.ml_debug_frame_spin(-1)
+    for ml, mr, seed in ((16, 5, 1), (1, 1, 2), (30, 30, 3), (7, 0, 4), (3, 40, 5)):
+        kl = synth.make_poses(ml, seed)
+        kr = synth.make_poses(mr, seed + 50) if mr else None
+        if kr is not None:
+            kr[:, 0] -= 15.0
+        want = net.forward(torch.tensor(kl).to(cuda_device), kk, keypoints_r=None if kr is None else torch.tensor(kr).to(cuda_device))
+        for as_list in (True, False):
+            got = net.forward(kl.tolist() if as_list else kl, kk, keypoints_r=None if kr is None else (kr.tolist() if as_list else kr))
+            assert list(got.keys()) == list(want.keys())
+            for key in ('h', 'w', 'l', 'ori', 'aux', 'bi', 'xyzd', 'd'):
+                assert got[key].shape == want[key].shape and torch.equal(got[key], want[key]), (ml, mr, key)
+            assert torch.equal(got['yaw'][0], want['yaw'][0]) and torch.equal(got['yaw'][1], want['yaw'][1])
+            assert got['epi'] == want['epi'] and torch.equal(got._geo[3], want._geo[3])
+    assert hip_lib.ml_debug_frame_spin(-1) == t0
+    # two identical right poses: every left person's best aux logit is tied -> both pair rows are kept (2 ml rows)
+    kl = synth.make_poses(6, 9)
+    kr = np.repeat(synth.make_poses(1, 10), 2, axis=0)
+    tied = net.forward(kl.tolist(), kk, keypoints_r=kr.tolist())
+    assert tied['d'].shape[0] == 12
+    want = net.forward(torch.tensor(kl).to(cuda_device), kk, keypoints_r=torch.tensor(kr).to(cuda_device))
+    assert torch.equal(tied['xyzd'], want['xyzd'])
