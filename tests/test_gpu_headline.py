@@ -298,8 +298,14 @@ def test_reference_trained_weights_at_the_full_batch(hip_lib, cuda_device, gold,
         raw_all = res['raw_all'].cpu()
         assert raw_all.shape == (ml * mr, 10)
         x, _ = O.preprocess_monstereo(torch.tensor(kl), torch.tensor(kr), synth.KITTI_K)
-        for lo in range(0, ml * mr, 8192):      # every pair row
-            assert (raw_all[lo:lo + 8192] - O.loco_forward(sd, x[lo:lo + 8192])).abs().max().item() <= TOL, lo
+        for lo in range(0, ml * mr, 8192):      # every pair row (round 5; a strided 512-row sample before)
+            ref = O.loco_forward(sd, x[lo:lo + 8192])
+            err = (raw_all[lo:lo + 8192] - ref).abs()
+            assert err[:, :9].max().item() <= TOL, lo
+            # the aux logit of a non-matching pair is -50 .. -90 on this checkpoint (its sigmoid is 0 to 20+ digits): fp32 holds such
+            # a value to 4-8e-6, the reference's own fp32 run is that far from fp64 -- the absolute bar plus 4e-6 relative
+            assert (err[:, 9] <= TOL + 4e-6 * ref[:, 9].abs()).all(), lo
+            assert (torch.sigmoid(raw_all[lo:lo + 8192, 9]) - torch.sigmoid(ref[:, 9])).abs().max().item() <= TOL
         # the per-left winner is the arg-max of the device's own aux logits
         best = res['best'].cpu().long()
         assert torch.equal(best, raw_all.view(ml, mr, 10)[:, :, -1].argmax(1))
