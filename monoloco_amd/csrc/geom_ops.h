@@ -114,26 +114,50 @@ __global__ __launch_bounds__(256) void post_geometry_kernel(const float* __restr
     post_geometry_person(kps, i, ki, d ? d[i * d_stride] : 0.0f, out);
 }
 
-// ... as the LAST launch of a stereo frame (ml_loco_frame_stereo): the same rows, then the frame's completion word (FrameDone,
-// geom_kernels.h) for a host that polls pinned memory
-// (+ n_words 32-bit words carried from device memory into the output block: the arg-max indices and the tie count, which
-//  stereo_best_kernel keeps in device memory -- its atomics stay off the host link)
-__global__ __launch_bounds__(256) void post_geometry_done_kernel(const float* __restrict__ kps, int64_t m, Kinv ki,
-                                                                 const float* __restrict__ d, int64_t d_stride,
-                                                                 float* __restrict__ out, const int32_t* __restrict__ words_src,
-                                                                 int32_t* __restrict__ words_dst, int64_t n_words, FrameDone done) {
+// The end of a stereo frame in ONE launch (ml_loco_frame_stereo), one lane per left person: stereo_best_kernel's arg-max over the
+// person's mr pair rows (first maximum; ties and NaN candidates counted), post_person of the winning row (post_kernel), the
+// post_process geometry of the person (post_geometry_kernel) -- same arithmetic, same order -- then the frame's completion:
+// every workgroup makes its stores visible system-wide and checks in; the last one writes the tie count behind the arg-max
+// indices, resets both device words and releases the completion word (FrameDone, geom_kernels.h).  words_dst = int32 [ties, best[ml]].
+__global__ __launch_bounds__(256) void stereo_tail_frame_kernel(const float* __restrict__ raw_all, int out_f, int64_t ml, int64_t mr,
+                                                                const float* __restrict__ centre, Kinv ki, const float* __restrict__ kps,
+                                                                float* __restrict__ out, float* __restrict__ xyzds,
+                                                                float* __restrict__ geo, int32_t* __restrict__ row_index,
+                                                                int32_t* __restrict__ ties_dev, int32_t* __restrict__ words_dst,
+                                                                FrameDone done) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < m) post_geometry_person(kps, i, ki, d ? d[i * d_stride] : 0.0f, out);
-    for (int64_t k = i; k < n_words; k += (int64_t)gridDim.x * 256) words_dst[k] = words_src[k];
-    if (done.flag) {
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (atomicAdd(done.arrive, 1) == (int)gridDim.x - 1) {
-                __hip_atomic_store(done.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence_system();
-                __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (i < ml) {
+        const float* p = raw_all + i * mr * out_f + (out_f - 1);
+        float bv = p[0];
+        int bj = 0, cnt = 1;
+        bool has_nan = (bv != bv);
+        for (int64_t j = 1; j < mr; ++j) {
+            const float v = p[j * out_f];
+            has_nan |= (v != v);
+            if (v > bv) {
+                bv = v;
+                bj = (int)j;
+                cnt = 1;
+            } else if (v == bv) {
+                ++cnt;
             }
+        }
+        words_dst[1 + i] = bj;
+        row_index[i] = (int32_t)(i * mr + bj);
+        if (cnt > 1 || has_nan) atomicAdd(ties_dev, 1);
+        const float* r = raw_all + (i * mr + bj) * out_f;
+        post_person(r, out_f, i, centre, ki, (const float*)nullptr, out, xyzds);
+        post_geometry_person(kps, i, ki, r[2], geo);   // (r[2] = the distance post_person stores in column 3 of the packed row)
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(done.arrive, 1) == (int)gridDim.x - 1) {
+            words_dst[0] = __hip_atomic_load(ties_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ties_dev, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            if (done.flag) __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

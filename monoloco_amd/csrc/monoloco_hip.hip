@@ -1534,6 +1534,23 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
     return forward_mono_impl(h, kps_dev, m, kinv_host, box_conf_dev, raw_dev, out_dev, xyzds_dev, stream, nullptr, nullptr);
 }
 
+// the stereo pipeline up to the raw rows of all ml x mr pairs: both pre-processes, the all-vs-all pairing, the network
+static int stereo_front(ml_loco* h, const float* kps_l_dev, int64_t ml, const float* kps_r_dev, int64_t mr, const mlk::Kinv& ki,
+                        float* raw, hipStream_t st) {
+    int rc;
+    const int64_t rows = ml * mr;
+    if ((rc = ensure_rows(h, rows))) return rc;
+    if ((rc = ensure_side(h, ml > mr ? ml : mr))) return rc;
+    if ((rc = launch_prep(st, kps_l_dev, ml, ki, 10.0f, h->d_xl, h->d_cl, (char*)nullptr, 0, ml, 0))) return rc;
+    if ((rc = launch_prep(st, kps_r_dev, mr, ki, 10.0f, h->d_xr, (float*)nullptr, (char*)nullptr, 0, mr, 0))) return rc;
+    const int64_t rows_pad = round_up64(rows, 256);
+    const int64_t chunks = rows_pad * (h->k0pad / 4);
+    hipLaunchKernelGGL(mlk::pairs_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, h->d_xl, ml, h->d_xr,
+                       mr, (float*)nullptr, h->buf[0], h->k0pad, rows_pad);
+    HIP_TRY(hipGetLastError());
+    return run_network(h, rows, raw ? raw : h->d_raw, st);
+}
+
 int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const float* kps_r_dev, int64_t mr,
                            const float* kinv_host, const float* box_conf_dev, float* raw_all_dev, float* out_dev,
                            float* xyzds_dev, int32_t* best_dev, int32_t* ties_dev, void* stream) {
@@ -1544,20 +1561,11 @@ int ml_loco_forward_stereo(ml_loco* h, const float* kps_l_dev, int64_t ml, const
     if (ml == 0) return ML_OK;
     if (ml < 0 || mr <= 0 || !kinv_host || !out_dev || !best_dev || !ties_dev || !kps_l_dev || !kps_r_dev)
         return fail(ML_ERR_ARG, "bad argument");
-    const int64_t rows = ml * mr;
-    if ((rc = ensure_rows(h, rows))) return rc;
-    if ((rc = ensure_side(h, ml > mr ? ml : mr))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const mlk::Kinv ki = make_kinv(kinv_host);
-    if ((rc = launch_prep(st, kps_l_dev, ml, ki, 10.0f, h->d_xl, h->d_cl, (char*)nullptr, 0, ml, 0))) return rc;
-    if ((rc = launch_prep(st, kps_r_dev, mr, ki, 10.0f, h->d_xr, (float*)nullptr, (char*)nullptr, 0, mr, 0))) return rc;
-    const int64_t rows_pad = round_up64(rows, 256);
-    const int64_t chunks = rows_pad * (h->k0pad / 4);
-    hipLaunchKernelGGL(mlk::pairs_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, h->d_xl, ml, h->d_xr,
-                       mr, (float*)nullptr, h->buf[0], h->k0pad, rows_pad);
-    HIP_TRY(hipGetLastError());
     float* raw = raw_all_dev ? raw_all_dev : h->d_raw;
-    if ((rc = run_network(h, rows, raw, st))) return rc;
+    if ((rc = stereo_front(h, kps_l_dev, ml, kps_r_dev, mr, ki, raw_all_dev, st))) return rc;
+    raw = raw_all_dev ? raw_all_dev : h->d_raw;   // (the workspace may have been re-allocated by this call)
     HIP_TRY(hipMemsetAsync(ties_dev, 0, 4, st));
     hipLaunchKernelGGL(mlk::stereo_best_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, st, raw, h->out_f, ml,
                        mr, best_dev, h->d_rowidx, ties_dev);
@@ -1832,7 +1840,7 @@ int ml_loco_frame_stereo(ml_loco* h, const float* kps_l_host, int64_t ml, const 
     };
     const size_t n_packed = (size_t)ml * ML_OUT_STRIDE, n_geo = (size_t)ml * ML_POSTGEO_STRIDE;
     const size_t words = n_packed + n_geo + 1 + (size_t)ml;
-    const bool direct = h && pinned(kps_l_host) && pinned(kps_r_host) && pinned(out_host);
+    const bool direct = h && h->d_arrive && pinned(kps_l_host) && pinned(kps_r_host) && pinned(out_host);
     const float* kl = kps_l_host;
     const float* kr = kps_r_host;
     float* blk = out_host;
@@ -1843,22 +1851,31 @@ int ml_loco_frame_stereo(ml_loco* h, const float* kps_l_host, int64_t ml, const 
         kr = kps_dev + (size_t)ml * 3 * mlk::NKP;
         blk = buf_dev;
     }
-    // the tie count and the arg-max indices are produced in DEVICE memory (stereo_best_kernel's atomics stay off the host link): the
-    // tail of buf_dev; the last launch carries them into the output block
-    int32_t* ties = (int32_t*)(buf_dev + n_packed + n_geo);
-    int32_t* best = ties + 1;
-    if ((rc = ml_loco_forward_stereo(h, kl, ml, kr, mr, kinv_host, nullptr, nullptr, blk, xyzds_dev, best, ties, stream))) return rc;
+    const mlk::Kinv ki = make_kinv(kinv_host);
     mlk::FrameDone fd;
-    const bool spin = direct && h->h_done && h->d_arrive && g_frame_spin.load(std::memory_order_relaxed) != 0;
-    if (spin) {
+    const bool spin = direct && h->h_done && g_frame_spin.load(std::memory_order_relaxed) != 0;
+    if (direct) {
+        // the whole end of the frame -- per-left arg-max, post-process of the winners, geometry, tie count, completion word -- is ONE
+        // launch (stereo_tail_frame_kernel); the tie counter is the second word of the handle's arrival block (0 between frames)
+        if ((rc = check_ready(h))) return rc;
+        if (h->in_f != 2 * mlk::NIN || h->out_f != 10) return fail(ML_ERR_SHAPE, "stereo pipeline needs a 68-input / 10-output model");
+        if ((rc = stereo_front(h, kl, ml, kr, mr, ki, nullptr, st))) return rc;
         fd.arrive = h->d_arrive;
-        fd.flag = h->h_done;
-        fd.seq = ++h->done_seq;
+        if (spin) {
+            fd.flag = h->h_done;
+            fd.seq = ++h->done_seq;
+        }
+        hipLaunchKernelGGL(mlk::stereo_tail_frame_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, st, (const float*)h->d_raw,
+                           h->out_f, ml, mr, (const float*)h->d_cl, ki, kl, blk, xyzds_dev, blk + n_packed, h->d_rowidx,
+                           (int32_t*)h->d_arrive + 1, (int32_t*)(blk + n_packed + n_geo), fd);
+        HIP_TRY(hipGetLastError());
+    } else {
+        // staged route: the public pipeline + the geometry launch into the device block, copied out below
+        int32_t* ties = (int32_t*)(buf_dev + n_packed + n_geo);
+        int32_t* best = ties + 1;
+        if ((rc = ml_loco_forward_stereo(h, kl, ml, kr, mr, kinv_host, nullptr, nullptr, blk, xyzds_dev, best, ties, stream))) return rc;
+        if ((rc = ml_post_geometry_strided(kl, ml, kinv_host, blk + 3, ML_OUT_STRIDE, blk + n_packed, stream))) return rc;
     }
-    hipLaunchKernelGGL(mlk::post_geometry_done_kernel, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, st, kl, ml, make_kinv(kinv_host),
-                       (const float*)(blk + 3), (int64_t)ML_OUT_STRIDE, blk + n_packed, (const int32_t*)ties,
-                       (int32_t*)(blk + n_packed + n_geo), direct ? (int64_t)(1 + ml) : (int64_t)0, fd);
-    HIP_TRY(hipGetLastError());
     if (!direct) HIP_TRY(hipMemcpyAsync(out_host, buf_dev, words * 4, hipMemcpyDeviceToHost, st));
     bool seen = false;
     if (spin) {
