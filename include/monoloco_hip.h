@@ -371,6 +371,10 @@ int ml_iou_greedy(const int64_t* order, int64_t n, const int32_t* jmax, const do
 int ml_iou_matches_host(const double* boxes, int64_t m, int64_t ldb, const double* gt, int64_t g, int64_t ldg,
                         const int64_t* order, double iou_min, const int64_t* order_left, int64_t* pairs, int64_t* n_pairs,
                         int32_t* zero_div);
+/* xyz_from_distance (utils/camera.py:161-177) on HOST arrays -- the ground-truth side of the matched persons of a frame
+ * (net.py:242-247), whose normalised centres are already on the host inside the geometry block: d (m) (or one value), centres (m,3)
+ * -> out (m,3); fp32, the reference's operation order, same bits as ml_xyz_from_distance. */
+int ml_xyz_from_distance_host(const float* d, int d_is_scalar, const float* centres, int64_t m, float* out);
 const char* ml_matching_last_error(void);
 
 /* ---- measurement: per-launch timing of the dense (MFMA) kernel ----------------------- */

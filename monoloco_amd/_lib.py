@@ -109,6 +109,7 @@ SIGNATURES = {
     'ml_iou_matrix_host': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, _P]),
     'ml_iou_greedy': (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_double, _P, _P, _P]),
     'ml_iou_matches_host': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_double, _P, _P, _P, _P]),
+    'ml_xyz_from_distance_host': (c_int, [_P, c_int, _P, c_int64, _P]),
     'ml_matching_last_error': (c_char_p, []),
     'ml_loco_profile_begin': (c_int, [_P, c_int]),
     'ml_loco_profile_end': (c_int, [_P, POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_int]),

@@ -242,4 +242,23 @@ int ml_iou_matches_host(const double* boxes, int64_t m, int64_t ldb, const doubl
     return ml_iou_greedy(order, m, jmax.data(), vmax.data(), m, g, iou_min, order_left, pairs, n_pairs);
 }
 
+int ml_xyz_from_distance_host(const float* d, int d_is_scalar, const float* centres, int64_t m, float* out) {
+    // xyz_from_distance (reference utils/camera.py:161-177) on host arrays, for the few matched persons of a frame whose geometry
+    // block is already on the host: centre * d / sqrt(1 + x^2 + y^2), fp32, one rounding per operation in the reference's order
+    // (-ffp-contract=off) -- the same bits as ml_xyz_from_distance's kernel
+    if (m < 0 || (m > 0 && (!d || !centres || !out))) return mfail(ML_ERR_ARG, "ml_xyz_from_distance_host: bad argument");
+    for (int64_t i = 0; i < m; ++i) {
+        const float* c = centres + 3 * i;
+        const float dd = d[d_is_scalar ? 0 : i];
+        const float xx = c[0] * c[0], yy = c[1] * c[1];
+        const float s1 = 1.0f + xx;
+        const float nrm = sqrtf(s1 + yy);
+        for (int j = 0; j < 3; ++j) {
+            const float num = c[j] * dd;
+            out[3 * i + j] = num / nrm;
+        }
+    }
+    return ML_OK;
+}
+
 }  // extern "C"

@@ -74,10 +74,10 @@ def _pyhost():
     return _PYHOST[0]
 
 
-# from this many matches on, the matched centres go through ml_xyz_from_distance on the device in one launch; below it the
-# three fp32 operations per value are done where the (m,12) geometry block already is (the host: it was fetched for the
-# dictionary), which is what the reference does too -- its xy_centers are CPU tensors.  IEEE fp32 multiply, divide and
-# square root are correctly rounded on both sides, so the two routes give the same bits (tests/test_gpu_matching.py).
+# from this many matches on, the matched centres go through ml_xyz_from_distance on the device in one launch; below it through the
+# library's host routine (ml_xyz_from_distance_host) on the (m,12) geometry block that is already on the host -- it was fetched for
+# the dictionary; the reference's xy_centers are CPU tensors too.  Both are the same three correctly rounded fp32 operations per
+# value in the reference's order: the same bits (tests/test_gpu_matching.py).
 XYZ_REAL_DEVICE_MIN = 512
 
 
@@ -88,10 +88,12 @@ def _xyz_real(dds_real, xy_centers, idx_m):
     if k >= XYZ_REAL_DEVICE_MIN:
         dd = torch.tensor(dds_real, dtype=torch.float64).to(torch.float32)   # (a Python float rounds to fp32 once, like torch.tensor(dd))
         return xyz_from_distance(dd, xy_centers[idx_m]).tolist()
-    c = (xy_centers.numpy() if isinstance(xy_centers, torch.Tensor) else np.asarray(xy_centers, dtype=np.float32))[idx_m]
-    dd = np.asarray(dds_real, dtype=np.float64).astype(np.float32)[:, None]
-    x, y = c[:, 0:1], c[:, 1:2]
-    return (c * dd / np.sqrt(1 + x * x + y * y)).tolist()
+    c = np.ascontiguousarray((xy_centers.numpy() if isinstance(xy_centers, torch.Tensor)
+                              else np.asarray(xy_centers, dtype=np.float32))[idx_m], dtype=np.float32)
+    dd = np.asarray(dds_real, dtype=np.float64).astype(np.float32)
+    out = np.empty((k, 3), dtype=np.float32)
+    engine.check(engine._lib.load().ml_xyz_from_distance_host(dd.ctypes.data, 0, c.ctypes.data, k, out.ctypes.data))
+    return out.tolist()
 
 
 class _LocoOut(dict):
