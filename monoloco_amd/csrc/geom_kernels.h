@@ -230,6 +230,71 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ xl
 }
 
 // ------------------------------------------------------------------------------------------
+// A stereo FRAME's front in one launch (ml_loco_frame_stereo, ml + mr <= STEREO_FRONT_MAX persons): both pre-processes and the
+// all-vs-all pairing -- prep_kernel (left, with the box centres), prep_kernel (right) and pairs_kernel in sequence are three
+// dependent launches of ~5 us each for a few KiB of work.  Every workgroup loads all keypoints of the frame into LDS, normalises
+// them (the same cam_row per joint as prep_kernel: same bits) and writes ITS share of the line-format pair rows [L_i, L_i - R_j];
+// workgroup 0 also writes the left persons' box centres.  No workgroup depends on another.
+constexpr int STEREO_FRONT_MAX = 96;
+__global__ __launch_bounds__(256) void stereo_front_kernel(const float* __restrict__ kps_l, int ml, const float* __restrict__ kps_r,
+                                                           int mr, Kinv ki, float z_met, float* __restrict__ centre,
+                                                           char* __restrict__ lines, int kpad, int64_t rows_pad) {
+    __shared__ float s_in[STEREO_FRONT_MAX * KPS_ROW];
+    __shared__ float s_x[STEREO_FRONT_MAX * NIN];
+    const int t = threadIdx.x;
+    const int np = ml + mr;
+    for (int i = t; i < ml * KPS_ROW; i += 256) s_in[i] = kps_l[i];
+    for (int i = t; i < mr * KPS_ROW; i += 256) s_in[ml * KPS_ROW + i] = kps_r[i];
+    __syncthreads();
+    if (blockIdx.x == 0 && centre && t < ml) {   // get_keypoints(.., 'center') of the left persons (camera.py:82-86), as prep_kernel
+        const float* u = s_in + t * KPS_ROW;
+        const float* v = u + NKP;
+        float umin = u[0], umax = u[0], vmin = v[0], vmax = v[0];
+#pragma unroll
+        for (int j = 1; j < NKP; ++j) {
+            umin = __builtin_fminf(umin, u[j]);
+            umax = __builtin_fmaxf(umax, u[j]);
+            vmin = __builtin_fminf(vmin, v[j]);
+            vmax = __builtin_fmaxf(vmax, v[j]);
+        }
+        centre[t * 2 + 0] = __fadd_rn(__fmul_rn(__fsub_rn(umax, umin), 0.5f), umin);
+        centre[t * 2 + 1] = __fadd_rn(__fmul_rn(__fsub_rn(vmax, vmin), 0.5f), vmin);
+    }
+    for (int id = t; id < np * NKP; id += 256) {
+        const int pi = id / NKP, j = id - pi * NKP;
+        const float* u = s_in + pi * KPS_ROW;
+        s_x[pi * NIN + 2 * j] = cam_row(u[j], u[NKP + j], ki.k + 0, z_met);
+        s_x[pi * NIN + 2 * j + 1] = cam_row(u[j], u[NKP + j], ki.k + 3, z_met);
+    }
+    __syncthreads();
+    const int64_t rows = (int64_t)ml * mr;
+    const int cpr = kpad / 4;
+    const float* xl = s_x;
+    const float* xr = s_x + ml * NIN;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + t; id < rows_pad * cpr; id += (int64_t)gridDim.x * 256) {   // pairs_kernel's chunk
+        const int64_t row = id / cpr;
+        const int c = (int)(id - row * cpr);
+        const int b = c >> 3, sub = c & 7;
+        const int k0 = b * 32 + (sub & 3) * 8;
+        const int64_t i = row / mr, j = row - i * mr;
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            float val = 0.0f;
+            if (row < rows && k < 2 * NIN) {
+                if (k < NIN) val = xl[i * NIN + k];
+                else val = __fsub_rn(xl[i * NIN + k - NIN], xr[j * NIN + k - NIN]);
+            }
+            _Float16 hi, lo;
+            split_f16(val, hi, lo);
+            o[e] = (sub < 4) ? hi : lo;
+        }
+        *(half8*)(lines + id * 16) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // heads: raw[row][col0 + o] = sum_n act[row][n] * wh[o][n] + bh[o], o < NH, exact fp32 FMAs on
 // hi+lo reconstructed activations.  One wave per row (4 rows per pass to amortise the weight
 // reads from LDS), lanes stride over (hi chunk, lo chunk) pairs = 8 consecutive n, butterfly

@@ -1536,17 +1536,25 @@ int ml_loco_forward_mono(ml_loco* h, const float* kps_dev, int64_t m, const floa
 
 // the stereo pipeline up to the raw rows of all ml x mr pairs: both pre-processes, the all-vs-all pairing, the network
 static int stereo_front(ml_loco* h, const float* kps_l_dev, int64_t ml, const float* kps_r_dev, int64_t mr, const mlk::Kinv& ki,
-                        float* raw, hipStream_t st) {
+                        float* raw, hipStream_t st, bool one_launch = false) {
     int rc;
     const int64_t rows = ml * mr;
     if ((rc = ensure_rows(h, rows))) return rc;
     if ((rc = ensure_side(h, ml > mr ? ml : mr))) return rc;
-    if ((rc = launch_prep(st, kps_l_dev, ml, ki, 10.0f, h->d_xl, h->d_cl, (char*)nullptr, 0, ml, 0))) return rc;
-    if ((rc = launch_prep(st, kps_r_dev, mr, ki, 10.0f, h->d_xr, (float*)nullptr, (char*)nullptr, 0, mr, 0))) return rc;
     const int64_t rows_pad = round_up64(rows, 256);
     const int64_t chunks = rows_pad * (h->k0pad / 4);
-    hipLaunchKernelGGL(mlk::pairs_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, h->d_xl, ml, h->d_xr,
-                       mr, (float*)nullptr, h->buf[0], h->k0pad, rows_pad);
+    if (one_launch && ml + mr <= mlk::STEREO_FRONT_MAX) {
+        // a frame: both pre-processes and the pairing in ONE launch (stereo_front_kernel; same values as the three below)
+        int grid = (int)((chunks + 255) / 256);
+        if (grid > 64) grid = 64;
+        hipLaunchKernelGGL(mlk::stereo_front_kernel, dim3((unsigned)grid), dim3(256), 0, st, kps_l_dev, (int)ml, kps_r_dev, (int)mr, ki, 10.0f,
+                           h->d_cl, h->buf[0], h->k0pad, rows_pad);
+    } else {
+        if ((rc = launch_prep(st, kps_l_dev, ml, ki, 10.0f, h->d_xl, h->d_cl, (char*)nullptr, 0, ml, 0))) return rc;
+        if ((rc = launch_prep(st, kps_r_dev, mr, ki, 10.0f, h->d_xr, (float*)nullptr, (char*)nullptr, 0, mr, 0))) return rc;
+        hipLaunchKernelGGL(mlk::pairs_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, h->d_xl, ml, h->d_xr,
+                           mr, (float*)nullptr, h->buf[0], h->k0pad, rows_pad);
+    }
     HIP_TRY(hipGetLastError());
     return run_network(h, rows, raw ? raw : h->d_raw, st);
 }
@@ -1859,7 +1867,7 @@ int ml_loco_frame_stereo(ml_loco* h, const float* kps_l_host, int64_t ml, const 
         // launch (stereo_tail_frame_kernel); the tie counter is the second word of the handle's arrival block (0 between frames)
         if ((rc = check_ready(h))) return rc;
         if (h->in_f != 2 * mlk::NIN || h->out_f != 10) return fail(ML_ERR_SHAPE, "stereo pipeline needs a 68-input / 10-output model");
-        if ((rc = stereo_front(h, kl, ml, kr, mr, ki, nullptr, st))) return rc;
+        if ((rc = stereo_front(h, kl, ml, kr, mr, ki, nullptr, st, true))) return rc;
         fd.arrive = h->d_arrive;
         if (spin) {
             fd.flag = h->h_done;
