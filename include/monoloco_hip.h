@@ -431,7 +431,8 @@ int ml_loco_plan(const ml_loco* h, int64_t rows, int mc_dropout, int with_post, 
 /* Named switches of the route plan of ONE handle (A/B runs, tests): "mid_heads" (default 1; alias "half_heads"): in the mid window
  * both heads ride in the dense epilogues (dense_mid_kernel's, or the half-size dense_kernel_w4 tile's) and tail_mono_kernel ends the
  * call; 0 = heads_pair_kernel behind the last layer (rounds 3-4); "half_from" (default 4096): the half-size tile takes the long-K
- * layers of calls with more rows than this (inside the mid window). */
+ * layers of calls with more rows than this (inside the mid window); "small_multi" (default 1): small-row calls of more than 64 rows
+ * run dense_small_multi_kernel (a workgroup keeps its 16 weight rows and walks several row tiles), 0 = one tile per workgroup. */
 int ml_loco_set_option(ml_loco* h, const char* name, int value);
 /* Path selection of ONE handle, for tests / A-B runs that compare the paths (negative = leave unchanged; defaults 512 / 128 /
  * 0 / 4): rows <= small_rows take the small-row dense kernels, above small32_rows those use 32x32 tiles; chunk_rows > 0 walks

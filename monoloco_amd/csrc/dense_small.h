@@ -125,6 +125,113 @@ __global__ __launch_bounds__(SMALL_THREADS) void dense_small_kernel(DenseParams 
     *(half4*)(p.y + yoff + 64) = ol;
 }
 
+// dense_small_multi_kernel (round 5) -- the 16 x 16 tiles of dense_small_kernel, but a workgroup KEEPS its 16 weight rows in
+// registers and walks several row tiles with them.  Why: with one tile per workgroup a call of 80 .. 512 rows re-reads the 4 MB
+// weight matrix once per row tile (5 .. 32 times) and every tile pays the full operand latency; the layer's time followed the
+// tile count in steps (tools/sweep_small_rows.py: 52 us per forward up to 64 rows, 77 us at 80 .. 128, 145 at 256, 250 at 512).
+// Here the grid is (N/16, gy) with (N/16) * gy <= the CU count; workgroup (bx, by) takes row tiles by, by + gy, ...: its waves load
+// their share of the 16 weight rows ONCE (wave w: lines w, w + 4, ... -- at most 8 lines = 64 registers, K <= 1024), then per row
+// tile only the activations (requested one tile ahead into a second register set), 24 MFMAs, the 4-wave reduction through LDS
+// (double-buffered by tile parity: ONE barrier per tile) and wave 0's epilogue, which overlaps the other waves' next tile.
+// Same operands, same per-tile arithmetic and summation order as dense_small_kernel: bit-identical results.
+constexpr int SMALL_MULTI_MAX_LINES = 32;   // K <= 1024
+template <int NSPLIT, bool RELU, bool RES>
+__global__ __launch_bounds__(SMALL_THREADS) void dense_small_multi_kernel(DenseParams p, int n_row_tiles) {
+    __shared__ __attribute__((aligned(16))) float red[2][3][4][64];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16;
+    const int r = lane & 15, q = lane >> 4;
+    const size_t rowb = (size_t)p.K * 4;
+    const int nl = p.K / 32;
+
+    // this wave's weight fragments, for every row tile (lines past the end of K: never used)
+    half8 whi[8], wlo[8];
+    {
+        const char* wp = p.w + (size_t)(n0 + r) * rowb + q * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int l = w + 4 * i;
+            if (l < nl) {
+                whi[i] = *(const half8*)(wp + (size_t)l * LINE);
+                if (NSPLIT == 3) wlo[i] = *(const half8*)(wp + (size_t)l * LINE + 64);
+            }
+        }
+    }
+    const f32x4 bias4 = *(const f32x4*)(p.bias_scaled + n0 + 4 * q);   // bias * 2^e of weight rows n0 + 4q .. +3 (this lane's D rows)
+
+    struct XF {
+        half8 hi[8], lo[8];
+    };
+    auto fetch_x = [&](XF& f, int mt) {
+        const char* xp = p.x + (size_t)(mt * 16 + r) * rowb + q * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int l = w + 4 * i;
+            if (l < nl) {
+                f.hi[i] = *(const half8*)(xp + (size_t)l * LINE);
+                if (NSPLIT == 3) f.lo[i] = *(const half8*)(xp + (size_t)l * LINE + 64);
+            }
+        }
+    };
+    // one row tile: cur holds its activations; nxt receives those of the workgroup's next tile (if any)
+    auto tile = [&](XF& cur, XF& nxt, int mt, int par) {
+        const int mt_next = mt + (int)gridDim.y;
+        if (mt_next < n_row_tiles) fetch_x(nxt, mt_next);
+        const int m0 = mt * 16;
+        const size_t yoff = (size_t)(m0 + r) * ((size_t)p.N * 4) + (size_t)(n0 >> 5) * LINE + (size_t)((n0 & 16) + 4 * q) * 2;
+        half4 rh, rl;
+        if (RES && w == 0) {
+            rh = *(const half4*)(p.res + yoff);
+            rl = *(const half4*)(p.res + yoff + 64);
+        }
+        f32x4 acc = (w == 0) ? bias4 : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (w + 4 * i < nl) {
+                if (NSPLIT == 3) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[i], cur.lo[i], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[i], cur.hi[i], acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[i], cur.hi[i], acc, 0, 0, 0);
+            }
+        }
+        if (w > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[par][w - 1][e][lane] = acc[e];
+        }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += red[par][ww][e][lane];
+            half4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[e] * p.descale;
+                if (RELU) v = __builtin_fmaxf(v, 0.0f);
+                if (RES) v += (float)rh[e] + (float)rl[e];
+                _Float16 a, b;
+                split_f16(v, a, b);
+                oh[e] = a;
+                ol[e] = b;
+            }
+            *(half4*)(p.y + yoff) = oh;
+            *(half4*)(p.y + yoff + 64) = ol;
+        }
+    };
+    XF xa, xb;
+    int mt = blockIdx.y;
+    if (mt >= n_row_tiles) return;
+    fetch_x(xa, mt);
+    for (; mt < n_row_tiles; mt += 2 * (int)gridDim.y) {
+        tile(xa, xb, mt, 0);
+        if (mt + (int)gridDim.y < n_row_tiles) tile(xb, xa, mt + (int)gridDim.y, 1);
+    }
+}
+
 // dense_small32_kernel -- the same idea with 32 (n) x 32 (m) output tiles and v_mfma_f32_32x32x16_f16, for a few
 // hundred to ~2000 rows: a 16x16 tile re-reads 8 KiB of operands per output value from L2, a 32x32 tile half of
 // that, and above ~256 rows there are enough 32x32 tiles ((N/32) * ceil(rows/32) >= 256) to fill the chip.

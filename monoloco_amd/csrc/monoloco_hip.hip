@@ -161,6 +161,7 @@ struct Tuning {
     int tile_kernel = 4, tile_all = 0;
     int mid_rows = 8192, mid_tile = 0;
     int half_from = 4096;   // mid window, rows above this: the long-K layers on dense_kernel_w4's half-size tile (mid_tile 256 forces it)
+    int small_multi = 1;    // small-row window, > 64 rows: dense_small_multi_kernel (option "small_multi"; 0: one tile per workgroup, rounds 1-4)
     int half_heads = 1;     // the whole mid window: both heads ride in the dense epilogues (half-size w4 tile / dense_mid_kernel) + tail_mono_kernel
                             // (option "mid_heads"; 0: heads_pair_kernel behind the last layer, rounds 3-4)
 };
@@ -438,6 +439,12 @@ bool use_mid_path(const Tuning& tu, int precision, int64_t rows) {
     return precision != ML_PREC_BF16 && rows > tu.small_rows && rows <= tu.mid_rows;
 }
 
+// does a small-row layer of `rows` rows and reduction length K run on dense_small_multi_kernel (a workgroup keeps its weight rows and
+// walks several row tiles)?  From 65 rows on (up to 64 rows the 16 x 16 tiles are at most one per CU and a layer costs one latency)
+bool small_multi_runs(const Tuning& tu, int64_t rows, int K) {
+    return tu.small_multi && rows > 64 && K / 32 <= mlk::SMALL_MULTI_MAX_LINES;
+}
+
 // does the tile path run dense_kernel_w4 for a layer with this K (and fused head width)?
 bool w4_runs(const Tuning& tu, int K, int head_nh) {
     return tu.tile_kernel == 4 && K % 64 == 0 && (tu.tile_all || (K > 128 && head_nh <= 0));
@@ -525,10 +532,36 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
     if (rows >= 0 && head_nh == 0) {  // the caller chose the small-row path
         // 16x16 tiles while they are few (latency: more workgroups), 32x32 tiles (half the L2 traffic) once there
         // are at least ~256 of those
+        if (rows == 0) return ML_OK;
+        if (small_multi_runs(tu, rows, p.K)) {
+            // round 5: more than 64 rows -- workgroups keep their 16 weight rows and walk several row tiles (dense_small_multi_kernel);
+            // (N/16) * gy workgroups, at most one per CU
+            const int nrt = (int)((rows + 15) / 16);
+            int gy = num_cus() / (p.N / 16);
+            if (gy < 1) gy = 1;
+            if (gy > nrt) gy = nrt;
+            const dim3 mgrid((unsigned)(p.N / 16), (unsigned)gy);
+#define ML_SMM(NS, RL, RS) hipLaunchKernelGGL((mlk::dense_small_multi_kernel<NS, RL, RS>), mgrid, dim3(mlk::SMALL_THREADS), 0, st, p, nrt)
+#define ML_SMM_NS(NS)                                  \
+    do {                                               \
+        if (p.relu) {                                  \
+            if (p.res) ML_SMM(NS, true, true);         \
+            else ML_SMM(NS, true, false);              \
+        } else {                                       \
+            if (p.res) ML_SMM(NS, false, true);        \
+            else ML_SMM(NS, false, false);             \
+        }                                              \
+    } while (0)
+            if (precision == ML_PREC_F16X2) ML_SMM_NS(3);
+            else ML_SMM_NS(1);
+#undef ML_SMM_NS
+#undef ML_SMM
+            HIP_TRY(hipGetLastError());
+            return ML_OK;
+        }
         const bool t32 = rows > tu.small32_rows;
         const int T = t32 ? 32 : 16;
         const dim3 grid((unsigned)(p.N / T), (unsigned)((rows + T - 1) / T));
-        if (grid.y == 0) return ML_OK;
 #define ML_SM(NS, RL, RS)                                                                                              \
     do {                                                                                                               \
         if (t32) hipLaunchKernelGGL((mlk::dense_small32_kernel<NS, RL, RS>), grid, dim3(mlk::SMALL_THREADS), 0, st, p); \
@@ -715,7 +748,8 @@ struct RoutePlan {
 };
 
 int route_family(const ml_loco* h, int64_t rows) {
-    if (use_small_path(h->tune, h->precision, rows)) return rows > h->tune.small32_rows ? ML_ROUTE_SMALL32 : ML_ROUTE_SMALL16;
+    if (use_small_path(h->tune, h->precision, rows))
+        return (rows > h->tune.small32_rows && !small_multi_runs(h->tune, rows, h->hidden)) ? ML_ROUTE_SMALL32 : ML_ROUTE_SMALL16;
     if (use_mid_path(h->tune, h->precision, rows)) {
         const int64_t m_pad = round_up64(rows, 256);
         if (use_half_tile(h->tune, h->precision, rows)) return ML_ROUTE_HALF;
@@ -805,7 +839,7 @@ RoutePlan make_plan(const ml_loco* h, int64_t rows, bool mc_on) {
             s.family = half ? FAM_HALF : (pl.route == ML_ROUTE_MID64 ? FAM_MID64 : (pl.route == ML_ROUTE_MID128 ? FAM_MID128 :
                        ((round_up64(rows, 256) / 128) * (L.n / mlk::MID_TN) >= num_cus() ? FAM_MID128 : FAM_MID64)));
         } else if (pl.small) {
-            s.family = rows > h->tune.small32_rows ? FAM_SMALL32 : FAM_SMALL16;
+            s.family = (rows > h->tune.small32_rows && !small_multi_runs(h->tune, rows, L.kpad)) ? FAM_SMALL32 : FAM_SMALL16;
         } else {
             s.family = w4_runs(h->tune, L.kpad, s.fused_fin ? s.fused_fin->nh : (s.fused_aux ? -1 : 0)) ? FAM_W4 : FAM_PP;
         }
@@ -1736,6 +1770,7 @@ int ml_loco_set_option(ml_loco* h, const char* name, int value) {
     const std::string n(name);
     if (n == "mid_heads" || n == "half_heads") h->tune.half_heads = value ? 1 : 0;
     else if (n == "half_from") h->tune.half_from = value;
+    else if (n == "small_multi") h->tune.small_multi = value ? 1 : 0;
     else return fail(ML_ERR_ARG, "unknown option '%s'", name);
     ++h->tune_version;
     return ML_OK;

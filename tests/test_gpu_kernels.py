@@ -316,3 +316,31 @@ def test_post_geometry_block_matches_oracle_and_strided_distances(hip_lib, cuda_
     xyz = O.xyz_from_distance(d.view(-1, 1), xy)
     assert (geo[:, 9:12] - xyz).abs().max() <= 1e-4 * 40
     assert engine.post_geometry(kps[:0].to(cuda_device), synth.KITTI_K, None, device=cuda_device).shape == (0, 12)
+
+
+@pytest.mark.parametrize("mode", ["mono", "stereo"])
+@pytest.mark.parametrize("m", [65, 80, 128, 129, 200, 333, 512])
+def test_small_multi_row_tiles_same_bits(hip_lib, cuda_device, m, mode):
+    """Round 5: above 64 rows the small-row layers run dense_small_multi_kernel (a workgroup keeps its 16 weight rows in registers
+    and walks several row tiles) -- same operands, same per-tile arithmetic and summation order as one 16 x 16 tile per workgroup:
+    the raw outputs are bit-identical to that route, and within the usual bar of the 32 x 32-tile route and of fp64."""
+    from monoloco_amd import engine
+    from oracle import monoloco_oracle as O
+    in_f, out_f = (34, 9) if mode == "mono" else (68, 10)
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(8, in_features=in_f, out_features=out_f).items()}
+    rng = np.random.default_rng(m)
+    x = torch.tensor((rng.standard_normal((m, in_f)) * 3).astype(np.float32), device=cuda_device)
+    eng = engine.LocoEngine(sd, device=cuda_device)
+    assert "small16" in eng.plan_for_rows(m, with_post=False)
+    raw_multi = eng.forward_raw(x).cpu()
+    eng.set_option('small_multi', 0)
+    eng.set_tuning(small32_rows=100000)
+    raw_t16 = eng.forward_raw(x).cpu()
+    eng.set_tuning(small32_rows=0)
+    raw_t32 = eng.forward_raw(x).cpu()
+    assert torch.equal(raw_multi, raw_t16)
+    ref64 = O.loco_forward(sd, x.cpu(), dtype=torch.float64)
+    scale = max(1.0, ref64.abs().max().item())
+    assert (raw_multi.double() - ref64).abs().max().item() <= 1e-4
+    assert (raw_multi - raw_t32).abs().max().item() <= 2e-6 * scale
+    eng.close()
