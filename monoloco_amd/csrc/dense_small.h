@@ -130,8 +130,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void dense_small_kernel(DenseParams 
 // weight matrix once per row tile (5 .. 32 times) and every tile pays the full operand latency; the layer's time followed the
 // tile count in steps (tools/sweep_small_rows.py: 52 us per forward up to 64 rows, 77 us at 80 .. 128, 145 at 256, 250 at 512).
 // Here the grid is (N/16, gy) with (N/16) * gy <= the CU count; workgroup (bx, by) takes row tiles by, by + gy, ...: its waves load
-// their share of the 16 weight rows ONCE (wave w: lines w, w + 4, ... -- at most 8 lines = 64 registers, K <= 1024), then per row
-// tile only the activations (requested one tile ahead into a second register set), 24 MFMAs, the 4-wave reduction through LDS
+// their share of the 16 weight rows ONCE (wave w: lines w, w + 4, ... -- at most 8 lines = 64 registers, K <= 1024) together with
+// the activations of their first two row tiles (two register sets, re-requested two tiles ahead), then per row tile 24 MFMAs, the
+// 4-wave reduction through LDS
 // (double-buffered by tile parity: ONE barrier per tile) and wave 0's epilogue, which overlaps the other waves' next tile.
 // Same operands, same per-tile arithmetic and summation order as dense_small_kernel: bit-identical results.
 constexpr int SMALL_MULTI_MAX_LINES = 32;   // K <= 1024
@@ -175,10 +176,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void dense_small_multi_kernel(DenseP
             }
         }
     };
-    // one row tile: cur holds its activations; nxt receives those of the workgroup's next tile (if any)
-    auto tile = [&](XF& cur, XF& nxt, int mt, int par) {
-        const int mt_next = mt + (int)gridDim.y;
-        if (mt_next < n_row_tiles) fetch_x(nxt, mt_next);
+    // one row tile: cur holds its activations; once its MFMAs are issued the set is re-requested for the tile after next
+    auto tile = [&](XF& cur, int mt, int par) {
         const int m0 = mt * 16;
         const size_t yoff = (size_t)(m0 + r) * ((size_t)p.N * 4) + (size_t)(n0 >> 5) * LINE + (size_t)((n0 & 16) + 4 * q) * 2;
         half4 rh, rl;
@@ -197,6 +196,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void dense_small_multi_kernel(DenseP
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[i], cur.hi[i], acc, 0, 0, 0);
             }
         }
+        const int mt_again = mt + 2 * (int)gridDim.y;
+        if (mt_again < n_row_tiles) fetch_x(cur, mt_again);
         if (w > 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) red[par][w - 1][e][lane] = acc[e];
@@ -222,13 +223,16 @@ __global__ __launch_bounds__(SMALL_THREADS) void dense_small_multi_kernel(DenseP
             *(half4*)(p.y + yoff + 64) = ol;
         }
     };
+    // the activations of the workgroup's first TWO row tiles are requested together with the weights: one memory latency for all
+    // three (up to 128 rows a workgroup has at most two tiles: nothing is requested later)
     XF xa, xb;
     int mt = blockIdx.y;
     if (mt >= n_row_tiles) return;
     fetch_x(xa, mt);
+    if (mt + (int)gridDim.y < n_row_tiles) fetch_x(xb, mt + (int)gridDim.y);
     for (; mt < n_row_tiles; mt += 2 * (int)gridDim.y) {
-        tile(xa, xb, mt, 0);
-        if (mt + (int)gridDim.y < n_row_tiles) tile(xb, xa, mt + (int)gridDim.y, 1);
+        tile(xa, mt, 0);
+        if (mt + (int)gridDim.y < n_row_tiles) tile(xb, mt + (int)gridDim.y, 1);
     }
 }
 

@@ -442,7 +442,9 @@ bool use_mid_path(const Tuning& tu, int precision, int64_t rows) {
 // does a small-row layer of `rows` rows and reduction length K run on dense_small_multi_kernel (a workgroup keeps its weight rows and
 // walks several row tiles)?  From 65 rows on (up to 64 rows the 16 x 16 tiles are at most one per CU and a layer costs one latency)
 bool small_multi_runs(const Tuning& tu, int64_t rows, int K) {
-    return tu.small_multi && rows > 64 && K / 32 <= mlk::SMALL_MULTI_MAX_LINES;
+    // ... up to 128: a workgroup then has at most two row tiles, both requested with the weights (beyond, the 32 x 32 tiles win:
+    // tools/sweep_small_rows.py)
+    return tu.small_multi && rows > 64 && rows <= 128 && K / 32 <= mlk::SMALL_MULTI_MAX_LINES;
 }
 
 // does the tile path run dense_kernel_w4 for a layer with this K (and fused head width)?

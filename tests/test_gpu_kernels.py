@@ -319,7 +319,7 @@ def test_post_geometry_block_matches_oracle_and_strided_distances(hip_lib, cuda_
 
 
 @pytest.mark.parametrize("mode", ["mono", "stereo"])
-@pytest.mark.parametrize("m", [65, 80, 128, 129, 200, 333, 512])
+@pytest.mark.parametrize("m", [65, 80, 100, 128])
 def test_small_multi_row_tiles_same_bits(hip_lib, cuda_device, m, mode):
     """Round 5: above 64 rows the small-row layers run dense_small_multi_kernel (a workgroup keeps its 16 weight rows in registers
     and walks several row tiles) -- same operands, same per-tile arithmetic and summation order as one 16 x 16 tile per workgroup:
