@@ -6,8 +6,8 @@ Two situations, one call (``monoloco_amd.compat.install()``):
   replaced wholesale: the reference's modules keep every name this repository does not implement
   (``monoloco.utils.get_task_error``, ``open_image``, ``monoloco.prep``, ``monoloco.eval`` ...).  Only the names of
   the keypoint->3D path are re-bound -- on ``monoloco.network``, ``monoloco.network.net``,
-  ``monoloco.network.process``, ``monoloco.network.architectures``, ``monoloco.utils`` and
-  ``monoloco.utils.camera`` -- and in every already-imported ``monoloco.*`` module that holds a
+  ``monoloco.network.process``, ``monoloco.network.architectures``, ``monoloco.utils``,
+  ``monoloco.utils.camera`` and ``monoloco.utils.iou`` -- and in every already-imported ``monoloco.*`` module that holds a
   ``from ..network import Loco``-style copy of one of them (``monoloco.predict``, ``monoloco.eval.generate_kitti``,
   ``monoloco.visuals.printer`` ...).  Modules imported later pick the patched names up from the packages.
   The reference callers (predict.py:31, visuals/webcam.py:25, eval/generate_kitti.py:14-18,
@@ -30,6 +30,10 @@ _PROCESS = ('preprocess_pifpaf', 'prepare_pif_kps', 'factory_for_gt', 'load_cali
             'extract_labels_aux', 'cluster_outputs', 'filter_outputs', 'laplace_sampling')
 _ARCH = ('LocoModel', 'MonolocoModel')
 _CAMERA = ('pixel_to_camera', 'get_keypoints', 'xyz_from_distance', 'to_cartesian', 'back_correct_angles')
+# ground-truth association (utils/iou.py): the same matches, one native call per image instead of m x g Python calls (round 5) --
+# Loco.post_process uses them here; the reference's other callers (eval/eval_kitti.py:21, eval/eval_activity.py:20,
+# prep/preprocess_kitti.py:19) get them too
+_IOU = ('calculate_iou', 'get_iou_matrix', 'get_iou_matches', 'get_iou_matches_matrix', 'reorder_matches')
 _TRAIN = ('Trainer',)   # only with install(trainer=True): `python -m monoloco.run train` then trains on the HIP step
 
 _saved = []  # (module, name, original object, existed) of everything install() re-bound
@@ -62,7 +66,7 @@ def install(trainer=False):
     import importlib.util  # noqa: F401  (find_spec)
     from . import activity, formats, network, train, utils  # noqa: F401  (import everything that gets an alias)
     from .network import architectures, net, process
-    from .utils import camera
+    from .utils import camera, iou
 
     if not _reference_available():
         # stand-alone: `monoloco` IS this package; every loaded submodule gets the matching alias so that
@@ -76,9 +80,9 @@ def install(trainer=False):
 
     import monoloco  # the reference
     ref = {key: importlib.import_module('monoloco.' + key)
-           for key in ('network', 'network.net', 'network.process', 'network.architectures', 'utils', 'utils.camera')}
+           for key in ('network', 'network.net', 'network.process', 'network.architectures', 'utils', 'utils.camera', 'utils.iou')}
     groups = [(_NET, net, 'network.net'), (_PROCESS, process, 'network.process'), (_ARCH, architectures, 'network.architectures'),
-              (_CAMERA, camera, 'utils.camera')]
+              (_CAMERA, camera, 'utils.camera'), (_IOU, iou, 'utils.iou')]
     if trainer:
         from .train import trainer as our_trainer
         for key in ('train', 'train.trainer'):
