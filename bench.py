@@ -343,11 +343,18 @@ def power_probe(step, dev, seconds=1.5):
         return {"error": repr(e)[:200]}
 
 
-def _ms(fn, iters, warmup, dev):
-    """Wall-clock ms per call of an asynchronous device call: warm-up, sync, `iters` calls, sync."""
+def _ms(fn, iters, warmup, dev, min_warm_s=0.05):
+    """Wall-clock ms per call of an asynchronous device call: warm-up, sync, `iters` calls, sync.  The warm-up lasts at least
+    `min_warm_s` of device work as well as `warmup` calls: the parity legs run the CPU oracle for seconds between two timed legs, the
+    GPU drops to its idle clocks meanwhile, and ten 150-us calls do not bring them back (round 6: the mid-size rows read 8 % low)."""
     import torch
-    for _ in range(warmup):
+    t_w = time.perf_counter()
+    n_w = 0
+    while n_w < warmup or time.perf_counter() - t_w < min_warm_s:
         fn()
+        n_w += 1
+        if n_w % 8 == 0:
+            torch.cuda.synchronize(dev)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(iters):
@@ -409,7 +416,77 @@ def parity_of_timed_run(sd, kps, conf, xyzds, raw, kk, packed=None, chunk=8192, 
     return res
 
 
-def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
+def train_parity(sd_t, x, y, dev):
+    """Deviation of ONE training step of the route this batch size takes (dropout 0, no update: the same kernels the timed steps ran,
+    minus the dropout masks, which come from a device RNG the CPU cannot replay) from the CPU oracle of the reference's loop body
+    (oracle/train_oracle.py: trainer.py:150-161 + losses.py:59-131 under torch autograd) run in fp64, next to the SAME oracle in fp32
+    (= the reference's own arithmetic) against that fp64 run: loss values, every train-mode output row, every gradient tensor (worst
+    element over the tensor's largest entry; rms error over the tensor's rms).  Bars = tests/test_gpu_train.py::
+    test_headline_batch_training_step_against_fp64_oracle: as close to exact as the reference's arithmetic, times a stated factor."""
+    import torch
+    from monoloco_amd.train import HipTrainer
+    from oracle.train_oracle import OracleTrainer
+    t0 = time.perf_counter()
+    tr = HipTrainer(sd_t, p_dropout=0.0, lr=0.001, device=dev)
+    res, out = tr.step(x, y, update=False, want_outputs=True)
+    route = tr.last_route
+    g = tr.grads()
+    out = out.cpu()
+    tr.close()
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(host_threads())
+    xc, yc = x.cpu(), y.cpu()
+    orc = OracleTrainer(sd_t, lr=0.001, dtype=torch.float64)
+    r64, out64 = orc.step(xc.double(), yc.double(), update=False)
+    g64 = orc.grads()
+    del orc
+    orc = OracleTrainer(sd_t, lr=0.001)
+    r32, out32 = orc.step(xc, yc, update=False)
+    g32 = orc.grads()
+    del orc
+    torch.set_num_threads(prev_threads)
+    names = [n for n in ('loss', 'd', 'x', 'y', 'h', 'w', 'l', 'ori') if n in r64]
+    e_loss = max(abs(res[n] - r64[n]) / max(1.0, abs(r64[n])) for n in names)
+    n_loss = max(abs(r32[n] - r64[n]) / max(1.0, abs(r64[n])) for n in names)
+    e_out = float((out.double() - out64).abs().max())
+    n_out = float((out32.double() - out64).abs().max())
+
+    def rel(a, ref):
+        d = a.double() - ref
+        return float(d.abs().max()) / (float(ref.abs().max()) + 1e-300), float(d.pow(2).mean().sqrt()) / (float(ref.pow(2).mean().sqrt()) + 1e-300)
+    worst = {"element": (0.0, 0.0, None), "rms": (0.0, 0.0, None)}
+    ok, n_t = True, 0
+    for k, v in g.items():
+        # a Linear bias in front of a BatchNorm has a mathematically zero gradient (the batch mean absorbs it): rounding noise on every side
+        if k.endswith('.bias') and 'batch_norm' not in k and not k.startswith(('w_aux', 'w_fin', 'w2.')):
+            continue
+        mx, rms = rel(v, g64[k])
+        mx32, rms32 = rel(g32[k], g64[k])
+        n_t += 1
+        ok = ok and mx <= max(3.0 * mx32, 3e-3) and rms <= 4.0 * max(rms32, 2.5e-5)
+        if mx > worst["element"][0]:
+            worst["element"] = (mx, mx32, k)
+        if rms > worst["rms"][0]:
+            worst["rms"] = (rms, rms32, k)
+    ok = ok and e_loss <= 2e-5 and e_out <= 2.0 * n_out + 2e-5
+    f = lambda v: float('%.3e' % v)
+    return {"route": route, "rows": int(x.shape[0]), "ok": bool(ok),
+            "max_rel_loss_values_vs_fp64": f(e_loss), "fp32_oracle_loss_values_vs_fp64": f(n_loss),
+            "max_abs_outputs_vs_fp64": f(e_out), "fp32_oracle_outputs_vs_fp64": f(n_out),
+            "gradients_vs_fp64": {"tensors": n_t,
+                                  "worst_element_over_tensor_max": f(worst["element"][0]), "fp32_oracle_same_tensor": f(worst["element"][1]),
+                                  "worst_element_tensor": worst["element"][2],
+                                  "worst_rms_over_tensor_rms": f(worst["rms"][0]), "fp32_oracle_same_tensor_rms": f(worst["rms"][1]),
+                                  "worst_rms_tensor": worst["rms"][2]},
+            "bars": "loss values 2e-5 relative; outputs 2 x the fp32 oracle's own distance from fp64 + 2e-5; per gradient tensor: worst element <= "
+                    "max(3 x the fp32 oracle's, 3e-3 of the tensor's maximum) -- a ReLU mask of a pre-activation within rounding of zero flips "
+                    "between any two fp32 implementations and moves single entries -- and rms <= 4 x max(the fp32 oracle's, 2.5e-5); Linear "
+                    "biases in front of a BatchNorm (mathematically zero gradient) excluded",
+            "against": "oracle/train_oracle.OracleTrainer (torch CPU autograd) in fp64 and fp32 on the whole batch, dropout 0, one step without "
+                       "update (%.1f s)" % (time.perf_counter() - t0)}
+
+
+def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms, main_out=None):
     """The other BASELINE configs and comparison modes, a few timed iterations each (N = 1 only)."""
     import numpy as np
     import torch
@@ -425,6 +502,9 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         torch.cuda.synchronize(dev)
 
     m = kps.shape[0]
+    sd_t = {k: torch.tensor(v) for k, v in sd.items()}
+    same_as_main = ("bit-identical to the outputs of the timed loop's last step, whose deviation from the oracle on every row is the "
+                    "line's `parity` block")
 
     def e2e():
         kps_pin = kps.cpu().pin_memory()
@@ -461,6 +541,9 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
                "within_1p3x_of_expected": bool(ms <= 1.3 * expect),
                "note": "pinned H2D of kps+conf, the step, pinned D2H of the (m,16) packed result and the (m,5) parity block, "
                        "device sync per step, median of 40 after 8 warm-up round trips; never reported as `value`"}
+        if main_out is not None:    # the round trip over the link returns what the HBM-resident step computed
+            res["parity"] = {"same_bits_as_timed_step": bool(torch.equal(o_pin, main_out[0].cpu()) and torch.equal(x_pin, main_out[1].cpu())),
+                             "note": same_as_main}
         if ms > 1.3 * expect:
             res["why_slower"] = ("median %.2f ms against %.2f expected: the copies of this box run below 25 GB/s "
                                  "(h2d+d2h alone: %.2f ms at the measured difference)" % (ms, expect, ms - main_ms))
@@ -510,7 +593,11 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         run(n)
         ms = (time.perf_counter() - t0) / n * 1e3
         same = bool(torch.equal(op[0], op[1]))   # both buffers carry the same batch: identical results expected
-        return {"e2e_pipelined_ms": round(ms, 4), "persons_per_s": round(m / ms * 1e3, 1), "buffers_agree": same,
+        par = None
+        if main_out is not None:
+            par = {"same_bits_as_timed_step": bool(torch.equal(op[0], main_out[0].cpu()) and torch.equal(xp[1], main_out[1].cpu())),
+                   "note": same_as_main}
+        return {"e2e_pipelined_ms": round(ms, 4), "persons_per_s": round(m / ms * 1e3, 1), "buffers_agree": same, "parity": par,
                 "note": "H2D / compute / D2H on three HIP streams, two buffers each; per batch over 20 back-to-back batches"}
     guarded("e2e_pipelined", e2e_pipelined)
 
@@ -521,10 +608,36 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         kr = torch.tensor(synth.make_keypoints(128, seed=301)).to(dev)
         cf = torch.rand(256, device=dev)
         ms = _ms(lambda: eng_s.forward_stereo(kl, kr, kinv, box_conf=cf), 20, 5, dev)
+        # the same call once more with every pair row's raw output kept: all 32768 rows against the oracle, the per-left winner and
+        # the (x, y, z, d, sigma) of the winners
+        from oracle import monoloco_oracle as O
+        got = eng_s.forward_stereo(kl, kr, kinv, box_conf=cf, want_raw_all=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        prev_threads = torch.get_num_threads()
+        torch.set_num_threads(host_threads())
+        ref = O.forward_stereo({k: torch.tensor(v) for k, v in sd_s.items()}, kl.cpu(), kr.cpu(), kk, box_conf=cf.cpu())
+        torch.set_num_threads(prev_threads)
+        raw_all = got['raw_all'].cpu()
+        err = (raw_all - ref['raw_all']).abs()
+        e_cols = float(err[:, :9].max())
+        # (the aux logit of a non-matching pair is -50 .. -90 on a trained net: fp32 holds it to 4e-6 relative; judged as its sigmoid too)
+        e_aux = float((err[:, 9] - 4e-6 * ref['raw_all'][:, 9].abs()).max())
+        e_sig = float((torch.sigmoid(raw_all[:, 9]) - torch.sigmoid(ref['raw_all'][:, 9])).abs().max())
+        best_ref = ref['raw_all'].view(256, 128, 10)[:, :, -1].argmax(1)
+        same_winner = got['best'].cpu().long() == best_ref
+        par = {"rows_checked": 32768, "max_abs_raw_cols_0_8": float('%.3e' % e_cols), "max_abs_aux_logit_minus_4e-6_rel": float('%.3e' % e_aux),
+               "max_abs_aux_sigmoid": float('%.3e' % e_sig), "winners_equal": int(same_winner.sum()), "winners": 256,
+               "ties_reported": int(got['ties'].item()), "tolerance": 1e-4,
+               "against": "oracle/monoloco_oracle.forward_stereo (torch CPU fp32) on EVERY pair row (%.1f s)" % (time.perf_counter() - t0)}
+        if 'xyzds' in ref and bool(same_winner.all()):
+            par["max_abs_xyzds_of_winners"] = float('%.3e' % float((got['xyzds'].cpu() - ref['xyzds']).abs().max()))
+        elif 'xyzds' in ref:   # a near-tie resolved the other way: compare the rows whose winner agrees
+            par["max_abs_xyzds_of_winners"] = float('%.3e' % float((got['xyzds'].cpu() - ref['xyzds'])[same_winner].abs().max()))
         eng_s.close()
         return {"config": "BASELINE configs[2]: MonStereo 68->1024->10, 256 x 128 all-vs-all = 32768 pair rows, 1 GPU",
                 "ms_per_step": round(ms, 4), "pair_rows_per_s": round(32768 / ms * 1e3, 1),
-                "algorithmic_tflops": round(FLOP_PER_ROW['stereo'] * 32768 / ms / 1e9, 2)}
+                "algorithmic_tflops": round(FLOP_PER_ROW['stereo'] * 32768 / ms / 1e9, 2), "parity": par}
     guarded("stereo_32768", stereo)
 
     def train():
@@ -535,9 +648,9 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
                          "on the exact fp32 MFMA reading the row-major tensors as they lie (launch list: profiles/r04_train_kernel_stats_rows331.txt) -> fraction of "
                          "the 157 TF fp32-MFMA peak.  From 4096 rows the hidden-layer GEMMs run on the 3-product fp16 MFMA "
                          "kernel (fp32-class accuracy): fraction of the 833 TF (2500 / 3) a 3-product scheme can reach"}
-        sd_t = {k: torch.tensor(v) for k, v in synth.make_state_dict(31, 34, 9, 1024).items()}
+        sd_tr = {k: torch.tensor(v) for k, v in synth.make_state_dict(31, 34, 9, 1024).items()}
         for tag, rows in (("fixture_331", 331), ("batch_512", 512), ("batch_65536", 65536)):
-            tr = HipTrainer(sd_t, p_dropout=0.2, lr=0.001, device=dev)
+            tr = HipTrainer(sd_tr, p_dropout=0.2, lr=0.001, device=dev)
             if rows == 331:
                 x, y = torch.tensor(g['mono_x']).to(dev), torch.tensor(g['mono_y']).to(dev)
             else:
@@ -555,6 +668,8 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
             else:
                 res[tag]["frac_of_f32_mfma_peak"] = round(tf / PEAK_TFLOPS_F32_MFMA, 4)
             tr.close()
+            if not args.no_parity:
+                res[tag]["parity"] = train_parity(sd_tr, x, y, dev)
         return res
     guarded("train", train)
 
@@ -601,6 +716,34 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
                            "row-gather launches per batch, and the epoch bookkeeping"}
             tr.hip.close()
             tr2.hip.close()
+            if not args.no_parity:
+                # the run above draws dropout masks from a device RNG the CPU cannot replay: the SAME ten optimisation steps (one
+                # 331-row fixture batch per epoch, Adam, per-batch StepLR, clip 3) with dropout 0 against the oracle's loop
+                from monoloco_amd.train import HipTrainer
+                from oracle.train_oracle import OracleTrainer
+                sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(33, 34, 9, 1024).items()}
+                xf, yf = torch.tensor(g['mono_x']), torch.tensor(g['mono_y'])
+                ht = HipTrainer(sd0, p_dropout=0.0, lr=0.001, sched_step=30, sched_gamma=0.98, device=dev)
+                ot = OracleTrainer(sd0, lr=0.001, sched_step=30, sched_gamma=0.98)
+                o64 = OracleTrainer(sd0, lr=0.001, sched_step=30, sched_gamma=0.98, dtype=torch.float64)
+                names_ = ('loss', 'd', 'x', 'y', 'h', 'w', 'l', 'ori')
+                ours, ref32 = [], []
+                for _ in range(10):
+                    a_, b_, c_ = ht.step(xf, yf), ot.step(xf, yf)[0], o64.step(xf.double(), yf.double())[0]
+                    ours.append(max(abs(a_[n] - c_[n]) / max(1.0, abs(c_[n])) for n in names_))
+                    ref32.append(max(abs(b_[n] - c_[n]) / max(1.0, abs(c_[n])) for n in names_))
+                ht.close()
+                # step 1 is a pure function of the inputs (bar 2e-5).  From step 2 on every parameter has moved by +-lr * sign(g) (Adam's
+                # first update): gradients within rounding of zero take either sign in any two implementations, and on seeded synthetic
+                # weights the loss falls 40x in three steps -- the trajectory itself is ill-conditioned, which the fp32 oracle's own distance
+                # from the fp64 run on the same steps shows (tests/test_gpu_train_mid.py::test_mid_route_trajectory_tracks_exact_route)
+                res["parity"] = {"steps": 10, "first_step_max_rel_loss_values_vs_fp64": float('%.3e' % ours[0]), "first_step_bar": 2e-5,
+                                 "per_step_max_rel_vs_fp64": [float('%.2e' % v) for v in ours],
+                                 "fp32_oracle_per_step_max_rel_vs_fp64": [float('%.2e' % v) for v in ref32],
+                                 "ok": bool(ours[0] <= 2e-5 and all(o <= max(4.0 * r, 2e-3) for o, r in zip(ours, ref32))),
+                                 "bars": "step 1: 2e-5; later steps: max(4 x the fp32 oracle's own deviation from the fp64 run at that step, 2e-3)",
+                                 "against": "oracle/train_oracle.OracleTrainer (trainer.py:150-161 under torch CPU autograd) in fp64 and fp32, the "
+                                            "same ten steps (one 331-row fixture batch, Adam, per-batch StepLR, clip 3) at dropout 0"}
             return res
     guarded("train_epoch", train_epoch)
 
@@ -613,23 +756,35 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
         o4 = torch.empty((rows, 16), dtype=torch.float32, device=dev)
         x4 = torch.empty((rows, 5), dtype=torch.float32, device=dev)
         eng.reserve(rows)
-        ms = _ms(lambda: eng.forward_mono(k4, kinv, box_conf=c4, out=o4, xyzds=x4), 4, 1, dev)
-        return {"config": "BASELINE configs[3] on one GPU: 1,048,576 persons per step", "ms_per_step": round(ms, 4),
-                "persons_per_s": round(rows / ms * 1e3, 1)}
+        r4 = torch.empty((rows, eng.out_features), dtype=torch.float32, device=dev)
+        ms = _ms(lambda: eng.forward_mono(k4, kinv, box_conf=c4, out=o4, xyzds=x4, raw=r4), 4, 1, dev)
+        res = {"config": "BASELINE configs[3] on one GPU: 1,048,576 persons per step", "ms_per_step": round(ms, 4),
+               "persons_per_s": round(rows / ms * 1e3, 1)}
+        if not args.no_parity:   # every 61st row (prime: the sample walks through every position of a 256-row tile) = 17190 rows
+            res["parity"] = parity_of_timed_run(sd, k4, c4, x4, r4, kk, o4, every=61)
+        return res
     guarded("config4_1M_rows_one_gpu", config4)
 
     def other_batches():
         # row counts between one image and the headline batch (a video batch, a handful of camera streams): the same pipeline, the
         # dense layers on the kernel the engine picks for that row count (small-row <= 512 < dense_mid_kernel <= 8192 < 256x256 tiles)
         res = {"config": "the same mono pipeline at other batch sizes, one GPU; route = the dense kernel family the engine chooses"}
+        kept = {}
         for rows in (1024, 2048, 4096, 6144, 8192, 16384):
             k = kps[:rows].contiguous()
             c = conf[:rows].contiguous()
             o = torch.empty((rows, 16), dtype=torch.float32, device=dev)
             x = torch.empty((rows, 5), dtype=torch.float32, device=dev)
-            ms = _ms(lambda: eng.forward_mono(k, kinv, box_conf=c, out=o, xyzds=x), 60, 10, dev)
+            r = torch.empty((rows, eng.out_features), dtype=torch.float32, device=dev)
+            ms = _ms(lambda: eng.forward_mono(k, kinv, box_conf=c, out=o, xyzds=x, raw=r), 60, 10, dev)
             res["rows_%d" % rows] = {"us_per_step": round(ms * 1e3, 1), "persons_per_s": round(rows / ms * 1e3, 1),
                                      "route": eng.route_for_rows(rows)}
+            kept[rows] = (k, c, o, x, r)
+        if not args.no_parity:   # every row of the timed calls' outputs (behind all the timings: the oracle idles the GPU for seconds)
+            for rows, (k, c, o, x, r) in kept.items():
+                par = parity_of_timed_run(sd, k, c, x, r, kk, o)
+                res["rows_%d" % rows]["parity"] = {kk_: par[kk_] for kk_ in ("max_abs_xyzds", "max_abs_raw", "rows_checked", "tolerance",
+                                                                            "max_abs_z_spherical")}
         return res
     guarded("other_batches", other_batches)
 
@@ -688,7 +843,7 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
             net_s.forward(kpl, kk1, keypoints_r=kpr)
         ts = time.perf_counter()
         for _ in range(n):
-            net_s.forward(kpl, kk1, keypoints_r=kpr)
+            dic_s = net_s.forward(kpl, kk1, keypoints_r=kpr)
         res["stereo_loco_forward_us"] = round((time.perf_counter() - ts) / n * 1e6, 1)
         net_s.engine.close()
         # with ground truth, as GenerateKitti calls it on every image (reference eval/generate_kitti.py:114-132): IoU of all
@@ -702,6 +857,8 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
             net.post_process(dic, boxes, kpl, kk1, dic_gt=dic_gt)
         res["post_process_with_gt_us"] = round((time.perf_counter() - t3) / n * 1e6, 1)
         res["post_process_with_gt_matches"] = int(sum(out['gt']))
+        from monoloco_amd.utils import iou as _iou0
+        out_matches = _iou0.get_iou_matches_ordered(boxes, dic_gt['boxes'])
         # an image crowd of 2048 detections against 2048 ground-truth boxes: matching alone (the IoUs on the device from 32768
         # pairs on); the reference's scalar Python loop needs seconds here
         import synth as _synth
@@ -714,6 +871,29 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms):
                 found = _iou.get_iou_matches_ordered(bx, gx)
             res["gt_matching_%d_boxes_ms" % mm] = round((time.perf_counter() - t4) / 5 * 1e3, 3)
             res["gt_matching_%d_boxes_matches" % mm] = len(found)
+            if mm == 256:
+                found_256, boxes_256 = found, (bx, gx)
+        if not args.no_parity:
+            # every figure above against the oracle on the very frames that were timed
+            from oracle import monoloco_oracle as O
+            ref16 = O.forward_mono(sd_t, k16.cpu(), kk, box_conf=c16.cpu())
+            ref_f = O.forward_mono(sd_t, torch.tensor(kpl), kk1, box_conf=torch.tensor([b[4] for b in boxes]))
+            pp = net.post_process(dic, boxes, kpl, kk1)
+            ref_s = O.forward_stereo({k: torch.tensor(v) for k, v in sd_s.items()}, torch.tensor(kpl), torch.tensor(kpr), kk1)
+            m_ref = O.reorder_matches(O.get_iou_matches(boxes_256[0], boxes_256[1]), boxes_256[0])
+            m_gt = O.associate(boxes, dic_gt['boxes'])[0]
+            res["parity"] = {
+                "device_pipeline_16_rows_max_abs_xyzds": float('%.3e' % float((x16.cpu() - ref16['xyzds']).abs().max())),
+                "loco_forward_max_abs_d_bi": float('%.3e' % max(float((dic['d'] - ref_f['d']).abs().max()), float((dic['bi'] - ref_f['bi']).abs().max()))),
+                "post_process_max_abs_xyz_pred": float('%.3e' % float((torch.tensor(pp['xyz_pred']) - ref_f['xyz_pred']).abs().max())),
+                "stereo_loco_forward_max_abs_d_bi": (float('%.3e' % max(float((dic_s['d'] - ref_s['d']).abs().max()), float((dic_s['bi'] - ref_s['bi']).abs().max())))
+                                                     if ref_s['d'].shape == dic_s['d'].shape else "tie: row counts differ"),
+                "post_process_with_gt_same_matches": bool([tuple(int(v) for v in mt) for mt in out_matches] == [tuple(mt) for mt in m_gt]),
+                "gt_matching_256_boxes_same_matches": bool([tuple(int(v) for v in mt) for mt in found_256] == [tuple(mt) for mt in m_ref]),
+                "tolerance": 1e-4,
+                "against": "oracle/monoloco_oracle.{forward_mono, forward_stereo, associate, get_iou_matches + reorder_matches} on the timed frames; "
+                           "the 2048-box matching is checked at 16 / 256 / 2048 boxes against the real reference in tests/test_gpu_matching.py "
+                           "(the scalar Python loop needs seconds there)"}
         return res
     guarded("latency_16_persons", latency)
 
@@ -1034,6 +1214,9 @@ def main(argv=None):
             line["roofline"] = {
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16_DENSE, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_F16_DENSE, 4),
+                # the same numerator over the WHOLE step's wall time (prep, tail and launch gaps included; what `value` implies)
+                "achieved_of_step": round(alg_flop / dt / 1e12, 2),
+                "frac_of_step": round(alg_flop / dt / 1e12 / PEAK_TFLOPS_F16_DENSE, 4),
                 "traffic": replay[0]["hbm_bytes_per_launch"] if replay else None,
                 "traffic_source": replay[1] if replay else "none: PMC cannot be read live; no committed pass covers this configuration",
                 "algorithmic_bytes_per_launch": replay[0].get("algorithmic_bytes_per_launch") if replay else None,
@@ -1079,7 +1262,7 @@ def main(argv=None):
         if args.workload == 'mono' and not stub and not args.no_parity:
             line["parity"] = parity_of_timed_run(sd, kps, conf, xyzds, raw, kk, out)
         if world == 1 and args.workload == 'mono' and not args.no_extra and not stub:
-            line["extra"] = extras(args, dev, sd, eng, kps, conf, kinv, kk, ms_per_step)
+            line["extra"] = extras(args, dev, sd, eng, kps, conf, kinv, kk, ms_per_step, main_out=(out.clone(), xyzds.clone()))
             if "e2e" in line["extra"] and "e2e_ms" in line["extra"]["e2e"]:
                 line["e2e_ms"] = line["extra"]["e2e"]["e2e_ms"]
         if world == 1 and args.cpu_seconds > 0 and args.workload == 'mono' and not stub:

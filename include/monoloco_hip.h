@@ -149,7 +149,9 @@ int ml_post_geometry_strided(const float* kps_dev, int64_t m, const float* kinv_
  * matched annotation, each with the K of its image): kps_dev (m,3,17); kinv_table_host (nk,9) = inverses of the
  * distinct intrinsic matrices; k_index_dev (m) int32 = table entry of each row (not range-checked).  kps_r_dev
  * NULL -> x_dev (m,34) mono inputs; else (m,3,17) right keypoints -> x_dev (m,68) stereo training rows
- * [L, L - R] (preprocess_kitti.py:242-247).  Bit-identical to the per-annotation calls. */
+ * [L, L - R] (preprocess_kitti.py:242-247).  Bit-identical to the per-annotation calls.  Asynchronous on `stream` (the table is
+ * staged through a per-device ring of pinned slots; kinv_table_host may be reused as soon as the call returns); callers on
+ * different devices never serialise, callers on different streams of one device only while they enqueue. */
 int ml_preprocess_rows(const float* kps_dev, const float* kps_r_dev, int64_t m, const float* kinv_table_host, int nk,
                        const int32_t* k_index_dev, float z_met, float* x_dev, void* stream);
 /* extract_outputs_mono (process.py:330-360, legacy 'monoloco_p' outputs x, y, z, log(b/z), h, w, l, sin, cos):
@@ -197,6 +199,19 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
  * word; pageable ones are staged through kps_dev ((ml + mr) * 51 floats) and buf_dev (same size as out_host).  xyzds_dev (ml, 5). */
 int ml_loco_frame_stereo(ml_loco* h, const float* kps_l_host, int64_t ml, const float* kps_r_host, int64_t mr,
                          const float* kinv_host, float* kps_dev, float* buf_dev, float* xyzds_dev, float* out_host, void* stream);
+/* The pinned-buffer contract of the two frame entries above.  Kernels dereference kps*_host / out_host directly, so before the
+ * first use of a host range both of its ends are asked of the runtime (hipPointerGetAttributes must say "host"); anything else --
+ * pageable memory, a failed query -- takes the staged route (copies through kps_dev / buf_dev), never an error.  The verdict is
+ * remembered per handle for the last 8 (pointer, byte extent) pairs, because a caller streams its frames through the same staging
+ * buffers.  In return the CALLER guarantees: a host buffer that was passed to ml_loco_frame_mono / _stereo stays pinned (no
+ * hipHostUnregister / hipHostFree / torch un-pinning of it) until either ml_loco_forget_pinned(h, that pointer) -- or
+ * ml_loco_forget_pinned(h, NULL): every remembered range -- has been called, or the handle is destroyed.  Freeing a remembered
+ * buffer without forgetting it and letting malloc reuse the address would put pageable memory behind a trusted pointer: a GPU page
+ * fault, not an error code.  out_host must be coherent pinned memory (hipHostMalloc default flags / torch pin_memory: NOT
+ * hipHostMallocNonCoherent) for the completion word the host polls to become visible; a frame that has not reported after 5 ms
+ * falls back to hipStreamSynchronize.  (The reference has no such call: it copies Python lists into fresh tensors per frame,
+ * monoloco/network/net.py:92-93.) */
+int ml_loco_forget_pinned(ml_loco* h, const void* host_ptr);
 /* stereo (net.py:112-122, process.py:307-327): all left x right pairs, per-left arg-max of the
  * aux logit.  best_dev (ml) int32 receives the first arg-max right index; ties_dev (1) int32
  * receives the number of left persons with more than one maximal pair (the reference keeps

@@ -68,6 +68,7 @@ SIGNATURES = {
     'ml_debug_frames_without_copies': (ctypes.c_longlong, []),
     'ml_debug_frame_spin': (ctypes.c_longlong, [c_int]),
     'ml_loco_frame_mono': (c_int, [_P, _P, c_int64, POINTER(c_float), _P, _P, _P, _P, _P]),
+    'ml_loco_forget_pinned': (c_int, [_P, _P]),
     'ml_loco_frame_stereo': (c_int, [_P, _P, c_int64, _P, c_int64, POINTER(c_float), _P, _P, _P, _P, _P]),
     'ml_loco_forward_stereo': (c_int, [_P, _P, c_int64, _P, c_int64, POINTER(c_float), _P, _P, _P, _P,
                                        _P, _P, _P]),

@@ -191,14 +191,14 @@ struct ml_loco {
     int32_t* d_rowidx = nullptr;
     float* d_part = nullptr;    // fused-head partial sums [2*hidden/256][cap_rows][16] ...
     float* d_part_aux = nullptr;  // ... and, behind them, the fused w_aux head's [2*hidden/256][cap_rows] (same allocation)
-    int part_slices = 0;        // slices per head d_part / d_part_aux hold
+    int64_t part_cells = 0;     // (slice, row) cells per head d_part / d_part_aux hold (part_cells_for)
     // ml_loco_frame_mono's completion word (pinned, coherent) + the arrival counter of the last launch's workgroups; frame_flag_req:
     // the frame entry asks run_network to arm the flag in the launch that ends a single image's forward
     int* h_done = nullptr;
     int* d_arrive = nullptr;
     int done_seq = 0;
     bool frame_flag_req = false, frame_flag_armed = false;
-    const void* pinned_seen[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ml_loco_frame_mono: host pointers verified to be pinned
+    struct PinnedSeen { const void* p = nullptr; size_t bytes = 0; } pinned_seen[8];   // ml_loco_frame_*: host ranges verified to be pinned
     int pinned_next = 0;
     int tune_version = 0;       // bumped by ml_loco_set_tuning / ml_loco_set_option: cached route plans of older versions are stale
     struct PlanCache* plans = nullptr;   // the route plans of the last few (rows, MC-dropout) calls (plan_for; freed in ml_loco_destroy)
@@ -373,6 +373,15 @@ int free_workspace(ml_loco* h) {
     return ML_OK;
 }
 
+// (slice, row) cells of fused-head partial sums a workspace of `need` rows holds: 128-column slices from the tile kernels at every
+// size, dense_mid_kernel's finer 64-column slices for the rows the mid window can be tuned to (<= 16384).  ONE formula for the
+// allocation (ensure_rows) and for the plan's prediction (part_fits): the printed plan is the plan that runs
+static int64_t part_cells_for(int hidden, int64_t need) {
+    const int64_t fine = (int64_t)(hidden / 64) * (need < 16384 ? need : 16384);
+    const int64_t coarse = (int64_t)(2 * hidden / 256) * need;
+    return fine > coarse ? fine : coarse;
+}
+
 int ensure_rows(ml_loco* h, int64_t rows) {
     const int64_t need = round_up64(rows > 0 ? rows : 1, 256);
     if (need <= h->cap_rows) return ML_OK;
@@ -386,11 +395,10 @@ int ensure_rows(ml_loco* h, int64_t rows) {
     if ((rc = dev_alloc(h, &h->d_centre, need * 2 * 4))) return rc;
     if ((rc = dev_alloc(h, &h->d_raw, need * (int64_t)h->out_f * 4))) return rc;
     if ((rc = dev_alloc(h, &h->d_rowidx, need * 4))) return rc;
-    // partial sums of the fused heads: 128-column slices from the tile kernels, 64-column slices from dense_mid_kernel (workspaces
-    // of up to 16384 rows, i.e. every size the mid window can be tuned to by default, hold the finer ones)
-    h->part_slices = need <= 16384 ? h->hidden / 64 : 2 * h->hidden / 256;
-    if ((rc = dev_alloc(h, &h->d_part, (int64_t)h->part_slices * need * 17 * 4))) return rc;
-    h->d_part_aux = h->d_part + (int64_t)h->part_slices * need * 16;
+    // partial sums of the fused heads (16 floats per cell for w_fin, then 1 per cell for w_aux)
+    h->part_cells = part_cells_for(h->hidden, need);
+    if ((rc = dev_alloc(h, &h->d_part, h->part_cells * 17 * 4))) return rc;
+    h->d_part_aux = h->d_part + h->part_cells * 16;
     if ((rc = dev_alloc(h, &h->d_mc, need * 4 * (int64_t)sizeof(double)))) return rc;
     h->cap_rows = need;
     return ML_OK;
@@ -765,8 +773,7 @@ int route_family(const ml_loco* h, int64_t rows) {
 // allocates when the call is larger than it)?
 bool part_fits(const ml_loco* h, int64_t rows, int slices) {
     const int64_t m_pad = round_up64(rows > 0 ? rows : 1, 256);
-    if (m_pad > h->cap_rows) return slices <= (m_pad <= 16384 ? h->hidden / 64 : 2 * h->hidden / 256);
-    return (int64_t)slices * m_pad <= (int64_t)h->part_slices * h->cap_rows;
+    return (int64_t)slices * m_pad <= (m_pad > h->cap_rows ? part_cells_for(h->hidden, m_pad) : h->part_cells);
 }
 
 RoutePlan make_plan(const ml_loco* h, int64_t rows, bool mc_on) {
@@ -900,7 +907,8 @@ std::string plan_text(const ml_loco* h, const RoutePlan& pl, bool with_tail) {
 struct PlanCache {
     struct Entry {
         int64_t rows, cap_rows;
-        int mc_on, version, part_slices;
+        int mc_on, version;
+        int64_t part_cells;
         RoutePlan plan;
     };
     std::vector<Entry> entries;
@@ -913,9 +921,9 @@ const RoutePlan& plan_for(ml_loco* h, int64_t rows, bool mc_on) {
     if (!h->plans) h->plans = new PlanCache();
     for (const PlanCache::Entry& e : h->plans->entries)
         if (e.rows == rows && e.mc_on == (int)mc_on && e.version == h->tune_version && e.cap_rows == h->cap_rows &&
-            e.part_slices == h->part_slices)
+            e.part_cells == h->part_cells)
             return e.plan;
-    PlanCache::Entry e{rows, h->cap_rows, (int)mc_on, h->tune_version, h->part_slices, make_plan(h, rows, mc_on)};
+    PlanCache::Entry e{rows, h->cap_rows, (int)mc_on, h->tune_version, h->part_cells, make_plan(h, rows, mc_on)};
     if (h->plans->entries.size() < 16) {
         h->plans->entries.push_back(std::move(e));
         return h->plans->entries.back().plan;
@@ -1408,36 +1416,59 @@ int ml_preprocess_rows(const float* kps_dev, const float* kps_r_dev, int64_t m, 
         return fail(ML_ERR_ARG, "bad argument");
     if (m == 0) return ML_OK;
     hipStream_t st = (hipStream_t)stream;
-    std::vector<mlk::Kinv> table((size_t)nk);
-    for (int i = 0; i < nk; ++i) table[i] = make_kinv(kinv_table_host + (size_t)i * 9);
-    // the device copy of the table lives in a grow-only per-device cache (this entry point has no handle to hang a workspace on):
-    // an allocation only when a call brings more matrices than any call before it on this device
-    static std::mutex table_mu;
-    static std::map<int, std::pair<mlk::Kinv*, int>> table_cache;
-    std::lock_guard<std::mutex> lock(table_mu);
+    // The device copy of the table comes from a small per-DEVICE ring of (pinned staging, device table, event) slots -- this entry point
+    // has no handle to hang a workspace on.  A slot is reused only after the event recorded behind the kernel that read it has
+    // completed, so the call itself is asynchronous on `stream` like every other entry (no stream synchronisation), callers on other
+    // devices never meet, and callers on other streams of one device hold the device's lock only while they enqueue.  The rings live
+    // for the life of the process (a few KiB per device that ever prepared rows).
+    struct Slot {
+        mlk::Kinv* host = nullptr;
+        mlk::Kinv* dev = nullptr;
+        int cap = 0;
+        hipEvent_t done = nullptr;
+        bool in_flight = false;
+    };
+    struct DevRing {
+        std::mutex mu;
+        Slot slot[4];
+        int next = 0;
+    };
+    static std::mutex map_mu;
+    static std::map<int, DevRing*> rings;
     int dev_id = 0;
     HIP_TRY(hipGetDevice(&dev_id));
-    auto& slot = table_cache[dev_id];
-    if (slot.second < nk) {
-        HIP_TRY(hipStreamSynchronize(st));
-        if (slot.first) (void)hipFree(slot.first);
-        slot = {nullptr, 0};
+    DevRing* ring;
+    {
+        std::lock_guard<std::mutex> lock(map_mu);
+        DevRing*& r = rings[dev_id];
+        if (!r) r = new DevRing();
+        ring = r;
+    }
+    std::lock_guard<std::mutex> lock(ring->mu);
+    Slot& sl = ring->slot[ring->next];
+    ring->next = (ring->next + 1) & 3;
+    if (sl.in_flight) {
+        HIP_TRY(hipEventSynchronize(sl.done));   // the launch that read this slot four calls ago
+        sl.in_flight = false;
+    }
+    if (sl.cap < nk) {
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.host) (void)hipHostFree(sl.host);
+        sl.dev = sl.host = nullptr;
+        sl.cap = 0;
         const int cap = nk < 64 ? 64 : nk;
-        HIP_TRY(hipMalloc((void**)&slot.first, (size_t)cap * sizeof(mlk::Kinv)));
-        slot.second = cap;
+        HIP_TRY(hipMalloc((void**)&sl.dev, (size_t)cap * sizeof(mlk::Kinv)));
+        HIP_TRY(hipHostMalloc((void**)&sl.host, (size_t)cap * sizeof(mlk::Kinv), hipHostMallocDefault));
+        if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        sl.cap = cap;
     }
-    mlk::Kinv* d_table = slot.first;
-    // `table` lives on this stack frame: wait for the upload before returning (dataset preparation is not a
-    // latency-critical call)
-    hipError_t e = hipMemcpyAsync(d_table, table.data(), (size_t)nk * sizeof(mlk::Kinv), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(mlk::prep_rows_kernel, ML_GRID(m * mlk::NKP), kps_dev, kps_r_dev, m, (const mlk::Kinv*)d_table,
-                           k_index_dev, z_met, x_dev);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);   // (the cached table may be overwritten by the next call)
-    if (e != hipSuccess) return fail(ML_ERR_HIP, "ml_preprocess_rows: %s", hipGetErrorString(e));
+    for (int i = 0; i < nk; ++i) sl.host[i] = make_kinv(kinv_table_host + (size_t)i * 9);
+    HIP_TRY(hipMemcpyAsync(sl.dev, sl.host, (size_t)nk * sizeof(mlk::Kinv), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mlk::prep_rows_kernel, ML_GRID(m * mlk::NKP), kps_dev, kps_r_dev, m, (const mlk::Kinv*)sl.dev, k_index_dev, z_met,
+                       x_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sl.done, st));
+    sl.in_flight = true;
     return ML_OK;
 }
 
@@ -1782,6 +1813,47 @@ static std::atomic<long long> g_frames_without_copies{0};   // (test hook: ml_de
 static std::atomic<long long> g_frame_flag_timeouts{0};     // frames whose completion word did not arrive within 5 ms (expected: 0)
 static std::atomic<int> g_frame_spin{1};                    // ml_debug_frame_spin: 0 = always hipStreamSynchronize (the A/B reference)
 
+// Is [p, p + bytes) pinned (device-mapped) host memory a kernel may dereference?  Both ends of the range are asked of the runtime
+// (hipPointerGetAttributes: a driver call each), and the verdict is remembered per handle for the last 8 (pointer, extent) pairs: a
+// caller streams its frames through the same staging buffers.  A remembered range is trusted until ml_loco_forget_pinned -- the
+// caller's side of the contract (include/monoloco_hip.h): memory that was handed to a frame entry stays pinned until it is forgotten
+// or the handle is destroyed (hipHostUnregister / hipHostFree of a remembered buffer, then reuse of the address by malloc, would
+// otherwise put pageable memory behind a remembered address: a GPU page fault, not an error code).
+static bool frame_pinned(ml_loco* h, const void* p, size_t bytes) {
+    if (!p || !bytes) return false;
+    if (h)
+        for (const auto& q : h->pinned_seen)
+            if (q.p == p && bytes <= q.bytes) return true;
+    const void* ends[2] = {p, (const char*)p + bytes - 1};
+    for (const void* e : ends) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, e) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    if (h) {
+        int slot = h->pinned_next;
+        for (int i = 0; i < 8; ++i)
+            if (h->pinned_seen[i].p == p) slot = i;       // the same buffer with a larger extent: replace its entry
+        h->pinned_seen[slot].p = p;
+        h->pinned_seen[slot].bytes = bytes;
+        if (slot == h->pinned_next) h->pinned_next = (h->pinned_next + 1) % 8;
+    }
+    return true;
+}
+
+int ml_loco_forget_pinned(ml_loco* h, const void* host_ptr) {
+    if (!h) return fail(ML_ERR_ARG, "bad argument");
+    for (auto& q : h->pinned_seen)
+        if (!host_ptr || q.p == host_ptr) {
+            q.p = nullptr;
+            q.bytes = 0;
+        }
+    return ML_OK;
+}
+
 // One image through the mono pipeline in ONE call: pinned host keypoints in, [packed (m, 16) | post-process geometry (m, 12)] in
 // pinned host memory out, one stream synchronisation.  What Loco.forward does per frame (reference net.py:83-133 + the geometry
 // of :195-215); as one entry the host pays one foreign call instead of five.
@@ -1797,26 +1869,9 @@ int ml_loco_frame_mono(ml_loco* h, const float* kps_host, int64_t m, const float
     int rc;
     // kernels may only dereference PINNED (device-mapped) host memory: anything else takes the staged route, where the runtime's
     // copies accept pageable memory as well (a wrong guess here would be a GPU page fault, not an error code)
-    // (the verdict is remembered per handle for the last few pointers: a caller streams frames through the same staging buffers, and
-    //  the attribute query is a driver call per pointer and frame; pinned allocations live in their own address range, so a
-    //  remembered address does not come back as pageable memory)
-    auto pinned = [h](const void* p) {
-        if (h)
-            for (const void* q : h->pinned_seen)
-                if (q == p) return true;
-        hipPointerAttribute_t a;
-        if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        if (a.type != hipMemoryTypeHost) return false;
-        if (h) {
-            h->pinned_seen[h->pinned_next] = p;
-            h->pinned_next = (h->pinned_next + 1) % 8;
-        }
-        return true;
-    };
-    if (m <= 128 && h && use_small_path(h->tune, h->precision, m) && pinned(kps_host) && pinned(out_host)) {
+    // (frame_pinned: the verdict is remembered per handle for the last few (pointer, extent) pairs -- the contract of
+    //  ml_loco_forget_pinned in include/monoloco_hip.h)
+    if (m <= 128 && h && use_small_path(h->tune, h->precision, m) && frame_pinned(h, kps_host, (size_t)m * 3 * mlk::NKP * 4) && frame_pinned(h, out_host, (size_t)m * (ML_OUT_STRIDE + ML_POSTGEO_STRIDE) * 4)) {
         bool geo_done = false;
         h->frame_flag_req = g_frame_spin.load(std::memory_order_relaxed) != 0;
         h->frame_flag_armed = false;
@@ -1867,25 +1922,10 @@ int ml_loco_frame_stereo(ml_loco* h, const float* kps_l_host, int64_t ml, const 
     if (ml == 0) return ML_OK;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    auto pinned = [h](const void* p) {
-        if (h)
-            for (const void* q : h->pinned_seen)
-                if (q == p) return true;
-        hipPointerAttribute_t a;
-        if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        if (a.type != hipMemoryTypeHost) return false;
-        if (h) {
-            h->pinned_seen[h->pinned_next] = p;
-            h->pinned_next = (h->pinned_next + 1) % 8;
-        }
-        return true;
-    };
     const size_t n_packed = (size_t)ml * ML_OUT_STRIDE, n_geo = (size_t)ml * ML_POSTGEO_STRIDE;
     const size_t words = n_packed + n_geo + 1 + (size_t)ml;
-    const bool direct = h && h->d_arrive && pinned(kps_l_host) && pinned(kps_r_host) && pinned(out_host);
+    const bool direct = h && h->d_arrive && frame_pinned(h, kps_l_host, (size_t)ml * 3 * mlk::NKP * 4) &&
+                        frame_pinned(h, kps_r_host, (size_t)mr * 3 * mlk::NKP * 4) && frame_pinned(h, out_host, words * 4);
     const float* kl = kps_l_host;
     const float* kr = kps_r_host;
     float* blk = out_host;

@@ -53,8 +53,12 @@ class _HipForward(nn.Module):
     def forward(self, x):
         if self.training or self.dropout.training:
             raise NotImplementedError(
-                "the module forward is the eval-mode network (running-stat BatchNorm, no dropout); training runs "
-                "through monoloco_amd.train.Trainer / HipTrainer and MC-dropout through Loco(n_dropout=...)")
+                "%s.forward in train mode: this module's forward is the eval-mode network on the HIP engine (running-stat "
+                "BatchNorm, no dropout, no autograd graph) -- the reference's `outputs = self.model(inputs); loss.backward()` "
+                "(monoloco/train/trainer.py:155-161) has no counterpart on the module.  Train with monoloco_amd.train.Trainer "
+                "(same arguments and checkpoints as monoloco.train.Trainer; monoloco_amd.train.HipTrainer is the step underneath), "
+                "or call monoloco_amd.compat.install(trainer=True) so that `monoloco.train.Trainer` IS that class; call .eval() "
+                "for inference; MC-dropout runs through Loco(n_dropout=...)" % type(self).__name__)
         home = x.device
         eng = self.hip_engine(home if home.type == 'cuda' else None)
         return eng.forward_raw(x.detach()).to(home)

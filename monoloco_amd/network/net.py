@@ -107,6 +107,7 @@ class Loco:
     logger = logging.getLogger(__name__)
     LINEAR_SIZE_MONO = 256
     N_SAMPLES = 100
+    _warned_default_device = False
 
     def __init__(self, model, mode, net=None, device=None, n_dropout=0, p_dropout=0.2, linear_size=1024):
         assert mode in ('mono', 'stereo'), "mode not recognized"
@@ -127,6 +128,18 @@ class Loco:
             input_size, output_size, linear_size = 34, 9, 256
         else:  # legacy MonoLoco: 34 -> linear_size -> (d, log(b/d)), net.py:58-60
             input_size, output_size = 34, 2
+        if device is None or torch.device(device).type != 'cuda':
+            # the reference's default is the CPU (net.py:60-63: `device=None` -> torch.device('cpu')); this path has no CPU build
+            if not torch.cuda.is_available() or device is not None:
+                raise engine.MonolocoHipError(
+                    "Loco(device=%r): the reference runs on the CPU here (monoloco/network/net.py:60-63, `device=None` means "
+                    "torch.device('cpu')); monoloco_amd is the HIP path only and has no CPU fallback -- pass device=torch.device('cuda', i) "
+                    "on a box with an AMD GPU%s" % (device, "" if torch.cuda.is_available() else " (no HIP device is visible to PyTorch)"))
+            if not Loco._warned_default_device:
+                Loco._warned_default_device = True
+                self.logger.warning("Loco(device=None): the reference's default device is the CPU (net.py:60-63); monoloco_amd "
+                                    "uses the current HIP device (cuda:%d) instead -- results come back as CPU tensors either way",
+                                    torch.cuda.current_device())
         self.device = engine._require_cuda(device)
         self.n_dropout = n_dropout
         self.epistemic = bool(self.n_dropout > 0)
@@ -241,6 +254,9 @@ class Loco:
         st = self._stage.get(m)
         if st is None:
             if len(self._stage) >= 16:
+                # the pinned staging buffers go back to torch's host allocator: the handle must stop trusting their addresses
+                # (the pinned-buffer contract of ml_loco_frame_*, include/monoloco_hip.h)
+                engine._lib.load().ml_loco_forget_pinned(self.engine._h, None)
                 self._stage.clear()
             pin_in = torch.empty((m, 3, 17), dtype=torch.float32).pin_memory()
             pin_out = torch.empty((m * (stride + 12),), dtype=torch.float32).pin_memory()
@@ -312,6 +328,9 @@ class Loco:
         st = self._stage.get(key)
         if st is None:
             if len(self._stage) >= 16:
+                # the pinned staging buffers go back to torch's host allocator: the handle must stop trusting their addresses
+                # (the pinned-buffer contract of ml_loco_frame_*, include/monoloco_hip.h)
+                engine._lib.load().ml_loco_forget_pinned(self.engine._h, None)
                 self._stage.clear()
             words = ml * (stride + 12) + 1 + ml
             pin_l = torch.empty((ml, 3, 17), dtype=torch.float32).pin_memory()

@@ -26,21 +26,44 @@ def _check(code):
         raise _lib.MonolocoHipError("monoloco_hip matching error %d: %s" % (code, msg.decode() if msg else '?'))
 
 
-def _boxes_f64(boxes):
-    """Rows of Python numbers -> one C-contiguous (n, >=4) float64 array (a Python float IS that double).  Rows of
-    unequal length (e.g. ground truth with and without a trailing field) keep their first four columns."""
+def _boxes_f64(boxes, cols=4):
+    """Rows of Python numbers -> one C-contiguous (n, >=cols) float64 array (a Python float IS that double).  Rows of
+    unequal length (ground truth with and without a trailing field, detections that carry extra fields) keep their first
+    `cols` columns: 4 for ground truth, 5 for detections whose confidence (box[4]) orders the greedy pass."""
     try:
         arr = np.asarray(boxes, dtype=np.float64)
     except ValueError:
         arr = None
     if arr is None or arr.ndim != 2:
-        arr = np.asarray([box[:4] for box in boxes], dtype=np.float64)
-    assert arr.ndim == 2 and arr.shape[1] >= 4, "boxes must be rows of x1, y1, x2, y2[, ...]"
+        arr = np.asarray([box[:cols] for box in boxes], dtype=np.float64)
+    assert arr.ndim == 2 and arr.shape[1] >= cols, "boxes must be rows of x1, y1, x2, y2[, conf, ...]"
     return arr if arr.flags.c_contiguous else np.ascontiguousarray(arr)
 
 
-def _raise_zero_div(flag):
-    if flag:
+def _python_floats(*box_sets):
+    """True when every box set holds plain Python numbers.  The reference's calculate_iou divides whatever it is handed
+    (iou.py:25): Python floats raise ZeroDivisionError on a zero union, numpy scalars (e.g. make_lower_boxes' arrays) give
+    nan / inf and a RuntimeWarning instead -- the native calls compute the IEEE quotient either way and report the event."""
+    for boxes in box_sets:
+        if isinstance(boxes, np.ndarray):
+            return False
+        if len(boxes) and (isinstance(boxes[0], np.ndarray) or isinstance(boxes[0][0], np.generic)):
+            return False
+    return True
+
+
+def _use_device(pairs):
+    """The IoUs of an image run on the GPU from DEVICE_MIN_PAIRS pairs on -- when there is one: a dataset-preparation or
+    evaluation box without a HIP device (compat.install() re-binds these helpers into the reference's eval / prep modules)
+    takes the library's host loops at every size (the same doubles in the same order, tests/test_matching.py)."""
+    if pairs < DEVICE_MIN_PAIRS:
+        return False
+    import torch
+    return torch.cuda.is_available()
+
+
+def _raise_zero_div(flag, python_floats=True):
+    if flag and python_floats:
         raise ZeroDivisionError("float division by zero")   # what the reference's calculate_iou raises (iou.py:25)
 
 
@@ -66,17 +89,17 @@ def _device_buffers(b, gt, out_bytes):
     return dev, b_d, gt_d, out_d
 
 
-def _best_rows(b, gt):
+def _best_rows(b, gt, python_floats=True):
     """(jmax int32 (m), vmax float64 (m)): per detection the first arg-max of the IoU over all ground-truth boxes."""
     lib = _lib.load()
     m, g = b.shape[0], gt.shape[0]
-    if m * g < DEVICE_MIN_PAIRS:
+    if not _use_device(m * g):
         jmax = np.empty((m,), dtype=np.int32)
         vmax = np.empty((m,), dtype=np.float64)
         flag = ctypes.c_int32(0)
         _check(lib.ml_iou_best_host(b.ctypes.data, m, b.shape[1], gt.ctypes.data, g, gt.shape[1], jmax.ctypes.data,
                                     vmax.ctypes.data, ctypes.byref(flag)))
-        _raise_zero_div(flag.value)
+        _raise_zero_div(flag.value, python_floats)
         return jmax, vmax
     import torch
     from .. import engine
@@ -89,7 +112,7 @@ def _best_rows(b, gt):
     host = out_d.cpu().numpy()
     vmax = host[:8 * m].view(np.float64)
     jmax = host[8 * m:12 * m].view(np.int32)
-    _raise_zero_div(int(host[12 * m:].view(np.int32)[0]))
+    _raise_zero_div(int(host[12 * m:].view(np.int32)[0]), python_floats)
     return jmax, vmax
 
 
@@ -100,12 +123,13 @@ def get_iou_matrix(boxes, boxes_gt):
         return np.zeros((m, g))
     lib = _lib.load()
     b, gt = _boxes_f64(boxes), _boxes_f64(boxes_gt)
-    if m * g < DEVICE_MIN_PAIRS:
+    pyf = _python_floats(boxes, boxes_gt)
+    if not _use_device(m * g):
         mat = np.empty((m, g), dtype=np.float64)
         flag = ctypes.c_int32(0)
         _check(lib.ml_iou_matrix_host(b.ctypes.data, m, b.shape[1], gt.ctypes.data, g, gt.shape[1], mat.ctypes.data,
                                       ctypes.byref(flag)))
-        _raise_zero_div(flag.value)
+        _raise_zero_div(flag.value, pyf)
         return mat
     import torch
     from .. import engine
@@ -119,14 +143,15 @@ def get_iou_matrix(boxes, boxes_gt):
             _check(lib.ml_iou_matrix(b_d.data_ptr() + lo * b.shape[1] * 8, n, b.shape[1], gt_d.data_ptr(), g, gt.shape[1],
                                      out_d.data_ptr(), flag_d.data_ptr(), engine._stream(dev)))
             mat[lo:lo + n] = out_d[:n].cpu().numpy()
-    _raise_zero_div(int(flag_d.cpu().numpy().view(np.int32)[0]))
+    _raise_zero_div(int(flag_d.cpu().numpy().view(np.int32)[0]), pyf)
     return mat
 
 
 def _matches(boxes, boxes_gt, iou_min, left_to_right):
     """get_iou_matches, optionally followed by reorder_matches, on arrays: one native call for the pairs."""
     lib = _lib.load()
-    b, gt = _boxes_f64(boxes), _boxes_f64(boxes_gt)
+    b, gt = _boxes_f64(boxes, cols=5), _boxes_f64(boxes_gt)
+    pyf = _python_floats(boxes, boxes_gt)
     m, g = b.shape[0], gt.shape[0]
     # the reference's own sort calls on the same doubles (iou.py:51-53, :97): ties come out in numpy's order
     # (argsort of a strided column sorts a contiguous copy of it: the same call on the same values)
@@ -137,12 +162,12 @@ def _matches(boxes, boxes_gt, iou_min, left_to_right):
     p_out = out.ctypes.data
     p_n, p_flag = p_out + 16 * min(m, g), p_out + 16 * min(m, g) + 8
     out[-1] = 0
-    if m * g < DEVICE_MIN_PAIRS:
+    if not _use_device(m * g):
         _check(lib.ml_iou_matches_host(b.ctypes.data, m, b.shape[1], gt.ctypes.data, g, gt.shape[1], order.ctypes.data,
                                        float(iou_min), p_left, p_out, p_n, p_flag))
-        _raise_zero_div(out[-1])
+        _raise_zero_div(out[-1], pyf)
     else:
-        jmax, vmax = _best_rows(b, gt)
+        jmax, vmax = _best_rows(b, gt, pyf)
         jmax, vmax = np.ascontiguousarray(jmax), np.ascontiguousarray(vmax)
         _check(lib.ml_iou_greedy(order.ctypes.data, m, jmax.ctypes.data, vmax.ctypes.data, m, g, float(iou_min), p_left,
                                  p_out, p_n))

@@ -52,8 +52,14 @@ def test_no_fallback_without_gpu():
         preprocess_monoloco(torch.zeros((2, 3, 17)), synth.KITTI_K)
     with pytest.raises(_lib.MonolocoHipError):
         engine.LocoEngine({k: torch.tensor(v) for k, v in synth.make_state_dict(1, hidden=256).items()})
-    with pytest.raises(_lib.MonolocoHipError):
+    with pytest.raises(_lib.MonolocoHipError, match=r"net\.py:60-63"):      # the message names the reference default that changed
         Loco(model=None, mode='mono')
+    with pytest.raises(_lib.MonolocoHipError, match=r"net\.py:60-63"):
+        Loco(model=None, mode='mono', device='cpu')
+    # the module in train mode points at the Trainer and at compat.install(trainer=True)
+    from monoloco_amd.network.architectures import LocoModel
+    with pytest.raises(NotImplementedError, match=r"monoloco_amd\.train\.Trainer.*compat\.install\(trainer=True\)"):
+        LocoModel(34, 9, 256).train()(torch.zeros(2, 34))
 
 
 def test_product_never_imports_oracle():

@@ -319,3 +319,85 @@ def test_task_lambdas_against_oracle(hip_lib, cuda_device):
         if auto:
             assert np.abs(tr.log_sigmas.numpy() - orc.log_sigmas.detach().numpy()).max() <= 2e-6
         tr.close()
+
+
+def _rel_errors(got, ref64):
+    """(worst element / largest entry, rms error / rms of the tensor) of `got` against the fp64 tensor `ref64`."""
+    d = got.double() - ref64
+    scale = float(ref64.abs().max()) + 1e-300
+    rms = float(ref64.pow(2).mean().sqrt()) + 1e-300
+    return float(d.abs().max()) / scale, float(d.pow(2).mean().sqrt()) / rms
+
+
+def test_headline_batch_training_step_against_fp64_oracle(hip_lib, cuda_device):
+    """BASELINE configs[4] at the size bench.py times it (`extra.train.batch_65536`): ONE 65536-row step at hidden 1024 on the DEFAULT
+    large-batch route -- dw_layout 1: the residual stream, the stages' inner activations and dz exist between kernels as fp16 hi+lo
+    lines only, where the reference keeps fp32 tensors -- against the loop body of monoloco/train/trainer.py:150-161 with
+    train/losses.py:59-131 restated in fp64 (oracle/train_oracle.py): the loss values, every train-mode output row and every
+    gradient tensor; next to it the SAME oracle in fp32 (= the reference's own arithmetic), so that every bar reads "as close to
+    exact as the reference itself, times a stated factor".  Then layouts 0 and 2 (fp32 tensors between kernels) on the same batch:
+    the line format must not move anything beyond ReLU-flip class."""
+    from monoloco_amd.train import HipTrainer
+    from oracle.train_oracle import OracleTrainer
+    rows, hidden = 65536, 1024
+    x, y = _big_batch('mono', rows, 23)
+    sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(43, 34, 9, hidden).items()}
+    names = ['loss', 'd', 'x', 'y', 'h', 'w', 'l', 'ori']
+    got = {}
+    for layout in (1, 0, 2):
+        tr = HipTrainer(sd0, p_dropout=0.0, lr=0.001, device=cuda_device, dw_layout=layout)
+        res, out = tr.step(x, y, update=False, want_outputs=True)
+        assert tr.last_route == 'fast'
+        got[layout] = (res, out.cpu(), tr.grads())
+        if layout == 1:     # ... and a real update step of the default layout runs and stays finite
+            assert np.isfinite(tr.step(x, y)['loss'])
+        tr.close()
+    o64 = OracleTrainer(sd0, lr=0.001, dtype=torch.float64)
+    r64, out64 = o64.step(x.double(), y.double(), update=False)
+    g64 = o64.grads()
+    del o64
+    o32 = OracleTrainer(sd0, lr=0.001)
+    r32, out32 = o32.step(x, y, update=False)
+    g32 = o32.grads()
+    del o32
+
+    res, out, g = got[1]
+    # losses: means over 65536 rows, fp64 reductions on the device
+    for n in names:
+        assert abs(res[n] - r64[n]) <= 2e-5 * max(1.0, abs(r64[n])), (n, res[n], r64[n], r32[n])
+    # outputs: every row
+    e_out = float((out.double() - out64).abs().max())
+    n_out = float((out32.double() - out64).abs().max())
+    print('65536-row step, dw_layout 1: max |out - fp64| %.3e (the fp32 oracle: %.3e)' % (e_out, n_out))
+    assert e_out <= 2.0 * n_out + 2e-5, (e_out, n_out)
+    # gradients: per tensor against fp64, next to the fp32 oracle's own distance
+    gmax_all = max(float(v.abs().max()) for v in g64.values())
+    rows_tab = []
+    for k in g:
+        if float(g64[k].abs().max()) <= 1e-9 * gmax_all:   # Linear bias in front of a BatchNorm: mathematically zero, rounding noise
+            assert float(g[k].abs().max()) <= 2e-7 * gmax_all, (k, float(g[k].abs().max()), gmax_all)
+            continue
+        mx, rms = _rel_errors(g[k], g64[k])
+        mx32, rms32 = _rel_errors(g32[k], g64[k])
+        rows_tab.append((k, mx, rms, mx32, rms32))
+    for k, mx, rms, mx32, rms32 in rows_tab:
+        print('  %-36s max-rel %.2e (fp32 oracle %.2e)  rms-rel %.2e (fp32 oracle %.2e)' % (k, mx, mx32, rms, rms32))
+    for k, mx, rms, mx32, rms32 in rows_tab:
+        # bars (the same classes as test_headline_width_steps_match_reference, DESIGN.md section 8): worst element <= max(3 x the fp32
+        # oracle's own distance from fp64, 3e-3) of the tensor's largest entry (a flipped ReLU mask moves single entries);
+        # rms <= 4 x the fp32 oracle's own rms distance (floor 1e-4)
+        assert mx <= max(3.0 * mx32, 3e-3), (k, mx, mx32)
+        assert rms <= 4.0 * max(rms32, 2.5e-5), (k, rms, rms32)
+    # the fp32-between-kernels layouts on the same batch: same losses and outputs to fp32 class, gradients to ReLU-flip class
+    for layout in (0, 2):
+        res_b, out_b, g_b = got[layout]
+        for n in names:
+            assert abs(res[n] - res_b[n]) <= 2e-5 * max(1.0, abs(res[n])), (layout, n, res[n], res_b[n])
+        assert float((out - out_b).abs().max()) <= 2e-5 * max(1.0, float(out.abs().max())), layout
+        for k in g:
+            scale = max(float(g64[k].abs().max()), 1e-9 * gmax_all)
+            if scale <= 1e-9 * gmax_all:
+                continue
+            d = (g[k] - g_b[k]).double()
+            assert float(d.abs().max()) <= 3e-3 * scale, (layout, k, float(d.abs().max()) / scale)
+            assert float(d.pow(2).mean().sqrt()) <= 1e-3 * float(g64[k].pow(2).mean().sqrt()), (layout, k)

@@ -82,6 +82,28 @@ def test_matching_edge_cases(hip_lib):
         O.get_iou_matches([[5., 5., 5., 5., 0.9]], [[5., 5., 5., 5.]])
     with pytest.raises(ZeroDivisionError):
         I.get_iou_matrix([[5., 5., 5., 5., 0.9]], [[5., 5., 5., 5.]])
+    # ragged DETECTIONS (some carry fields behind the confidence): box[4] still orders the greedy pass, as in the reference's loop
+    ragged_det = [row + [7.0, 8.0] if i % 3 == 0 else row for i, row in enumerate(boxes)]
+    assert I.get_iou_matches(ragged_det, gt) == O.get_iou_matches(boxes, gt)
+    assert I.get_iou_matches_ordered(ragged_det, ragged) == O.reorder_matches(O.get_iou_matches(boxes, gt), boxes)
+    # numpy scalars instead of Python floats (make_lower_boxes-style arrays): the reference's division gives nan + a RuntimeWarning
+    # there, no exception -- same here; the nan never passes `>= iou_min`
+    with np.errstate(invalid='ignore', divide='ignore'):
+        want = O.get_iou_matrix(np.array([[5., 5., 5., 5., 0.9]]), np.array([[5., 5., 5., 5.]]))
+    got = I.get_iou_matrix(np.array([[5., 5., 5., 5., 0.9]]), np.array([[5., 5., 5., 5.]]))
+    assert np.isnan(want).all() and np.isnan(got).all()
+    np_rows = lambda rows: [[np.float64(v) for v in row] for row in rows]     # (an ndarray fails `not boxes` in the reference too)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        assert I.get_iou_matches(np_rows([[5., 5., 5., 5., 0.9]]), np_rows([[5., 5., 5., 5.]])) == [] \
+            == O.get_iou_matches(np_rows([[5., 5., 5., 5., 0.9]]), np_rows([[5., 5., 5., 5.]]))
+    # a box set large enough for the device kernels on a box WITHOUT a device: the library's host loops (a CPU-only dataset-preparation
+    # or evaluation box that re-binds these helpers through compat.install())
+    import torch
+    if not torch.cuda.is_available():
+        bb, gg = synth.make_boxes(256, 256, 11)
+        assert 256 * 256 >= I.DEVICE_MIN_PAIRS
+        assert I.get_iou_matches(bb, gg) == O.get_iou_matches(bb, gg)
+        assert np.array_equal(I.get_iou_matrix(bb[:200], gg[:200] + gg[:40]), O.get_iou_matrix(bb[:200], gg[:200] + gg[:40]))
     # a NaN IoU is np.argmax's first choice and never passes `>= iou_min`
     nan_gt = [[float('nan'), 0., 10., 10.], [0., 0., 10., 10.]]
     assert I.get_iou_matches([[0., 0., 10., 10., 0.5]], nan_gt) == O.get_iou_matches([[0., 0., 10., 10., 0.5]], nan_gt)
