@@ -234,7 +234,7 @@ def timed_steps(step, steps, warmup, world, device, begin=None, end=None, local_
     def fence():
         if on_gpu:
             torch.cuda.synchronize(device)
-        if world > 1:
+        if world > 1 or (dist.is_available() and dist.is_initialized()):   # (a forced world-1 group takes the barrier too)
             dist.barrier()
         if on_gpu:
             torch.cuda.synchronize(device)
@@ -252,7 +252,7 @@ def timed_steps(step, steps, warmup, world, device, begin=None, end=None, local_
     extra = end() if end is not None else None
     if local_out is not None:
         local_out['local_s'] = dt
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -1013,6 +1013,9 @@ def main(argv=None):
                          "random keypoints (set T).  Same kernels, same work; the board's power -- hence the clock at its cap -- depends on the "
                          "values by about 1 %% (measured: 2.647 vs 2.622 ms, tools/ab_weights.sh); `extra.reference_trained_weights` times and "
                          "checks the other set in every default run")
+    ap.add_argument('--force-distributed', action='store_true',
+                    help='take the N > 1 code path (process group on the real backend, sharded rows, the gather, gather_check, '
+                         'config4_strong) at ANY world size, also 1: the pre-flight of the multi-GPU run on a one-GPU box')
     ap.add_argument('--stub-engine', action='store_true',
                     help='launch-contract test on a box without a GPU: tests/stub_engine.py on CPU over gloo; the line is '
                          'marked "data": "stub" and measures nothing')
@@ -1020,6 +1023,12 @@ def main(argv=None):
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU) and relay their line
+        if not args.stub_engine:
+            import torch
+            have = torch.cuda.device_count()
+            if have < args.gpus:      # fail before N processes do, with one line
+                raise SystemExit("bench.py: --gpus %d but this node shows %d HIP device(s) (torch.cuda.device_count()); nothing launched"
+                                 % (args.gpus, have))
         return self_launch(args.gpus, list(sys.argv[1:] if argv is None else argv))
 
     import numpy as np
@@ -1033,8 +1042,14 @@ def main(argv=None):
         ensure_library(_lib.LIB_PATH, int(os.environ.get('LOCAL_RANK', '0')), __graft_entry__.build)
     from monoloco_amd import engine, parallel
 
-    multi = int(os.environ.get('WORLD_SIZE', '1')) > 1
-    rank, world, local = parallel.init_from_env(('gloo' if stub else 'nccl') if multi else None)
+    multi = int(os.environ.get('WORLD_SIZE', '1')) > 1 or args.force_distributed
+    if not stub and multi:
+        # one-line, non-zero failure BEFORE the rendezvous when this rank has no device of its own (torchrun with more ranks than GPUs)
+        have, want_local = torch.cuda.device_count(), int(os.environ.get('LOCAL_RANK', '0'))
+        if have <= want_local or have < min(args.gpus, int(os.environ.get('LOCAL_WORLD_SIZE', args.gpus))):
+            raise SystemExit("bench.py: rank %s (local rank %d) has no HIP device of its own: --gpus %d, torch.cuda.device_count() = %d"
+                             % (os.environ.get('RANK', '0'), want_local, args.gpus, have))
+    rank, world, local = parallel.init_from_env(('gloo' if stub else 'nccl') if multi else None, force=args.force_distributed)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's --nproc-per-node and --gpus must agree)"
                          % (args.gpus, world))
@@ -1094,7 +1109,7 @@ def main(argv=None):
     xyzds = torch.empty((n_out, 5), dtype=torch.float32, device=dev)
     raw = torch.empty((n_out, eng.out_features), dtype=torch.float32, device=dev)
     total_out = args.total_rows if strong else n_out * world
-    sharded = parallel.ShardedRows(total_out, 5, dev, mode=args.gather) if world > 1 else None
+    sharded = parallel.ShardedRows(total_out, 5, dev, mode=args.gather) if multi else None
 
     def local_block(lo=0, hi=0):
         if args.workload == 'mono':
@@ -1118,7 +1133,7 @@ def main(argv=None):
     # who took part: one record per rank (its device's identity and its own clock around the same K steps)
     me = {"rank": rank, "local_rank": local, "device": device_identity(dev), "rows": rows,
           "ms_per_step": round(mine['local_s'] / args.steps * 1e3, 4)}
-    if world > 1:
+    if multi:
         seen = [None] * world
         dist.all_gather_object(seen, me)
     else:
@@ -1148,7 +1163,7 @@ def main(argv=None):
     # N > 1: the same launch also times BASELINE configs[3] (1,048,576 persons cut into N shards, one gather: "strong"), so the
     # driver's `bench.py --gpus N` needs no further flags to cover it; reported as `config4_strong` beside the weak line
     strong4 = None
-    if world > 1 and not strong and args.workload == 'mono':
+    if multi and not strong and args.workload == 'mono':
         total4 = 1048576
         lo4, hi4 = parallel.shard_bounds(total4, world, rank)
         m4 = hi4 - lo4
@@ -1192,6 +1207,13 @@ def main(argv=None):
                        "weights": weights_txt,
                        "parallelism": "rows sharded x%d, 1 %s" % (world, args.gather)},
         }
+        if multi:
+            # which collective library carried the gather: RCCL's version as torch reports it (the `nccl` backend IS RCCL on ROCm)
+            try:
+                line["collectives"] = {"backend": dist.get_backend(), "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())
+                                       if not stub else None, "forced_at_world_1": bool(args.force_distributed and world == 1)}
+            except Exception as e:   # identity garnish
+                line["collectives"] = {"backend": dist.get_backend(), "rccl_version": repr(e)[:80]}
         line["ranks_seen"] = len({(r["rank"], r["device"]) for r in seen})
         line["ranks"] = seen
         per = [r["ms_per_step"] for r in seen]
@@ -1234,7 +1256,7 @@ def main(argv=None):
                         "time on rank 0 (HIP events on the launch stream); executed MFMA FLOP are %sx higher"
                         % (FLOP_PER_ROW[args.workload], "~2.6" if args.precision == 'f16x2' else "~0.88"),
             }
-        if world == 1 and "roofline" in line and not args.no_live_counters and args.workload == 'mono' and not stub \
+        if world == 1 and not multi and "roofline" in line and not args.no_live_counters and args.workload == 'mono' and not stub \
                 and not args.total_rows and not args.tile_kernel and args.chunk_rows < 0 \
                 and args.batch == 65536 and args.precision == 'f16x2' and not args.no_merge:   # (the launch list tools/traffic_from_pmc.py knows)
             # the counters of THIS run: child processes of the same command under rocprofv3 (the parent only waits meanwhile)
@@ -1261,14 +1283,14 @@ def main(argv=None):
                 line["roofline"]["power"] = pw
         if args.workload == 'mono' and not stub and not args.no_parity:
             line["parity"] = parity_of_timed_run(sd, kps, conf, xyzds, raw, kk, out)
-        if world == 1 and args.workload == 'mono' and not args.no_extra and not stub:
+        if world == 1 and not multi and args.workload == 'mono' and not args.no_extra and not stub:
             line["extra"] = extras(args, dev, sd, eng, kps, conf, kinv, kk, ms_per_step, main_out=(out.clone(), xyzds.clone()))
             if "e2e" in line["extra"] and "e2e_ms" in line["extra"]["e2e"]:
                 line["e2e_ms"] = line["extra"]["e2e"]["e2e_ms"]
         if world == 1 and args.cpu_seconds > 0 and args.workload == 'mono' and not stub:
             line["cpu_baseline"] = cpu_baseline(sd, kps_np, kk, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -18,13 +18,15 @@ def shard_bounds(total_rows, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise torch.distributed from torchrun's env (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*).
-    Returns (rank, world_size, local_rank).  A single process is (0, 1, 0) with no group."""
+    Returns (rank, world_size, local_rank).  A single process is (0, 1, 0) with no group -- unless ``force``: then a
+    world-size-1 group is created too, so that the very code path of N > 1 (process group, collectives on the real
+    backend) can be exercised on a one-GPU box (bench.py --force-distributed, tests/test_gpu_parallel.py)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:

@@ -102,3 +102,46 @@ def test_w4_is_deterministic_and_row_independent(hip_lib, cuda_device):
     _, x2, r2 = eng.forward_mono(kps[perm].contiguous(), kinv, want_raw=True)
     assert torch.equal(r2, r0[perm])
     eng.close()
+
+
+@pytest.mark.parametrize("rows", [65536, 8192])
+def test_w4_repeat_run_stress_on_two_streams(hip_lib, cuda_device, rows):
+    """The repeat-run detector that found the xgemm prologue race (profiles/r03_xgemm_occupancy.md), pointed at dense_kernel_w4's
+    hand-counted LDS-DMA ring: 200 forwards -- two engines on two HIP streams, launched alternately so that their workgroups
+    share CUs, L2 and the memory system in ever-changing phase -- must all produce the bits of the first, quiet run.  A wait that
+    is one DMA group short, a hazard pad that a new compiler no longer respects or a slot refilled one barrier early shows up
+    here as a handful of differing 32 x 32 sub-tiles in some run; the test reports how many rows differed and in which run.
+    65536 rows: the full-size tile walking several tiles per workgroup; 8192 rows: the half-size tile (NJ = 2)."""
+    from monoloco_amd import engine
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(1).items()}
+    kinv = engine.inverse_intrinsics(synth.KITTI_K)
+    engs = [engine.LocoEngine(sd, device=cuda_device, reserve_rows=rows) for _ in range(2)]
+    for e in engs:
+        if rows > 8192:
+            e.set_tuning(tile_kernel=4, everywhere=True)
+    kps = [torch.tensor(synth.make_keypoints(rows, seed=31 + i)).to(cuda_device) for i in range(2)]
+    want = []
+    for e, k in zip(engs, kps):
+        _, _, r = e.forward_mono(k, kinv, want_raw=True)
+        want.append(r.clone())
+    torch.cuda.synchronize(cuda_device)
+    assert engs[0].route_for_rows(rows) == ('tile' if rows > 8192 else 'half')
+    streams = [torch.cuda.Stream(cuda_device) for _ in range(2)]
+    outs = [[torch.empty((rows, 16), dtype=torch.float32, device=cuda_device) for _ in range(4)] for _ in range(2)]
+    xyz = [[torch.empty((rows, 5), dtype=torch.float32, device=cuda_device) for _ in range(4)] for _ in range(2)]
+    raws = [[torch.empty_like(want[0]) for _ in range(4)] for _ in range(2)]
+    bad = []
+    n_runs = 100                      # per stream: 200 forwards = 1400 w4 launches at 65536 rows
+    for base in range(0, n_runs, 4):
+        for j in range(4):
+            for s in range(2):        # alternate the two streams launch by launch
+                with torch.cuda.stream(streams[s]):
+                    engs[s].forward_mono(kps[s], kinv, out=outs[s][j], xyzds=xyz[s][j], raw=raws[s][j])
+        torch.cuda.synchronize(cuda_device)
+        for j in range(4):
+            for s in range(2):
+                if not torch.equal(raws[s][j], want[s]):
+                    bad.append((base + j, s, int((raws[s][j] != want[s]).any(1).sum())))
+    for e in engs:
+        e.close()
+    assert not bad, "runs whose bits differ (run, stream, rows differing): %s" % bad[:10]

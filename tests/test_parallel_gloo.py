@@ -231,6 +231,16 @@ def test_bench_main_under_torchrun_world2():
     assert 'all_gather' in d['config']['parallelism']
 
 
+def test_bench_main_forced_through_the_n_gt_1_branch_at_world_1():
+    """--force-distributed: a world-size-1 process group, and every statement of the N > 1 branch (sharded rows, gather,
+    gather_check, the all_gather_object of device identities, config4_strong) -- what tests/test_gpu_parallel.py runs on RCCL."""
+    d = _run_bench(['bench.py', '--gpus', '1', '--stub-engine', '--steps', '2', '--warmup', '1', '--batch', '256', '--force-distributed'],
+                   extra_env={'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(_free_port())})
+    assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['collectives']['backend'] == 'gloo' and d['collectives']['forced_at_world_1']
+    assert d['gather_check']['ok'] and d['gather_check']['shards'] == 1 and d['gather_ms'] > 0
+    assert d['config4_strong']['rows_per_gpu'] == 1048576
+
+
 def test_bench_main_strong_world2():
     d = _run_bench(['bench.py', '--gpus', '2', '--stub-engine', '--steps', '2', '--warmup', '1', '--total-rows', '1001'])
     assert d['scaling'] == 'strong' and d['ranks_seen'] == 2
