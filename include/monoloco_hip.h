@@ -412,6 +412,9 @@ int ml_loco_profile_end(ml_loco* h, int64_t* launches, double* total_ms, double*
 #define ML_DEBUG_TILE_W4 1024   /* ... the tile path on dense_kernel_w4 wherever it runs (default: w4 for K > 128) */
 #define ML_DEBUG_MID_64 2048    /* ... dense_mid_kernel with 128 x 64 tiles */
 #define ML_DEBUG_MID_128 4096   /* ... dense_mid_kernel with 128 x 128 tiles */
+#define ML_DEBUG_MID_SPLIT2 8192   /* ... its reduction cut into 2 k ranges per output tile (split-K, the last arriver runs the epilogue) */
+#define ML_DEBUG_MID_SPLIT4 16384  /* ... into 4 */
+#define ML_DEBUG_MID_NODMA 32768   /* ... dense_mid_kernel with the rounds-3-5 loader (global -> VGPR -> ds_write) instead of LDS-DMA */
 int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, const float* b_host,
                     int n, int relu, const float* res_dev, float* y_dev, int precision, void* stream);
 /* Host fp32 -> fp16 hi/lo split used by the packer (round-to-nearest-even), for unit tests. */

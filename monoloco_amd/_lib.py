@@ -26,6 +26,9 @@ ML_DEBUG_TILE_PP = 512
 ML_DEBUG_TILE_W4 = 1024
 ML_DEBUG_MID_64 = 2048
 ML_DEBUG_MID_128 = 4096
+ML_DEBUG_MID_SPLIT2 = 8192
+ML_DEBUG_MID_SPLIT4 = 16384
+ML_DEBUG_MID_NODMA = 32768
 ML_FLAG_MERGE_W2W3 = 1
 ML_FLAG_HOST_ONLY = 256
 ML_OUT_STRIDE = 16

@@ -49,7 +49,10 @@ struct DenseParams {
     float descale;      // 2^-e
     const float* descale_ptr;  // if not null: 2^-e lives on the device (weights packed on the device, training path)
     int M_pad, N, K;    // M_pad % 256 == 0, N % 256 == 0, K % 32 == 0
-    int ksplit = 1;     // dense_kernel_w4<.., -3> only: work items per output tile, each reducing over K columns
+    int ksplit = 1;     // dense_kernel_w4<.., -3>: work items per output tile, each reducing over K columns; dense_mid_kernel<.., SPLITK>:
+                        // k ranges per output tile (the K / 32 steps divide evenly), partial tiles in kpart, tickets in kcount
+    float* kpart = nullptr;       // [tiles][ksplit][128 x TM] fp32 partial tiles (dense_mid_kernel<.., SPLITK>)
+    unsigned* kcount = nullptr;   // [tiles] arrival counters, zero between launches
     int relu;
     int debug;          // bring-up/ablation bits (0 in production), see dense_kernel_pp.h
     unsigned long long* trace;  // optional s_memtime trace [grid][8 waves][64], nullptr in production

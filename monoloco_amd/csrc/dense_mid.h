@@ -26,8 +26,24 @@
 // 64 columns instead of the activation tile (the layer that feeds w_fin is never stored); -1: w_aux's partial sums beside the
 // stored tile (of the stored hi + lo values); head_part holds N/64 slices per head here (the tile kernels: N/128), tail_mono_kernel /
 // head_reduce_kernel add them in slice order.  0: no head (heads_pair_kernel or launch_heads behind the last layer).
+// SPLITK (round 6): the reduction of ONE output tile is cut into p.ksplit contiguous k ranges, one workgroup each -- a 1024 x 1024 layer
+// at 2048 rows is 256 tiles = one workgroup per CU, whose single wave per SIMD pays every wait in full (fragment read -> MFMA -> barrier:
+// ~1100 cycles per k-step for 384 cycles of MFMA, 384 of LDS pipe and 384 of vector-memory pipe).  With 2-4 k ranges per tile the chip holds
+// 512 workgroups, two or three per CU, and one's waits hide behind another's MFMAs.  The epilogue (ReLU, residual, hi|lo split, fused heads)
+// needs the COMPLETE sum: every workgroup stores its fp32 partial tile (thread-linear float4s: coalesced) to p.kpart with agent-scope
+// write-through stores (the XCDs' L2s are not coherent with each other; no fence -- see below) and takes a ticket from the tile's counter;
+// whoever draws the last ticket reads the others' partials with agent-scope loads, adds them IN SPLIT ORDER (its own from registers at its
+// own position: the bits do not depend on who arrives last), runs the unchanged epilogue and re-arms the counter for the next launch.  Nobody ever waits for anybody: no co-residency
+// assumption, no deadlock.  Split 0 starts from the bias, the others from zero.
 #pragma once
 #include "dense_kernel_pp.h"
+
+// timing ablations of the LDS-DMA loop, COMPILE-TIME (-DML_MID_ABL=<bits>, results are garbage): 1 no requests inside the loop, 2 no MFMAs,
+// 4 no fragment reads, 8 no barrier / vmcnt wait per step, 16 no epilogue stores
+#ifndef ML_MID_ABL
+#define ML_MID_ABL 0
+#endif
+#define MID_DBG(bit) (((ML_MID_ABL) & (bit)) != 0)
 
 namespace mlk {
 
@@ -41,15 +57,27 @@ struct MidCfg {
     static constexpr int W_BYTES = MID_TN * LINE;        // 16 KiB
     static constexpr int STAGE = W_BYTES + TM * LINE;    // W rows then X rows
     static constexpr int LDS = 2 * STAGE;
+    static constexpr int LDS_DMA = 3 * STAGE;            // the LDS-DMA loader's ring: 72 / 96 KiB
+    static constexpr int NI = (MID_TN + TM) / 32;        // LDS-DMA instructions (8 rows each) per wave and step
 };
 
-template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0>
-__global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p) {
+// DMA (round 6): the loader is LDS-DMA (global_load_lds_dwordx4 straight into a ring of three stages, the chunk swizzle applied on the
+// source address) instead of global -> VGPR -> ds_write.  Why: the register-staged loop is FEED-bound, not LDS- or latency-bound -- a
+// 128 x 64 tile pulls (128 + 64) x 4 KiB = 768 KiB through its CU in 20 us = 18 B/clk, exactly what tools/ubench/feed.hip measures for
+// `global_load_dwordx4 -> VGPR` with every CU pulling (18.5 B/clk/CU, 11 TB/s chip-wide; profiles/r01_ablation.md), which is why deeper
+// prefetch, pipelined fragment reads (r05_ablation.md section 5) and two co-resident workgroups per CU (split-K, r06_ablation.md) all
+// changed nothing; the LDS-DMA path delivers 34-36 B/clk/CU in the same micro-benchmark.  One raw s_barrier per step; the stage read in
+// step i - 1 is refilled with step i + 2 right behind step i's barrier; every wave waits for its OWN share of a stage with a counted
+// vmcnt(NI) (requests retire in order; past the end the requests repeat the last step so that the count never changes).
+template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0, bool SPLITK = false, bool DMA = false>
+__global__ __launch_bounds__(MID_THREADS, (DMA && TM == 128) ? 1 : 2) void dense_mid_kernel(DenseParams p) {   // (the 96 KiB ring: one workgroup per CU)
     typedef MidCfg<TM> C;
     constexpr int NB = C::NB, XL = C::XL;
     constexpr bool AUX = HEAD == -1;
     static_assert(HEAD == 0 || HEAD == -1 || ((HEAD == 8 || HEAD == 9) && RELU && !RES), "fused head: w_aux (-1) or w_fin (8 | 9) behind relu, no residual");
-    __shared__ __attribute__((aligned(16))) char smem[C::LDS];
+    __shared__ __attribute__((aligned(16))) char smem[DMA ? C::LDS_DMA : C::LDS];
+    // (the split-K ticket lives in the first word of the stage buffers, free behind the loop: a SECOND LDS object makes hipcc guard
+    //  every fragment read that follows an LDS-DMA request with its own vmcnt(0) -- seen in the ISA, tools/check_loops.py)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -60,20 +88,27 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
     // column tile fastest, so that the workgroups resident on an XCD share a few row panels of X
     const int tiles_n = p.N / MID_TN;
     const int tiles = tiles_n * (p.M_pad / TM);
-    const int per = (tiles + 7) >> 3;
-    const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-    if (tile >= tiles) return;
-    const int n0 = (tile % tiles_n) * MID_TN;
-    const int m0 = (tile / tiles_n) * TM;
+    const int S = SPLITK ? p.ksplit : 1;
+    const int units = tiles * S;             // work items: (row panel, k range, column tile), column tile fastest: the 8 workgroups that run
+    const int per = (units + 7) >> 3;        // side by side on an XCD share one k range of one X panel
+    const int unit = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (unit >= units) return;
+    const int nt = unit % tiles_n;
+    const int split = SPLITK ? (unit / tiles_n) % S : 0;
+    const int mt = unit / (tiles_n * S);
+    const int tile = mt * tiles_n + nt;
+    const int n0 = nt * MID_TN;
+    const int m0 = mt * TM;
 
     const size_t rowb = (size_t)p.K * 4;
-    const int nk = p.K / 32;
+    const int nk = (p.K / 32) / S;           // k32 steps of this work item (the host guarantees divisibility)
+    const size_t kbase = (size_t)split * nk * LINE;
     const float descale = p.descale_ptr ? *p.descale_ptr : p.descale;
 
     // loader: thread -> (row lrow + 32 j, chunk lch) of both operands
     const int lrow = tid >> 3, lch = tid & 7;
-    const char* gw = p.w + (size_t)(n0 + lrow) * rowb + lch * 16;
-    const char* gx = p.x + (size_t)(m0 + lrow) * rowb + lch * 16;
+    const char* gw = p.w + (size_t)(n0 + lrow) * rowb + lch * 16 + kbase;
+    const char* gx = p.x + (size_t)(m0 + lrow) * rowb + lch * 16 + kbase;
     const int lst = lrow * LINE + ((lch ^ ((lrow >> 1) & 7)) * 16);   // + 32 j rows (the swizzle term repeats every 16 rows)
 
     struct Raw {
@@ -124,7 +159,8 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 b4 = *(const f32x4*)(p.bias_scaled + n0 + wn * 64 + a * 32 + 8 * g + 4 * q);
+            f32x4 b4 = *(const f32x4*)(p.bias_scaled + n0 + wn * 64 + a * 32 + 8 * g + 4 * q);
+            if (SPLITK && split != 0) b4 = f32x4{0.f, 0.f, 0.f, 0.f};   // the bias enters the sum once, with the first k range
 #pragma unroll
             for (int c = 0; c < NB; ++c)
 #pragma unroll
@@ -141,48 +177,208 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
             }
     };
 
-    Raw R0, R1;
-    gload(R0, 0);
-    gload(R1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XL) : "memory");
-    lstore(R0, 0);
-    gload(R0, 2);
-    __syncthreads();
-
-    // step i: LDS stage i&1 holds k-step i; the set named `nxt` holds step i+1 (requested two steps ago), the other set
-    // step i+2 (requested one step ago, stays in flight across the wait).  Schedules measured against this one (us per forward
-    // at 4096 / 8192 rows, 128-row tiles; this one: 256-259 / 403-406):
-    //   * the barrier in the middle of the step's MFMAs, the next step's first fragments requested right behind it: 271 / 422;
-    //   * the loader without a branch (the `if (i + 1 < nk)` below makes hipcc's own waitcnt insertion drain ALL requests,
-    //     vmcnt(0), before every second LDS store; branch-free it waits for exactly the set it stores, vmcnt(8)): 256 / 428 --
-    //     no gain with one workgroup per CU, a loss with two;
-    //   * three register sets (requests three steps ahead), loader unconditional, MFMAs of padded steps skipped: 267 / 425;
-    //   * round 5, for ONE 128 x 64 tile per CU (<= 2048 rows): three register sets behind two stages (148 vs 150 us per forward at
-    //     1024 rows, 160 vs 161 at 2048: -1 %), and three LDS stages + three sets with the next step's first fragments read behind
-    //     this step's first MFMAs, branch-free groups of six steps so that hipcc's waits stay counted (vmcnt(12) in front of every
-    //     store, checked in the ISA): 150.7 vs 150.0 at 1024 rows, 158 vs 156 at 2048 -- neither the request latency nor the
-    //     fragment round trip is what a step waits for; the step is LDS-pipe time (12 reads + 6 writes of 1 KiB per wave and step)
-    //     plus a barrier.  Both removed again (profiles/r05_ablation.md section 5).
-    // With two workgroups per CU the kernel is bound by the LDS pipe both of them feed through (reads + writes = the 768 MFMA
-    // cycles of a step at 128 B/clk; profiles/r03_mid_pmc_rows8192.txt: matrix pipe 39-44 % busy, 16 % of the wave cycles waiting on
-    // LDS, 3.5 % bank conflicts), not by request latency.
-    auto step = [&](Raw& nxt, int i) {
-        const int s = i & 1;
-        Frag f0, f1;
-        fread(f0, s, 0);
-        fread(f1, s, 1);
-        mma_rows(f0, 0);
-        mma_rows(f0, 1);
+    if (DMA) {
+        constexpr int NI = C::NI;
+        // instruction j of wave w fetches row group gq = w + 4 j of the stage (8 rows x 128 B = 1 KiB, lane-linear in LDS): groups
+        // 0..15 are the 128 W rows, the rest the TM X rows; lane -> row 8 gq + lane / 8, position lane % 8, source chunk = position ^ swizzle(row)
+        const char* gsrc[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int gq = w + 4 * j;
+            const bool is_w = gq < MID_TN / 8;   // (wave-uniform)
+            const int rr = 8 * gq + (lane >> 3) - (is_w ? 0 : MID_TN);
+            const char* base = is_w ? p.w + (size_t)(n0 + rr) * rowb : p.x + (size_t)(m0 + rr) * rowb;
+            gsrc[j] = base + kbase + (((lane & 7) ^ ((rr >> 1) & 7)) * 16);
+        }
+        // instructions [ja, jb) of this wave's share of stage `st` <- k-step k
+        auto issue = [&](int st, int k, int ja, int jb) {
+            const int kk = k < nk ? k : nk - 1;   // past the end: a harmless repeat (the vmcnt arithmetic stays constant)
+            char* sb = smem + st * C::STAGE + w * 1024;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (j >= ja && j < jb) glds16(gsrc[j] + (size_t)kk * LINE, sb + j * 4096);
+        };
+        // the bias loads above are the only ordinary vector loads in front of the epilogue: complete them HERE (left alone, hipcc
+        // sinks their wait to the first MFMA inside the loop and, with LDS-DMA in the same queue, makes it a vmcnt(0) per step --
+        // seen in the split-K instantiations' ISA, tools/check_loops.py)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < NB; ++c) asm volatile("" : "+v"(acc[a][c]));
+        issue(0, 0, 0, NI);
+        issue(1, 1, 0, NI);
+        issue(2, 2, 0, NI);
+        // One request behind every unit of three MFMAs (one 32 x 32 output block's hi.lo + lo.hi + hi.hi: 96 matrix-pipe cycles against
+        // ~110 of issue) -- TM = 128: eight units, eight requests; TM = 64: four units, six requests (2 + 2 + 1 + 1).
+        auto mma_unit = [&](const Frag& f, int a, int c) {
+            if (MID_DBG(2)) return;
+            if (NSPLIT == 3) {
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.whi[a], f.xlo[c], acc[a][c], 0, 0, 0);
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.wlo[a], f.xhi[c], acc[a][c], 0, 0, 0);
+            }
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.whi[a], f.xhi[c], acc[a][c], 0, 0, 0);
+        };
+        auto read_step = [&](Frag& g0, Frag& g1, int st) {
+            if (!MID_DBG(4)) {
+                fread(g0, st, 0);
+                fread(g1, st, 1);
+            } else {
+                asm volatile("" : "=v"(g0.whi[0]), "=v"(g0.whi[1]), "=v"(g0.wlo[0]), "=v"(g0.wlo[1]));
+                asm volatile("" : "=v"(g1.whi[0]), "=v"(g1.whi[1]), "=v"(g1.wlo[0]), "=v"(g1.wlo[1]));
+#pragma unroll
+                for (int c = 0; c < NB; ++c) asm volatile("" : "=v"(g0.xhi[c]), "=v"(g0.xlo[c]), "=v"(g1.xhi[c]), "=v"(g1.xlo[c]));
+            }
+        };
+        // The fragment reads are pipelined ONE STEP AHEAD in registers (round 6; ablation: un-pipelined they cost 300-400 exposed cycles
+        // per step between the barrier and the first MFMA -- 6.4 us of a 26 us layer at 4096 rows, profiles/r06_ablation.md).  Step i:
+        //   wait: my share of stage i + 1 has landed (only stage i + 2's requests are younger: vmcnt(NI)), my reads of stage i are complete
+        //   barrier: everybody's share of stage i + 1; everybody is done reading stage i, whose buffer is therefore free
+        //   read the fragments of stage i + 1 into the other register set; the MFMAs of stage i, with stage i + 3's requests
+        //   (into stage i's buffer) between them
+        Frag fa0, fa1, fb0, fb1;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+        pp_barrier();
+        read_step(fa0, fa1, 0);
+        int st = 0;   // buffer of stage i
+        auto step_dma = [&](Frag& c0, Frag& c1, Frag& n0f, Frag& n1f, int i) {
+            const int nst = st == 2 ? 0 : st + 1;
+            if (!MID_DBG(8)) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+                pp_barrier();
+            }
+            read_step(n0f, n1f, nst);   // (unconditional: behind the last step it reads a landed repeat nobody uses -- a branch here makes hipcc wait lgkmcnt(0) at the join, in front of the MFMAs)
+            int j = 0;
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) {
+                        mma_unit(hs ? c1 : c0, a, c);     // (same order as mma_rows: the same bits as the register-staged loop)
+                        const int unit = (hs * 2 + a) * NB + c, n_here = NB == 2 ? 1 : (unit < 2 ? 2 : 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!MID_DBG(1)) issue(st, i + 3, j, j + n_here);
+                        __builtin_amdgcn_sched_barrier(0);
+                        j += n_here;
+                    }
+            st = nst;
+        };
+        for (int i = 0; i < nk; i += 2) {
+            step_dma(fa0, fa1, fb0, fb1, i);
+            if (i + 1 < nk) step_dma(fb0, fb1, fa0, fa1, i + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeats behind the end have landed: the stages become epilogue scratch
+        pp_barrier();
+    } else {
+        Raw R0, R1;
+        gload(R0, 0);
+        gload(R1, 1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XL) : "memory");
-        if (i + 1 < nk) lstore(nxt, s ^ 1);
-        gload(nxt, i + 3);
-        mma_rows(f1, 0);
-        mma_rows(f1, 1);
+        lstore(R0, 0);
+        gload(R0, 2);
         __syncthreads();
-    };
-    for (int i = 0; i < nk; i += 2) {
-        step(R1, i);
-        if (i + 1 < nk) step(R0, i + 1);
+
+        // step i: LDS stage i&1 holds k-step i; the set named `nxt` holds step i+1 (requested two steps ago), the other set
+        // step i+2 (requested one step ago, stays in flight across the wait).  Schedules measured against this one (us per forward
+        // at 4096 / 8192 rows, 128-row tiles; this one: 256-259 / 403-406):
+        //   * the barrier in the middle of the step's MFMAs, the next step's first fragments requested right behind it: 271 / 422;
+        //   * the loader without a branch (the `if (i + 1 < nk)` below makes hipcc's own waitcnt insertion drain ALL requests,
+        //     vmcnt(0), before every second LDS store; branch-free it waits for exactly the set it stores, vmcnt(8)): 256 / 428 --
+        //     no gain with one workgroup per CU, a loss with two;
+        //   * three register sets (requests three steps ahead), loader unconditional, MFMAs of padded steps skipped: 267 / 425;
+        //   * round 5, for ONE 128 x 64 tile per CU (<= 2048 rows): three register sets behind two stages (148 vs 150 us per forward at
+        //     1024 rows, 160 vs 161 at 2048: -1 %), and three LDS stages + three sets with the next step's first fragments read behind
+        //     this step's first MFMAs, branch-free groups of six steps so that hipcc's waits stay counted (vmcnt(12) in front of every
+        //     store, checked in the ISA): 150.7 vs 150.0 at 1024 rows, 158 vs 156 at 2048 -- neither the request latency nor the
+        //     fragment round trip is what a step waits for; the step is LDS-pipe time (12 reads + 6 writes of 1 KiB per wave and step)
+        //     plus a barrier.  Both removed again (profiles/r05_ablation.md section 5).
+        // With two workgroups per CU the kernel is bound by the LDS pipe both of them feed through (reads + writes = the 768 MFMA
+        // cycles of a step at 128 B/clk; profiles/r03_mid_pmc_rows8192.txt: matrix pipe 39-44 % busy, 16 % of the wave cycles waiting on
+        // LDS, 3.5 % bank conflicts), not by request latency.
+        auto step = [&](Raw& nxt, int i) {
+            const int s = i & 1;
+            Frag f0, f1;
+            fread(f0, s, 0);
+            fread(f1, s, 1);
+            mma_rows(f0, 0);
+            mma_rows(f0, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + XL) : "memory");
+            if (i + 1 < nk) lstore(nxt, s ^ 1);
+            gload(nxt, i + 3);
+            mma_rows(f1, 0);
+            mma_rows(f1, 1);
+            __syncthreads();
+        };
+        for (int i = 0; i < nk; i += 2) {
+            step(R1, i);
+            if (i + 1 < nk) step(R0, i + 1);
+        }
+    }
+
+    if (SPLITK) {
+        // ---- the partial tile of this k range -> p.kpart[tile][split][quad][thread] (float4 per thread and quad: whole 4 KiB rows).
+        // The XCDs' L2s are not coherent with each other, and a release / acquire FENCE at agent scope writes back and invalidates a whole
+        // L2 (measured: a forward 4-7x slower with __threadfence() -- every workgroup threw away the weights its neighbours were reading).
+        // So the partials never live in a non-coherent cache line at all: stores and loads carry the agent-scope bit (sc1: write-through
+        // to / read from the device-coherent level), which is what an agent-scope relaxed atomic access compiles to; a store's vmcnt
+        // return means it is performed at that scope.  Order: my stores performed (vmcnt 0) -> workgroup barrier -> the ticket (a relaxed
+        // agent-scope atomic) -> barrier -> the last arriver's loads.
+        constexpr int QUADS = 2 * NB * 4;
+        const f32x4* const all = (const f32x4*)p.kpart + (size_t)tile * S * (QUADS * MID_THREADS) + tid;
+        f32x4* const mine = (f32x4*)all + (size_t)split * (QUADS * MID_THREADS);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[a][c][g * 4], acc[a][c][g * 4 + 1], acc[a][c][g * 4 + 2], acc[a][c][g * 4 + 3]};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + ((a * NB + c) * 4 + g) * MID_THREADS), "v"(v) : "memory");
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        volatile unsigned* const ticket_s = (volatile unsigned*)smem;
+        if (tid == 0) *ticket_s = __hip_atomic_fetch_add(p.kcount + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ticket = *ticket_s;
+        __syncthreads();                             // (everybody has read it: the epilogue's scratch may overwrite the word)
+        if (ticket != (unsigned)(S - 1)) return;   // (workgroup-uniform) not the last k range to finish: done
+        // the partials IN SPLIT ORDER, whoever reduces (the bits do not depend on the arrival order): the ranges before mine summed
+        // first, then mine (a + b == b + a exactly), then the ranges behind it
+        f32x4 pre[QUADS], tmp[QUADS];
+        auto fetch = [&](f32x4* dst, int s2) {
+#pragma unroll
+            for (int qd = 0; qd < QUADS; ++qd)
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst[qd]) : "v"(all + ((size_t)s2 * QUADS + qd) * MID_THREADS) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int qd = 0; qd < QUADS; ++qd) asm volatile("" : "+v"(dst[qd]));   // (values are defined from here on)
+        };
+        auto add_to_acc = [&](const f32x4* src) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[a][c][g * 4 + e] += src[(a * NB + c) * 4 + g][e];
+        };
+        if (split > 0) {
+            fetch(pre, 0);
+            for (int s2 = 1; s2 < split; ++s2) {
+                fetch(tmp, s2);
+#pragma unroll
+                for (int qd = 0; qd < QUADS; ++qd) pre[qd] += tmp[qd];
+            }
+            add_to_acc(pre);
+        }
+        for (int s2 = split + 1; s2 < S; ++s2) {
+            fetch(tmp, s2);
+            add_to_acc(tmp);
+        }
+        if (tid == 0) __hip_atomic_store(p.kcount + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
     }
 
     // ---- epilogue: the stage buffers are free behind the last barrier; wave w takes 4 KiB of them as its scratch
@@ -290,7 +486,10 @@ __global__ __launch_bounds__(MID_THREADS, 2) void dense_mid_kernel(DenseParams p
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) d[qq] = *(const f32x4*)(scr + rd_off + qq * 1024);
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) *(f32x4*)(p.y + line0 + (size_t)(qq * 8) * yrowb + st_off) = d[qq];
+            for (int qq = 0; qq < 4; ++qq) {
+                if (MID_DBG(16)) asm volatile("" ::"v"(d[qq]));
+                else *(f32x4*)(p.y + line0 + (size_t)(qq * 8) * yrowb + st_off) = d[qq];
+            }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -162,6 +162,11 @@ struct Tuning {
     int mid_rows = 8192, mid_tile = 0;
     int half_from = 4096;   // mid window, rows above this: the long-K layers on dense_kernel_w4's half-size tile (mid_tile 256 forces it)
     int small_multi = 1;    // small-row window, > 64 rows: dense_small_multi_kernel (option "small_multi"; 0: one tile per workgroup, rounds 1-4)
+    int mid_splitk = -1;    // dense_mid_kernel: k ranges per output tile (workgroups that share a tile, last arriver runs the epilogue):
+                            // -1 = auto (as many as it takes to reach mid_wgs workgroups: 1 | 2 | 4), 0 / 1 = off, 2 / 4 = forced where K allows
+    int mid_wgs = 256;      // ... auto: workgroups a dense_mid_kernel launch should reach: one per CU -- splitting only fills IDLE CUs (fewer
+                            // tiles than CUs); two co-resident workgroups per CU lose 10-40 % (measured, profiles/r06_ablation.md)
+    int mid_dma = 1;        // dense_mid_kernel's loader: 1 = LDS-DMA into a three-stage ring (round 6), 0 = global -> VGPR -> ds_write (rounds 3-5)
     int half_heads = 1;     // the whole mid window: both heads ride in the dense epilogues (half-size w4 tile / dense_mid_kernel) + tail_mono_kernel
                             // (option "mid_heads"; 0: heads_pair_kernel behind the last layer, rounds 3-4)
 };
@@ -192,6 +197,9 @@ struct ml_loco {
     float* d_part = nullptr;    // fused-head partial sums [2*hidden/256][cap_rows][16] ...
     float* d_part_aux = nullptr;  // ... and, behind them, the fused w_aux head's [2*hidden/256][cap_rows] (same allocation)
     int64_t part_cells = 0;     // (slice, row) cells per head d_part / d_part_aux hold (part_cells_for)
+    float* d_kpart = nullptr;   // dense_mid_kernel<.., SPLITK>: fp32 partial tiles [tiles][ksplit][128 x TM] ...
+    unsigned* d_kcount = nullptr;   // ... and the tiles' arrival counters (zero between launches)
+    int64_t kpart_floats = 0;
     // ml_loco_frame_mono's completion word (pinned, coherent) + the arrival counter of the last launch's workgroups; frame_flag_req:
     // the frame entry asks run_network to arm the flag in the launch that ends a single image's forward
     int* h_done = nullptr;
@@ -365,6 +373,11 @@ int free_workspace(ml_loco* h) {
     dev_free(h->d_raw);
     dev_free(h->d_rowidx);
     dev_free(h->d_part);
+    dev_free(h->d_kpart);
+    dev_free(h->d_kcount);
+    h->d_kpart = nullptr;
+    h->d_kcount = nullptr;
+    h->kpart_floats = 0;
     dev_free(h->d_mc);
     h->d_mc = nullptr;
     h->d_xf32 = h->d_centre = h->d_raw = h->d_part = h->d_part_aux = nullptr;
@@ -381,6 +394,8 @@ static int64_t part_cells_for(int hidden, int64_t need) {
     const int64_t coarse = (int64_t)(2 * hidden / 256) * need;
     return fine > coarse ? fine : coarse;
 }
+
+constexpr int MID_KCOUNT = 8192;   // arrival counters of dense_mid_kernel<.., SPLITK>: one per output tile of a launch
 
 int ensure_rows(ml_loco* h, int64_t rows) {
     const int64_t need = round_up64(rows > 0 ? rows : 1, 256);
@@ -400,6 +415,11 @@ int ensure_rows(ml_loco* h, int64_t rows) {
     if ((rc = dev_alloc(h, &h->d_part, h->part_cells * 17 * 4))) return rc;
     h->d_part_aux = h->d_part + h->part_cells * 16;
     if ((rc = dev_alloc(h, &h->d_mc, need * 4 * (int64_t)sizeof(double)))) return rc;
+    // split-K partial tiles of the mid window (dense_mid_kernel<.., SPLITK>): two k ranges of up to 4096 rows (four of 2048, ...)
+    h->kpart_floats = (need < 4096 ? need : 4096) * (int64_t)h->hidden * 2;
+    if ((rc = dev_alloc(h, &h->d_kpart, h->kpart_floats * 4))) return rc;
+    if ((rc = dev_alloc(h, &h->d_kcount, MID_KCOUNT * 4))) return rc;
+    HIP_TRY(hipMemset(h->d_kcount, 0, MID_KCOUNT * 4));
     h->cap_rows = need;
     return ML_OK;
 }
@@ -466,6 +486,23 @@ bool use_half_tile(const Tuning& tu, int precision, int64_t rows) {
     return precision == ML_PREC_F16X2 && (tu.mid_tile == 256 || (tu.mid_tile == 0 && round_up64(rows, 256) > tu.half_from));
 }
 
+// tile height of a dense_mid_kernel launch whose 128-row tiling has `tiles128` tiles (ONE rule for launch_dense and for the route label)
+int mid_tile_rows(const Tuning& tu, int precision, int tiles128) {
+    if (tu.mid_tile == 64 || tu.mid_tile == 128) return tu.mid_tile;
+    return tiles128 >= (tu.mid_dma && precision == ML_PREC_F16X2 ? (3 * num_cus()) / 4 : num_cus()) ? 128 : 64;
+}
+
+// k ranges per output tile of a dense_mid_kernel launch (round 6): the smallest of 1, 2, 4 that reaches tu.mid_wgs workgroups, limited
+// by what the reduction length allows (>= 4 k32 steps per range, equal ranges), by `room` (ranges the partial-tile workspace holds) and by
+// Tuning::mid_splitk (0 / 1 off, 2 / 4 forced); the 3-product mode only
+int mid_ksplit(const Tuning& tu, int precision, int tiles, int nk, int room) {
+    if (precision != ML_PREC_F16X2 || tu.mid_splitk == 0 || tu.mid_splitk == 1 || room < 2) return 1;
+    int want = tu.mid_splitk > 1 ? tu.mid_splitk : (tiles >= tu.mid_wgs ? 1 : (2 * tiles >= tu.mid_wgs ? 2 : 4));
+    if (want > room) want = room >= 4 ? 4 : (room >= 2 ? 2 : 1);
+    while (want > 1 && (nk % want != 0 || nk / want < 4)) want >>= 1;
+    return want < 1 ? 1 : want;
+}
+
 // mid: 0 = no, 1 = the mid-size path (dense_mid_kernel), 2 = ... with dense_kernel_w4's half-size tile for the long-K layers
 int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, hipStream_t st, int head_nh = 0, int64_t rows = -1,
                  int mid = 0) {
@@ -504,13 +541,31 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
             return ML_OK;
         }
         const int tiles128 = (p.M_pad / 128) * (p.N / mlk::MID_TN);
-        const int tm = (tu.mid_tile == 64 || tu.mid_tile == 128) ? tu.mid_tile : (tiles128 >= num_cus() ? 128 : 64);   // (measured: 4096 rows 256 vs 266 us)
+        // 128-row tiles once they cover the CUs -- with the LDS-DMA loader (one 96 KiB workgroup per CU) already from three quarters of
+        // them (3072 rows: 188 vs 199 us per forward; 2048 rows, half of them: 181 vs 134)
+        const int tm = mid_tile_rows(tu, precision, tiles128);
         const int tiles = (p.M_pad / tm) * (p.N / mlk::MID_TN);
-        const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
-#define ML_MID(NS, RL, RS, HD)                                                                                                  \
-    do {                                                                                                                        \
-        if (tm == 128) hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, 128, HD>), grid, dim3(mlk::MID_THREADS), 0, st, p); \
-        else hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, 64, HD>), grid, dim3(mlk::MID_THREADS), 0, st, p);           \
+        // round 6, split-K: k ranges per output tile so that the launch reaches tu.mid_wgs workgroups (two per CU) -- 1, 2 or 4, each at
+        // least four k32 steps long, as many as the caller's workspace holds (p.ksplit on entry; no workspace: none) and the counters cover
+        const int ksplit = mid_ksplit(tu, precision, tiles, p.K / 32, (p.kpart && p.kcount && tiles <= MID_KCOUNT) ? p.ksplit : 1);
+        p.ksplit = ksplit;
+        const dim3 grid((unsigned)(((tiles * ksplit + 7) / 8) * 8));
+        const bool dma = tu.mid_dma && precision == ML_PREC_F16X2;
+#define ML_MID_L(NS, RL, RS, TMV, HD, SK, DM) \
+    hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, TMV, HD, SK, DM>), grid, dim3(mlk::MID_THREADS), 0, st, p)
+#define ML_MID(NS, RL, RS, HD)                                                   \
+    do {                                                                         \
+        if (NS == 3 && dma) {                                                    \
+            if (ksplit > 1) {                                                    \
+                if (tm == 128) ML_MID_L(3, RL, RS, 128, HD, true, true);         \
+                else ML_MID_L(3, RL, RS, 64, HD, true, true);                    \
+            } else if (tm == 128) ML_MID_L(3, RL, RS, 128, HD, false, true);     \
+            else ML_MID_L(3, RL, RS, 64, HD, false, true);                       \
+        } else if (ksplit > 1 && NS == 3) {                                      \
+            if (tm == 128) ML_MID_L(3, RL, RS, 128, HD, true, false);            \
+            else ML_MID_L(3, RL, RS, 64, HD, true, false);                       \
+        } else if (tm == 128) ML_MID_L(NS, RL, RS, 128, HD, false, false);       \
+        else ML_MID_L(NS, RL, RS, 64, HD, false, false);                         \
     } while (0)
 #define ML_MID_NS(NS)                                     \
     do {                                                  \
@@ -535,6 +590,7 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
         else ML_MID_NS(1);
 #undef ML_MID_NS
 #undef ML_MID
+#undef ML_MID_L
         HIP_TRY(hipGetLastError());
         return ML_OK;
     }
@@ -763,8 +819,7 @@ int route_family(const ml_loco* h, int64_t rows) {
     if (use_mid_path(h->tune, h->precision, rows)) {
         const int64_t m_pad = round_up64(rows, 256);
         if (use_half_tile(h->tune, h->precision, rows)) return ML_ROUTE_HALF;
-        if (h->tune.mid_tile == 64 || h->tune.mid_tile == 128) return h->tune.mid_tile == 64 ? ML_ROUTE_MID64 : ML_ROUTE_MID128;
-        return (m_pad / 128) * (h->hidden / mlk::MID_TN) >= num_cus() ? ML_ROUTE_MID128 : ML_ROUTE_MID64;
+        return mid_tile_rows(h->tune, h->precision, (int)((m_pad / 128) * (h->hidden / mlk::MID_TN))) == 128 ? ML_ROUTE_MID128 : ML_ROUTE_MID64;
     }
     return ML_ROUTE_TILE;
 }
@@ -976,6 +1031,9 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             p.trace = nullptr;
             p.head_w = nullptr;
             p.head_part = nullptr;
+            p.kpart = h->d_kpart;          // (launch_dense decides whether this layer's reduction is split)
+            p.kcount = h->d_kcount;
+            p.ksplit = (int)(h->kpart_floats / ((int64_t)m_pad * L.n > 0 ? (int64_t)m_pad * L.n : 1));   // k ranges the workspace can hold
             if (step.fused_fin) {
                 p.head_w = step.fused_fin->d_w;
                 p.head_part = h->d_part + r0 * (int64_t)nparts * 16;
@@ -1804,6 +1862,9 @@ int ml_loco_set_option(ml_loco* h, const char* name, int value) {
     if (n == "mid_heads" || n == "half_heads") h->tune.half_heads = value ? 1 : 0;
     else if (n == "half_from") h->tune.half_from = value;
     else if (n == "small_multi") h->tune.small_multi = value ? 1 : 0;
+    else if (n == "mid_splitk") h->tune.mid_splitk = value;
+    else if (n == "mid_wgs") h->tune.mid_wgs = value;
+    else if (n == "mid_dma") h->tune.mid_dma = value ? 1 : 0;
     else return fail(ML_ERR_ARG, "unknown option '%s'", name);
     ++h->tune_version;
     return ML_OK;
@@ -2037,7 +2098,12 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
     const bool mid_path = (precision & (ML_DEBUG_MID_64 | ML_DEBUG_MID_128)) != 0;   // dense_mid_kernel with that tile height
     if (mid_path)   // (both bits: dense_kernel_w4's half-size tile for the long-K layers)
         tu.mid_tile = ((precision & ML_DEBUG_MID_64) && (precision & ML_DEBUG_MID_128)) ? 256 : ((precision & ML_DEBUG_MID_64) ? 64 : 128);
-    precision &= ~(ML_DEBUG_SMALL_PATH | ML_DEBUG_TILE_PP | ML_DEBUG_TILE_W4 | ML_DEBUG_MID_64 | ML_DEBUG_MID_128);
+    // dense_mid_kernel's reduction in 2 / 4 k ranges per tile (split-K, last arriver runs the epilogue); without the bits: one range
+    const int dbg_split = (precision & ML_DEBUG_MID_SPLIT4) ? 4 : ((precision & ML_DEBUG_MID_SPLIT2) ? 2 : 1);
+    tu.mid_splitk = dbg_split;
+    tu.mid_dma = (precision & ML_DEBUG_MID_NODMA) ? 0 : 1;
+    precision &= ~(ML_DEBUG_SMALL_PATH | ML_DEBUG_TILE_PP | ML_DEBUG_TILE_W4 | ML_DEBUG_MID_64 | ML_DEBUG_MID_128 | ML_DEBUG_MID_SPLIT2 |
+                   ML_DEBUG_MID_SPLIT4 | ML_DEBUG_MID_NODMA);
     if ((small_path || mid_path) && precision == ML_PREC_BF16) return fail(ML_ERR_ARG, "the bf16 mode runs on the 256x256-tile kernels only");
     hipStream_t st = (hipStream_t)stream;
     ml_loco tmp;
@@ -2053,6 +2119,13 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
     int rc = upload_layer(&tmp, L);
     const int64_t m_pad = round_up64(m, 256);
     char *xl = nullptr, *yl = nullptr, *rl = nullptr;
+    float* kpart = nullptr;
+    unsigned* kcount = nullptr;
+    if (!rc && mid_path && dbg_split > 1) {
+        rc = dev_alloc(&tmp, &kpart, m_pad * (int64_t)n * 4 * dbg_split);
+        if (!rc) rc = dev_alloc(&tmp, &kcount, MID_KCOUNT * 4);
+        if (!rc && hipMemset(kcount, 0, MID_KCOUNT * 4) != hipSuccess) rc = fail(ML_ERR_HIP, "debug_linear: memset failed");
+    }
     if (!rc) rc = dev_alloc(&tmp, &xl, m_pad * (int64_t)L.kpad * 4);
     if (!rc) rc = dev_alloc(&tmp, &yl, m_pad * (int64_t)n * 4);
     if (!rc && res_dev) rc = dev_alloc(&tmp, &rl, m_pad * (int64_t)n * 4);
@@ -2082,6 +2155,9 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
         p.trace = nullptr;
         p.head_w = nullptr;
         p.head_part = nullptr;
+        p.kpart = kpart;
+        p.kcount = kcount;
+        p.ksplit = dbg_split;
         if (precision == ML_PREC_BF16) {
             int64_t pairs = m_pad * (int64_t)(L.kpad / 32) * 4;
             hipLaunchKernelGGL(mlk::lines_to_bf16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, xl, pairs);
@@ -2102,6 +2178,8 @@ int ml_debug_linear(const float* x_dev, int64_t m, int k, const float* w_host, c
     dev_free(xl);
     dev_free(yl);
     dev_free(rl);
+    dev_free(kpart);
+    dev_free(kcount);
     dev_free(L.d_w);
     dev_free(L.d_b);
     dev_free(L.d_bs);

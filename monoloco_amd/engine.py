@@ -241,11 +241,12 @@ def laplace_sampling_device(mu_b, n_samples, seed=1):
     return out
 
 
-def debug_linear(x, w, b, relu=False, res=None, precision='f16x2', small_path=False, tile_kernel=None):
+def debug_linear(x, w, b, relu=False, res=None, precision='f16x2', small_path=False, tile_kernel=None, ksplit=1, mid_dma=True):
     """Single dense layer through the MFMA kernel (test hook): the tile kernel (tile_kernel: None = the default choice, 'pp' =
     dense_kernel_pp, 'w4' = dense_kernel_w4 wherever it runs, 'mid64' / 'mid128' = dense_mid_kernel with that tile height, 'half' =
     dense_kernel_w4's half-size 256 x 128 tile for K > 128), or
-    the small-row kernels."""
+    the small-row kernels.  ksplit 2 | 4 (with 'mid64' / 'mid128'): the reduction of every output tile cut into that many k ranges,
+    one workgroup each, the last arriver runs the epilogue (dense_mid_kernel<.., SPLITK>)."""
     lib = _lib.load()
     dev = _require_cuda(x.device)
     x = _dev_f32(x, dev)
@@ -258,7 +259,9 @@ def debug_linear(x, w, b, relu=False, res=None, precision='f16x2', small_path=Fa
         check(lib.ml_debug_linear(_ptr(x), x.shape[0], k, fptr(w), fptr(b), n, int(bool(relu)), _ptr(res), _ptr(y),
                                   PRECISIONS[precision] | (_lib.ML_DEBUG_SMALL_PATH if small_path else 0)
                                   | {None: 0, 'pp': _lib.ML_DEBUG_TILE_PP, 'w4': _lib.ML_DEBUG_TILE_W4, 'mid64': _lib.ML_DEBUG_MID_64,
-                                     'mid128': _lib.ML_DEBUG_MID_128, 'half': _lib.ML_DEBUG_MID_64 | _lib.ML_DEBUG_MID_128}[tile_kernel],
+                                     'mid128': _lib.ML_DEBUG_MID_128, 'half': _lib.ML_DEBUG_MID_64 | _lib.ML_DEBUG_MID_128}[tile_kernel]
+                                  | {1: 0, 2: _lib.ML_DEBUG_MID_SPLIT2, 4: _lib.ML_DEBUG_MID_SPLIT4}[int(ksplit)]
+                                  | (0 if mid_dma else _lib.ML_DEBUG_MID_NODMA),
                                   _stream(dev)))
     return y
 

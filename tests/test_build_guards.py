@@ -105,9 +105,23 @@ def test_pp_and_mid_loops_keep_their_shape(reports):
             assert loop.get('lds_dma') == 14 and loop.get('barrier') == 4 and loop.get('vmcnt_waits') == {0: 2, 2: 1}, (name, loop)
             assert loop.get('mfma') == {3: 48, 1: 16, 0: 16}[nsplit] and 'other_vmem' not in loop and 'ds_write' not in loop, (name, loop)
             seen_pp += 1
+        if name.startswith('dense_mid_kernel<') and loop is not None and name.rstrip('>').endswith(', true'):
+            # round 6, the LDS-DMA loader (last template argument): two steps per iteration (the two fragment register sets), per step
+            # NI = (128 + TM) / 32 requests per wave, ONE counted wait vmcnt(NI), one barrier, the next step's fragment reads (2 half-steps
+            # x (4 W + 2 TM / 64 X) ds_read_b128); no register-staged load or LDS store left, and no wait of hipcc's own in front of the
+            # MFMAs (a second LDS object in the kernel once made it guard every fragment read with vmcnt(0); a branch around the reads
+            # made it wait lgkmcnt(0) at the join -- both seen here first)
+            tm = int(name.split(',')[3])
+            ni = (128 + tm) // 32
+            assert loop.get('barrier') == 2 and loop.get('lds_dma') == 2 * ni and loop.get('vmcnt_waits') == {ni: 2}, (name, loop)
+            assert loop.get('mfma') == 2 * 3 * 4 * tm // 64 and loop.get('ds_read') == 2 * 2 * (4 + 2 * tm // 64), (name, loop)
+            assert 'other_vmem' not in loop and 'ds_write' not in loop, (name, loop)
+            seen_mid += 1
+            continue
         if name.startswith('dense_mid_kernel<') and loop is not None:
             nsplit, tm = int(name.split('<')[1].split(',')[0]), int(name.split(',')[3])
-            assert loop.get('barrier') == 1 and 'lds_dma' not in loop and loop.get('mfma') == (3 if nsplit == 3 else 1) * 4 * tm // 64, (name, loop)
+            steps = loop.get('barrier')    # hipcc keeps one k32 step per iteration, or two (the split-K variants): one barrier each
+            assert steps in (1, 2) and 'lds_dma' not in loop and loop.get('mfma') == steps * (3 if nsplit == 3 else 1) * 4 * tm // 64, (name, loop)
             seen_mid += 1
     assert seen_pp >= 12 and seen_mid >= 8, (seen_pp, seen_mid)
 

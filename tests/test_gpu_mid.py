@@ -192,3 +192,94 @@ def test_mid_fused_heads_match_the_pair_kernel(hip_lib, cuda_device, m, mode):
         assert (xyz_f - xyz_p).abs().max().item() <= 2e-5
         assert (out_f_.nan_to_num() - out_p.nan_to_num()).abs().max().item() <= 1e-4
     eng.close()
+
+
+@pytest.mark.parametrize("tile", ["mid64", "mid128"])
+@pytest.mark.parametrize("m,k,n", [(256, 64, 256), (700, 96, 256), (1000, 1024, 1024), (2048, 1024, 1024), (4096, 1024, 1024), (3000, 32, 512),
+                                   (513, 2048, 512), (128, 192, 256)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
+def test_mid_loaders_agree(hip_lib, cuda_device, tile, m, k, n, relu, res):
+    """Round 6: dense_mid_kernel's loader is LDS-DMA into a three-stage ring (the default); the rounds-3-5 loader (global -> VGPR ->
+    ds_write, two stages) stays selectable.  Same operands, same fragment reads, same MFMA order: the SAME bits, for K of one line
+    (a single k-step: the ring's requests past the end) up to 64, row counts that are no multiple of the tile, in-place residual."""
+    from monoloco_amd import engine
+    rng = np.random.default_rng(m + k + n + 7)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    x = (rng.standard_normal((m, k)) * 2).astype(np.float32)
+    r = (rng.standard_normal((m, n)) * 3).astype(np.float32) if res else None
+    xd = torch.tensor(x).to(cuda_device)
+    rd = torch.tensor(r).to(cuda_device) if res else None
+    y_dma = engine.debug_linear(xd, w, b, relu=relu, res=rd, tile_kernel=tile)
+    y_reg = engine.debug_linear(xd, w, b, relu=relu, res=rd, tile_kernel=tile, mid_dma=False)
+    assert torch.equal(y_dma, y_reg)
+    for _ in range(3):
+        assert torch.equal(engine.debug_linear(xd, w, b, relu=relu, res=rd, tile_kernel=tile), y_dma)
+
+
+@pytest.mark.parametrize("tile,ksplit,dma", [("mid64", 2, True), ("mid64", 4, True), ("mid128", 2, True), ("mid128", 4, True),
+                                             ("mid64", 2, False), ("mid128", 4, False)])
+@pytest.mark.parametrize("m,k,n", [(1000, 1024, 1024), (2048, 1024, 1024), (4096, 1024, 1024), (700, 256, 256), (3000, 512, 512), (513, 2048, 512)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
+def test_mid_split_k_single_layer(hip_lib, cuda_device, tile, ksplit, dma, m, k, n, relu, res):
+    """dense_mid_kernel<.., SPLITK> (round 6): the reduction of every output tile cut into 2 / 4 k ranges, one workgroup each, the
+    last arriver adds the partial tiles in split order and runs the epilogue.  Against fp64 at the fp32-class bar, <= 2e-6 (relative
+    to the layer's largest output) from the unsplit kernel -- only the fp32 summation order differs -- and the SAME bits in every
+    one of 6 repetitions (the sum order does not depend on which workgroup arrives last).  The layer: architectures.py:88-102."""
+    from monoloco_amd import engine
+    rng = np.random.default_rng(m + k + n + ksplit)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    x = (rng.standard_normal((m, k)) * 2).astype(np.float32)
+    r = (rng.standard_normal((m, n)) * 3).astype(np.float32) if res else None
+    xd = torch.tensor(x).to(cuda_device)
+    rd = torch.tensor(r).to(cuda_device) if res else None
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    if res:
+        ref = ref + r
+    scale = max(1.0, np.abs(ref).max())
+    y_one = engine.debug_linear(xd, w, b, relu=relu, res=rd, tile_kernel=tile, mid_dma=dma).cpu().numpy()
+    y_split = engine.debug_linear(xd, w, b, relu=relu, res=rd, tile_kernel=tile, ksplit=ksplit, mid_dma=dma).cpu().numpy()
+    assert np.abs(y_split - ref).max() <= 4e-6 * scale
+    assert np.abs(y_split - y_one).max() <= 2e-6 * scale
+    if (k // 32) % ksplit == 0 and (k // 32) // ksplit >= 4:
+        assert not np.array_equal(y_split, y_one) or k <= 64, "the split kernel did not run"
+    for _ in range(5):
+        again = engine.debug_linear(xd, w, b, relu=relu, res=rd, tile_kernel=tile, ksplit=ksplit, mid_dma=dma).cpu().numpy()
+        assert np.array_equal(again, y_split)
+
+
+@pytest.mark.parametrize("mode", ["mono", "stereo"])
+@pytest.mark.parametrize("m", [513, 1024, 2048, 3000, 4096])
+def test_mid_split_k_whole_model(hip_lib, cuda_device, m, mode):
+    """Whole models through the mid window with the split reduction (auto, 2, 4 k ranges; both tile heights) against the unsplit
+    route and the fp64 oracle, the fused heads riding in the last arriver's epilogue; 50 repetitions give the same bits (the arrival
+    counters re-arm themselves, the sum order is fixed)."""
+    from monoloco_amd import engine
+    from oracle import monoloco_oracle as O
+    in_f, out_f = (34, 9) if mode == "mono" else (68, 10)
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(4, in_features=in_f, out_features=out_f).items()}
+    rng = np.random.default_rng(m)
+    x = torch.tensor((rng.standard_normal((m, in_f)) * 3).astype(np.float32), device=cuda_device)
+    eng = engine.LocoEngine(sd, device=cuda_device)
+    ref64 = O.loco_forward(sd, x.cpu(), dtype=torch.float64)
+    scale = max(1.0, ref64.abs().max().item())
+    for tile in (64, 128):
+        eng.set_tuning(mid_tile=tile)
+        eng.set_option('mid_splitk', 1)
+        eng.set_option('mid_dma', 0)
+        raw_reg = eng.forward_raw(x).cpu()
+        eng.set_option('mid_dma', 1)
+        raw_one = eng.forward_raw(x).cpu()
+        assert torch.equal(raw_one, raw_reg), tile            # the two loaders: the same bits through a whole model
+        assert (raw_one.double() - ref64).abs().max().item() <= 1e-4
+        for sk in (-1, 2, 4):
+            eng.set_option('mid_splitk', sk)
+            raw = eng.forward_raw(x).cpu()
+            assert (raw.double() - ref64).abs().max().item() <= 1e-4, (tile, sk)
+            assert (raw - raw_one).abs().max().item() <= 4e-6 * scale, (tile, sk)
+            for _ in range(50):
+                assert torch.equal(eng.forward_raw(x).cpu(), raw), (tile, sk)
+    eng.close()
