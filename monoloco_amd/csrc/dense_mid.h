@@ -57,7 +57,14 @@ struct MidCfg {
     static constexpr int W_BYTES = MID_TN * LINE;        // 16 KiB
     static constexpr int STAGE = W_BYTES + TM * LINE;    // W rows then X rows
     static constexpr int LDS = 2 * STAGE;
-    static constexpr int LDS_DMA = 3 * STAGE;            // the LDS-DMA loader's ring: 72 / 96 KiB
+    // The LDS-DMA loader's ring: three stages (one being read, one in flight, one being requested).  -DMID_RING=<n> builds deeper rings
+    // for the A/B: as many stages as the CU's 160 KiB hold (6 x 24 / 5 x 32 KiB, one workgroup per CU) measured SLOWER -- 2048 rows 144.8 vs
+    // 133.8 us per forward, 4096 rows 224.6 vs 211.4 (profiles/r06_ablation.md): the loop is not short of requests in flight
+#ifndef MID_RING
+#define MID_RING 3
+#endif
+    static constexpr int RING = MID_RING;
+    static constexpr int LDS_DMA = RING * STAGE;
     static constexpr int NI = (MID_TN + TM) / 32;        // LDS-DMA instructions (8 rows each) per wave and step
 };
 
@@ -70,7 +77,7 @@ struct MidCfg {
 // step i - 1 is refilled with step i + 2 right behind step i's barrier; every wave waits for its OWN share of a stage with a counted
 // vmcnt(NI) (requests retire in order; past the end the requests repeat the last step so that the count never changes).
 template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0, bool SPLITK = false, bool DMA = false>
-__global__ __launch_bounds__(MID_THREADS, (DMA && TM == 128) ? 1 : 2) void dense_mid_kernel(DenseParams p) {   // (the 96 KiB ring: one workgroup per CU)
+__global__ __launch_bounds__(MID_THREADS, (DMA && MidCfg<TM>::LDS_DMA > 80 * 1024) ? 1 : 2) void dense_mid_kernel(DenseParams p) {   // (a ring above 80 KiB: one workgroup per CU)
     typedef MidCfg<TM> C;
     constexpr int NB = C::NB, XL = C::XL;
     constexpr bool AUX = HEAD == -1;
@@ -206,9 +213,9 @@ __global__ __launch_bounds__(MID_THREADS, (DMA && TM == 128) ? 1 : 2) void dense
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int c = 0; c < NB; ++c) asm volatile("" : "+v"(acc[a][c]));
-        issue(0, 0, 0, NI);
-        issue(1, 1, 0, NI);
-        issue(2, 2, 0, NI);
+        constexpr int RING = C::RING;
+#pragma unroll
+        for (int r0 = 0; r0 < RING; ++r0) issue(r0, r0, 0, NI);
         // One request behind every unit of three MFMAs (one 32 x 32 output block's hi.lo + lo.hi + hi.hi: 96 matrix-pipe cycles against
         // ~110 of issue) -- TM = 128: eight units, eight requests; TM = 64: four units, six requests (2 + 2 + 1 + 1).
         auto mma_unit = [&](const Frag& f, int a, int c) {
@@ -232,19 +239,20 @@ __global__ __launch_bounds__(MID_THREADS, (DMA && TM == 128) ? 1 : 2) void dense
         };
         // The fragment reads are pipelined ONE STEP AHEAD in registers (round 6; ablation: un-pipelined they cost 300-400 exposed cycles
         // per step between the barrier and the first MFMA -- 6.4 us of a 26 us layer at 4096 rows, profiles/r06_ablation.md).  Step i:
-        //   wait: my share of stage i + 1 has landed (only stage i + 2's requests are younger: vmcnt(NI)), my reads of stage i are complete
+        //   wait: my share of stage i + 1 has landed (the requests of stages i + 2 .. i + RING - 1 are younger: vmcnt((RING - 2) NI)), my
+        //         reads of stage i are complete
         //   barrier: everybody's share of stage i + 1; everybody is done reading stage i, whose buffer is therefore free
-        //   read the fragments of stage i + 1 into the other register set; the MFMAs of stage i, with stage i + 3's requests
-        //   (into stage i's buffer) between them
+        //   read the fragments of stage i + 1 into the other register set; the MFMAs of stage i, with stage i + RING's requests
+        //   (into stage i's buffer; past the end: harmless repeats, the count never changes) between them
         Frag fa0, fa1, fb0, fb1;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * NI) : "memory");
         pp_barrier();
         read_step(fa0, fa1, 0);
         int st = 0;   // buffer of stage i
         auto step_dma = [&](Frag& c0, Frag& c1, Frag& n0f, Frag& n1f, int i) {
-            const int nst = st == 2 ? 0 : st + 1;
+            const int nst = st == RING - 1 ? 0 : st + 1;
             if (!MID_DBG(8)) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * NI) : "memory");
                 pp_barrier();
             }
             read_step(n0f, n1f, nst);   // (unconditional: behind the last step it reads a landed repeat nobody uses -- a branch here makes hipcc wait lgkmcnt(0) at the join, in front of the MFMAs)
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(MID_THREADS, (DMA && TM == 128) ? 1 : 2) void dense
                         mma_unit(hs ? c1 : c0, a, c);     // (same order as mma_rows: the same bits as the register-staged loop)
                         const int unit = (hs * 2 + a) * NB + c, n_here = NB == 2 ? 1 : (unit < 2 ? 2 : 1);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (!MID_DBG(1)) issue(st, i + 3, j, j + n_here);
+                        if (!MID_DBG(1)) issue(st, i + RING, j, j + n_here);
                         __builtin_amdgcn_sched_barrier(0);
                         j += n_here;
                     }

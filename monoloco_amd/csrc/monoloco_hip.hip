@@ -497,7 +497,8 @@ int mid_tile_rows(const Tuning& tu, int precision, int tiles128) {
 // Tuning::mid_splitk (0 / 1 off, 2 / 4 forced); the 3-product mode only
 int mid_ksplit(const Tuning& tu, int precision, int tiles, int nk, int room) {
     if (precision != ML_PREC_F16X2 || tu.mid_splitk == 0 || tu.mid_splitk == 1 || room < 2) return 1;
-    int want = tu.mid_splitk > 1 ? tu.mid_splitk : (tiles >= tu.mid_wgs ? 1 : (2 * tiles >= tu.mid_wgs ? 2 : 4));
+    // (auto: two ranges when the tiles cover at most half of mid_wgs, never four -- 640 rows: 110 us per forward with 2, 136 with 4, 124 with 1)
+    int want = tu.mid_splitk > 1 ? tu.mid_splitk : (2 * tiles <= tu.mid_wgs ? 2 : 1);
     if (want > room) want = room >= 4 ? 4 : (room >= 2 ? 2 : 1);
     while (want > 1 && (nk % want != 0 || nk / want < 4)) want >>= 1;
     return want < 1 ? 1 : want;
@@ -1221,6 +1222,10 @@ int ml_loco_finalize(ml_loco* h, int precision, int flags) {
     h->precision = precision;
     h->flags = flags;
     h->host_only = (flags & ML_FLAG_HOST_ONLY) != 0;
+    // where the small-row kernels hand over to dense_mid_kernel (round 6, tools/ab_small_mid.py): at the headline width the LDS-DMA loader
+    // with two k ranges per tile takes 320-512 rows in 106 us per forward against 159-162 us on the 32 x 32 tiles (256 rows: 104 vs 105);
+    // narrower models have too few 128-column tiles for that and keep the measured round-3 boundary
+    if (precision == ML_PREC_F16X2 && h->hidden >= 1024) h->tune.small_rows = 256;
     if (!h->host_only) HIP_TRY(hipGetDevice(&h->device));
     const int H = h->hidden_real, HP = h->hidden, IN = h->in_f;
     const int NFIN = h->out_f - 1;  // w_fin rows; the aux head adds the last column (architectures.py:12,70)
@@ -1836,7 +1841,8 @@ int ml_loco_plan(const ml_loco* h, int64_t rows, int mc_dropout, int with_post, 
 }
 
 int ml_loco_set_tuning(ml_loco* h, int small_rows, int small32_rows, int chunk_rows, int tile_kernel, int mid_rows, int mid_tile) {
-    // negative = keep; the defaults are 512 / 128 / 0 / 4 / 8192 / 0 (measured crossovers, profiles/r03_mid_sweep.txt)
+    // negative = keep; the defaults are 512 (256 from hidden 1024 on, set at finalize) / 128 / 0 / 4 / 8192 / 0 (measured crossovers,
+    // profiles/r03_mid_sweep.txt, profiles/r06_ablation.md)
     if (mid_tile > 0 && mid_tile != 64 && mid_tile != 128 && mid_tile != 256)
         return fail(ML_ERR_ARG, "mid tile must be 0 (auto), 64 or 128 (dense_mid_kernel's tile height) or 256 (dense_kernel_w4's half-size tile)");
     if (!h) return fail(ML_ERR_ARG, "null handle");

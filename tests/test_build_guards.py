@@ -113,7 +113,9 @@ def test_pp_and_mid_loops_keep_their_shape(reports):
             # made it wait lgkmcnt(0) at the join -- both seen here first)
             tm = int(name.split(',')[3])
             ni = (128 + tm) // 32
-            assert loop.get('barrier') == 2 and loop.get('lds_dma') == 2 * ni and loop.get('vmcnt_waits') == {ni: 2}, (name, loop)
+            ring = 3                         # stages of the LDS ring; the counted wait leaves ring - 2 stages' requests in flight
+            assert loop.get('barrier') == 2 and loop.get('lds_dma') == 2 * ni and loop.get('vmcnt_waits') == {(ring - 2) * ni: 2}, (name, loop)
+            assert int(v['resources']['LDS Size [bytes/block]']) == ring * (128 + tm) * 128, (name, v['resources']['LDS Size [bytes/block]'])
             assert loop.get('mfma') == 2 * 3 * 4 * tm // 64 and loop.get('ds_read') == 2 * 2 * (4 + 2 * tm // 64), (name, loop)
             assert 'other_vmem' not in loop and 'ds_write' not in loop, (name, loop)
             seen_mid += 1

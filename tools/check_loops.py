@@ -82,6 +82,27 @@ def main_loop(lines):
     return best
 
 
+def request_loop(lines):
+    """(first, last) of the innermost loop holding the most LDS-DMA instructions and NO MFMA (a request-only wave's loop), or None."""
+    labels = {}
+    for i, l in enumerate(lines):
+        m = re.match(r'^(\.LBB\d+_\d+):', l)
+        if m:
+            labels[m.group(1)] = i
+    loops = []
+    for i, l in enumerate(lines):
+        m = re.match(r'^\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)', l) or re.match(r'^\s+s_branch\s+(\.LBB\d+_\d+)', l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loops.append((labels[m.group(1)], i))
+    best, best_n = None, 0
+    for a, b in loops:
+        inner = any((a2, b2) != (a, b) and a <= a2 and b2 <= b for a2, b2 in loops)
+        n = sum(1 for x in lines[a:b] if 'global_load_lds' in x)
+        if n > best_n and not inner and not any('v_mfma' in x for x in lines[a:b]):
+            best, best_n = (a, b), n
+    return best
+
+
 def mix(lines, span):
     a, b = span
     c = collections.Counter()
@@ -138,8 +159,10 @@ def report(unit='monoloco_hip', extra=(), pattern='dense_kernel_w4'):
     out = {}
     for n in names:
         span = main_loop(funcs[n])
+        rspan = request_loop(funcs[n])
         out[dm[n].replace('void mlk::', '').replace('(mlk::DenseParams)', '')] = {
-            'loop': mix(funcs[n], span) if span else None, 'resources': res.get(n, {})}
+            'loop': mix(funcs[n], span) if span else None, 'request_loop': mix(funcs[n], rspan) if rspan else None,
+            'resources': res.get(n, {})}
     return out
 
 

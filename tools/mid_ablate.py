@@ -26,7 +26,7 @@ for m in [int(a) for a in sys.argv[1:]]:
 print('   '.join(out))
 ''' % (ROOT, os.path.join(ROOT, 'tests'))
 rows = sys.argv[1:] or ['2048', '4096']
-for bits in ('', '1', '2', '4', '8', '16', '3'):
+for bits in ('', '1', '2', '4', '8', '16', '3', '19'):
     lib = os.path.join(ROOT, 'monoloco_amd', 'lib', 'libmonoloco_hip%s.so' % ('_abl' + bits if bits else ''))
     if not os.path.exists(lib):
         continue
