@@ -265,6 +265,16 @@ int ml_trainer_get_grad(ml_trainer* t, const char* key, float* host_data, int64_
  * Synchronises the stream before returning (the reference syncs with .item() too). */
 int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m,
                     int update, double* losses_host, float* raw_out_dev, void* stream);
+/* The same iteration with the seams a caller-owned loop needs (reference trainer.py:155-160: `outputs = self.model(inputs)` in train
+ * mode, the caller's own criterion, `loss.backward()`, the caller's own clip_grad_norm_ and optimizer): ml_trainer_forward_train =
+ * LocoModel.forward in train mode (architectures.py:48-71) -> raw_out_dev (m, out_features), running BatchNorm statistics updated,
+ * fresh dropout masks per call; ml_trainer_backward = backward from dout_dev (m, out_features), the gradient of the caller's loss with
+ * respect to those outputs -> every parameter gradient, UNCLIPPED, through ml_trainer_get_grad.  x_dev must stay valid and unchanged
+ * between the two calls; exactly one backward per forward (ML_ERR_STATE otherwise); the gradient with respect to x is not computed.
+ * Exact-fp32 route below fast_rows rows, the large-batch route from there on.  ml_trainer_backward synchronises the stream.
+ * monoloco_amd.network.architectures.LocoModel routes its train-mode forward through these (torch.autograd.Function). */
+int ml_trainer_forward_train(ml_trainer* t, const float* x_dev, int64_t m, float* raw_out_dev, void* stream);
+int ml_trainer_backward(ml_trainer* t, const float* dout_dev, int64_t m, void* stream);
 /* AutoTuneMultiTaskLoss (train/losses.py:17-43, selected by `--auto_tune_mtl`, trainer.py:95-96): every task loss is divided by
  * 2 exp(log_sigma)^2 and the log_sigmas are added to the total; the eight log_sigmas (d, x, y, h, w, l, ori, aux; zero at
  * creation) are optimised by the same Adam and schedule, unclipped, and are not part of the state_dict.  With it on,

@@ -61,6 +61,10 @@ struct ml_trainer {
     int sched_step;
     uint32_t seed;
     int64_t step = 0;
+    int64_t fwd_pending_rows = 0;   // rows of a forward whose backward has not run yet (0: none)
+    const float* fwd_pending_x = nullptr;
+    int64_t fwd_calls = 0;          // ml_trainer_forward_train calls: the dropout masks of a forward / backward pair outside ml_trainer_step
+                                    // (no optimizer step moves `step` there) differ from call to call
     std::map<std::string, Slot> slots;
     int64_t n_param = 0, n_stat = 0;
     float *w = nullptr, *g = nullptr, *m1 = nullptr, *m2 = nullptr, *stat = nullptr;
@@ -475,12 +479,12 @@ int block_fwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, const float* r
     if (y_lines || (x_lines && (H & 7) == 0))   // (also the large-batch route's last block, no lines: 4 columns per lane instead of 1)
         hipLaunchKernelGGL(mlt::bn_relu_drop_lines_kernel, dim3(nblk(m * H / 4)), dim3(256), 0, st, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
-                           (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site,
+                           (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)(t->step + t->fwd_calls) * 977u, b.site,
                            res_lines ? (const float*)nullptr : residual, lines_only ? (float*)nullptr : b.y, y_lines, res_lines);
     else
         hipLaunchKernelGGL(mlt::bn_relu_drop_kernel, dim3(nblk(m * H)), dim3(256), 0, st, (const float*)b.z, m, H,
                            (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
-                           (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)t->step * 977u, b.site, residual, b.y);
+                           (const float*)P(t, b.bn + ".bias"), t->p_drop, t->seed + (uint32_t)(t->step + t->fwd_calls) * 977u, b.site, residual, b.y);
     return 0;
 }
 
@@ -500,7 +504,7 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
     const int H = t->H;
     float* mean = t->bn_mean + (size_t)b.bn_idx * H;
     float* inv = t->bn_invstd + (size_t)b.bn_idx * H;
-    const uint32_t seed = t->seed + (uint32_t)t->step * 977u;
+    const uint32_t seed = t->seed + (uint32_t)(t->step + t->fwd_calls) * 977u;
     int rc;
     if ((H & 3) == 0) {
         // fused chain (train_kernels.h): pass 1 = sum(dy), sum(dy * xhat) with dy / xhat recomputed from (dout, z); pass 2 =
@@ -832,7 +836,7 @@ int step_mid(ml_trainer* t, const float* x_dev, const float* labels_dev, int lab
     const bool side = t->side_stream && t->st2;
     hipStream_t sw = side ? t->st2 : st;
     int nlin = 0;                         // Linears whose backward has started (index into the events / the rotation)
-    const uint32_t seed = t->seed + (uint32_t)t->step * 977u;
+    const uint32_t seed = t->seed + (uint32_t)(t->step + t->fwd_calls) * 977u;
     auto mean_of = [&](int bn_idx) { return t->bn_mean + (size_t)bn_idx * H; };
     auto inv_of = [&](int bn_idx) { return t->bn_invstd + (size_t)bn_idx * H; };
 
@@ -1283,23 +1287,27 @@ int ml_debug_xgemm(const float* a_dev, int64_t lda, int a_layout, const float* b
                         sumsq_dev);
 }
 
-int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m,
-                    int update, double* losses_host, float* raw_out_dev, void* stream) {
-    if (!t || !x_dev || !labels_dev || m <= 1 || label_cols < 10) return tfail(ML_ERR_ARG, "bad argument");
-    if (t->C == 10 && label_cols < 11) return tfail(ML_ERR_ARG, "stereo labels need 11 columns");
-    int rc = ensure_cap(t, m);
-    if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
+}  // extern "C"
+
+namespace {
+
+// The exact / large-batch routes of one iteration of the reference's loop (trainer.py:150-161), in PHASES: PH_FWD = the train-mode
+// forward (`outputs = self.model(inputs)`), PH_LOSS = MultiTaskLoss and its gradient, PH_BWD = `loss.backward()` (every parameter
+// gradient, unclipped, into t->g), PH_OPT = clip_grad_norm_(3) + Adam + StepLR.  ml_trainer_step runs all four; ml_trainer_forward_train
+// runs PH_FWD and ml_trainer_backward PH_BWD from a caller-supplied gradient of the outputs (the autograd-capable module of
+// monoloco_amd/network/architectures.py: a third-party loop that calls the model, computes its own loss and steps its own optimizer).
+// The buffer plan below is a pure function of (t, m, route): a backward-only call finds every activation where the forward left it.
+enum { PH_FWD = 1, PH_LOSS = 2, PH_BWD = 4, PH_OPT = 8, PH_ALL = 15 };
+
+int step_phases(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m, int update, double* losses_host,
+                float* raw_out_dev, hipStream_t st, int phases, int route, const float* dout_dev) {
     const int H = t->H, S = t->S, C = t->C;
-    const int route = pick_route(t, m);
-    t->last_route = route;
-    if (route == 2) {
-        if (!mid_rows_ok(t, m)) return tfail(ML_ERR_SHAPE, "the mid route takes operands below 4 GiB (rows x hidden x 4)");
-        return step_mid(t, x_dev, labels_dev, label_cols, m, update, losses_host, raw_out_dev, st);
+    int rc;
+    if (phases & PH_FWD) {
+        T_TRY(hipMemsetAsync(t->d_red_base, 0, (size_t)t->red_slots * (2 * H + 32) * sizeof(double), st));
+        t->red_slot = 0;
+        t->d_red = t->d_red_base;
     }
-    T_TRY(hipMemsetAsync(t->d_red_base, 0, (size_t)t->red_slots * (2 * H + 32) * sizeof(double), st));
-    t->red_slot = 0;
-    t->d_red = t->d_red_base;
     // buffer plan
     int bi = 0;
     auto nb = [&]() { return t->bufs[bi++]; };
@@ -1321,8 +1329,8 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     // fast forward path: the activations that feed an H x H Linear also exist as lines (la[s] = a_s, lt[s] = t_s, ly2 = y2);
     // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
     const bool fast = route == 1;
-    t->packed_all = false;
-    if (fast) {
+    if (phases & PH_FWD) t->packed_all = false;
+    if (fast && (phases & PH_FWD)) {
         T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 2) * 32, st));
         T_TRY(hipMemsetAsync(t->d_colmax, 0, (size_t)(2 * S + 2) * 2 * H * sizeof(float), st));
         // every weight image of the step -- W for the forward GEMMs, W^T for the data-gradient GEMMs -- in two launches up front
@@ -1348,43 +1356,51 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     // (round 4: on the large-batch route the residual stream a_0 .. a_S exists as lines only -- every consumer, the next Linear's
     // GEMMs and the next stage's skip connection, reads the lines)
     const bool stream_lines = fast && t->dw_trans && t->lines_chain;
-    if ((rc = block_fwd(t, st, b0, m, nullptr, nullptr, la(0), -1, stream_lines))) return rc;
+    const bool fwd = (phases & PH_FWD) != 0;
+    if (fwd && (rc = block_fwd(t, st, b0, m, nullptr, nullptr, la(0), -1, stream_lines))) return rc;
     std::vector<Block> sa(S), sb(S);
     for (int s = 0; s < S; ++s) {
         const std::string p = "linear_stages." + std::to_string(s) + ".";
         sa[s].lin = p + "w1"; sa[s].bn = p + "batch_norm1"; sa[s].bn_idx = 1 + 2 * s; sa[s].in_dim = H;
         sa[s].x = a[s]; sa[s].x_lines = la(s); sa[s].z = za[s]; sa[s].y = tt[s]; sa[s].site = 1 + 2 * s;
         // (t_s is read by the next Linear's GEMMs only -- forward and, reduction-major, weight gradient --: lines, no fp32 copy)
-        if ((rc = block_fwd(t, st, sa[s], m, nullptr, la(s), lt(s), fast ? 2 * s : -1, stream_lines))) return rc;
+        if (fwd && (rc = block_fwd(t, st, sa[s], m, nullptr, la(s), lt(s), fast ? 2 * s : -1, stream_lines))) return rc;
         sb[s].lin = p + "w2"; sb[s].bn = p + "batch_norm2"; sb[s].bn_idx = 2 + 2 * s; sb[s].in_dim = H;
         sb[s].x = tt[s]; sb[s].x_lines = lt(s); sb[s].z = zb[s]; sb[s].y = a[s + 1]; sb[s].site = 2 + 2 * s;
-        if ((rc = block_fwd(t, st, sb[s], m, a[s], lt(s), la(s + 1), fast ? 2 * s + 1 : -1, stream_lines,
-                            stream_lines ? la(s) : nullptr)))
+        if (fwd && (rc = block_fwd(t, st, sb[s], m, a[s], lt(s), la(s + 1), fast ? 2 * s + 1 : -1, stream_lines,
+                                   stream_lines ? la(s) : nullptr)))
             return rc;  // a_{s+1} = a_s + block(t_s)
     }
-    if (fast) {
-        if ((rc = fast_linear_fwd(t, st, la(S), "w2", y2, m, 2 * S))) return rc;
-        hipLaunchKernelGGL(mlt::act_lines_kernel, dim3(nblk(m * H / 8)), dim3(256), 0, st, (const float*)y2, m, H, ly2);
-    } else if ((rc = linear_fwd(t, st, a[S], H, P(t, "w2.weight"), P(t, "w2.bias"), y2, H, (int)m, H, H))) return rc;
     const bool skinny = skinny_ok(t, C - 1);
-    if (!(skinny && skinny_heads(t, st, y2, m, P(t, "w_aux.weight"), P(t, "w_aux.bias"), 1, t->d_out + (C - 1), C)))
-        if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
     Block b3;
     b3.lin = "w3"; b3.bn = "batch_norm3"; b3.bn_idx = 2 * S + 1; b3.in_dim = H; b3.x = y2; b3.x_lines = ly2; b3.z = z3; b3.y = y3;
     b3.site = 2 * S + 1;
-    if ((rc = block_fwd(t, st, b3, m, nullptr, ly2, nullptr, fast ? 2 * S + 1 : -1))) return rc;
-    if (!(skinny && skinny_heads(t, st, y3, m, P(t, "w_fin.weight"), P(t, "w_fin.bias"), C - 1, t->d_out, C)))
-        if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
-    if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
+    if (fwd) {
+        if (fast) {
+            if ((rc = fast_linear_fwd(t, st, la(S), "w2", y2, m, 2 * S))) return rc;
+            hipLaunchKernelGGL(mlt::act_lines_kernel, dim3(nblk(m * H / 8)), dim3(256), 0, st, (const float*)y2, m, H, ly2);
+        } else if ((rc = linear_fwd(t, st, a[S], H, P(t, "w2.weight"), P(t, "w2.bias"), y2, H, (int)m, H, H))) return rc;
+        if (!(skinny && skinny_heads(t, st, y2, m, P(t, "w_aux.weight"), P(t, "w_aux.bias"), 1, t->d_out + (C - 1), C)))
+            if ((rc = linear_fwd(t, st, y2, H, P(t, "w_aux.weight"), P(t, "w_aux.bias"), t->d_out + (C - 1), C, (int)m, 1, H))) return rc;
+        if ((rc = block_fwd(t, st, b3, m, nullptr, ly2, nullptr, fast ? 2 * S + 1 : -1))) return rc;
+        if (!(skinny && skinny_heads(t, st, y3, m, P(t, "w_fin.weight"), P(t, "w_fin.bias"), C - 1, t->d_out, C)))
+            if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
+        if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
+    }
     // ---------------- loss and its gradient
-    double* d_loss = t->d_red + 2 * H;  // the tail of the current (pre-zeroed) slot
-    T_TRY(hipMemsetAsync(t->d_dout, 0, (size_t)m * C * 4, st));
+    double lv[16] = {0};
     const bool task_weights = t->auto_tune || t->weighted;
-    if ((rc = upload_task_weights(t, st, task_weights))) return rc;
-    hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
-                       t->d_dout, d_loss, (const float*)(task_weights ? t->d_tw : nullptr));
-    double lv[16];
-    T_TRY(hipMemcpyAsync(lv, d_loss, mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (phases & PH_LOSS) {
+        double* d_loss = t->d_red + 2 * H;  // the tail of the current (pre-zeroed) slot
+        T_TRY(hipMemsetAsync(t->d_dout, 0, (size_t)m * C * 4, st));
+        if ((rc = upload_task_weights(t, st, task_weights))) return rc;
+        hipLaunchKernelGGL(mlt::loss_kernel, dim3(nblk(m)), dim3(256), 0, st, (const float*)t->d_out, C, labels_dev, label_cols, m,
+                           t->d_dout, d_loss, (const float*)(task_weights ? t->d_tw : nullptr));
+        T_TRY(hipMemcpyAsync(lv, d_loss, mlt::LOSS_NV * sizeof(double), hipMemcpyDeviceToHost, st));
+    } else if ((phases & PH_BWD) && dout_dev) {   // the caller's own loss: its gradient with respect to the (m, C) outputs
+        T_TRY(hipMemcpyAsync(t->d_dout, dout_dev, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (!(phases & PH_BWD)) return ML_OK;
     // ---------------- backward
     // (large-batch route: every gradient tensor is written in full by its producer -- no 34 MB memset of the gradient buffer)
     if (!fast) T_TRY(hipMemsetAsync(t->g, 0, (size_t)t->n_param * 4, st));
@@ -1447,6 +1463,12 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
         if (rc) return rc;
     }
     if ((rc = block_bwd(t, st, b0, m, gA, xhat, -2))) return rc;
+    if (!(phases & PH_OPT)) {   // the caller clips and steps its own optimizer: the raw gradients stay in t->g
+        flush_col_sums(t, st);
+        t->csf_defer = false;
+        T_TRY(hipStreamSynchronize(st));
+        return ML_OK;
+    }
     // ---------------- clip (always) + Adam + StepLR (per batch, only when updating)
     const int64_t k = t->step + 1;
     const float lr = t->lr0 * std::pow(t->gamma, (float)(t->step / t->sched_step));
@@ -1463,6 +1485,60 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     T_TRY(hipStreamSynchronize(st));
     finish_step_host(t, lv, task_weights, update, lr, bc1, bc2, losses_host);
     return ML_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, int label_cols, int64_t m,
+                    int update, double* losses_host, float* raw_out_dev, void* stream) {
+    if (!t || !x_dev || !labels_dev || m <= 1 || label_cols < 10) return tfail(ML_ERR_ARG, "bad argument");
+    if (t->C == 10 && label_cols < 11) return tfail(ML_ERR_ARG, "stereo labels need 11 columns");
+    int rc = ensure_cap(t, m);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int route = pick_route(t, m);
+    t->last_route = route;
+    t->fwd_pending_rows = 0;
+    if (route == 2) {
+        if (!mid_rows_ok(t, m)) return tfail(ML_ERR_SHAPE, "the mid route takes operands below 4 GiB (rows x hidden x 4)");
+        return step_mid(t, x_dev, labels_dev, label_cols, m, update, losses_host, raw_out_dev, st);
+    }
+    return step_phases(t, x_dev, labels_dev, label_cols, m, update, losses_host, raw_out_dev, st, PH_ALL, route, nullptr);
+}
+
+// The train-mode forward on its own (reference trainer.py:155 `outputs = self.model(inputs)` with the module in train mode,
+// architectures.py:48-71: batch-statistics BatchNorm with the running-statistics update, dropout from the counter-based generator --
+// fresh masks per call): raw_out_dev (m, C).  Everything the backward needs stays in the trainer's workspace; x_dev must stay valid and
+// unchanged until ml_trainer_backward has run.  Exact-fp32 route below fast_rows rows, the 3-product large-batch route from there on
+// (the fused small-batch route of ml_trainer_step has no seam between forward, loss and backward).
+int ml_trainer_forward_train(ml_trainer* t, const float* x_dev, int64_t m, float* raw_out_dev, void* stream) {
+    if (!t || !x_dev || !raw_out_dev || m <= 1) return tfail(ML_ERR_ARG, "bad argument");
+    int rc = ensure_cap(t, m);
+    if (rc) return rc;
+    int route = pick_route(t, m);
+    if (route == 2) route = 0;
+    t->last_route = route;
+    ++t->fwd_calls;
+    t->fwd_pending_rows = 0;
+    if ((rc = step_phases(t, x_dev, nullptr, 0, m, 0, nullptr, raw_out_dev, (hipStream_t)stream, PH_FWD, route, nullptr))) return rc;
+    t->fwd_pending_rows = m;
+    t->fwd_pending_x = x_dev;
+    return ML_OK;
+}
+
+// `loss.backward()` for the outputs of the last ml_trainer_forward_train (trainer.py:158): dout_dev (m, C) = gradient of the caller's
+// loss with respect to those outputs -> every parameter gradient, UNCLIPPED, readable through ml_trainer_get_grad (the caller clips and
+// steps its own optimizer, trainer.py:159-160).  Synchronises the stream.  The gradient with respect to the inputs is not computed
+// (the reference's inputs are data).
+int ml_trainer_backward(ml_trainer* t, const float* dout_dev, int64_t m, void* stream) {
+    if (!t || !dout_dev) return tfail(ML_ERR_ARG, "bad argument");
+    if (t->fwd_pending_rows != m || m <= 1)
+        return tfail(ML_ERR_STATE, "ml_trainer_backward: no ml_trainer_forward_train of %lld rows is pending", (long long)m);
+    const float* x_dev = t->fwd_pending_x;
+    t->fwd_pending_rows = 0;
+    return step_phases(t, x_dev, nullptr, 0, m, 0, nullptr, nullptr, (hipStream_t)stream, PH_BWD, t->last_route, dout_dev);
 }
 
 }  // extern "C"

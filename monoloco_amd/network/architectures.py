@@ -52,16 +52,53 @@ class _HipForward(nn.Module):
 
     def forward(self, x):
         if self.training or self.dropout.training:
-            raise NotImplementedError(
-                "%s.forward in train mode: this module's forward is the eval-mode network on the HIP engine (running-stat "
-                "BatchNorm, no dropout, no autograd graph) -- the reference's `outputs = self.model(inputs); loss.backward()` "
-                "(monoloco/train/trainer.py:155-161) has no counterpart on the module.  Train with monoloco_amd.train.Trainer "
-                "(same arguments and checkpoints as monoloco.train.Trainer; monoloco_amd.train.HipTrainer is the step underneath), "
-                "or call monoloco_amd.compat.install(trainer=True) so that `monoloco.train.Trainer` IS that class; call .eval() "
-                "for inference; MC-dropout runs through Loco(n_dropout=...)" % type(self).__name__)
+            return self._forward_train(x)
         home = x.device
         eng = self.hip_engine(home if home.type == 'cuda' else None)
         return eng.forward_raw(x.detach()).to(home)
+
+    def _forward_train(self, x):
+        raise NotImplementedError(
+            "%s.forward in train mode: this module's forward is the eval-mode network on the HIP engine (running-stat "
+            "BatchNorm, no dropout, no autograd graph); only LocoModel has a train-mode forward.  Train with monoloco_amd.train.Trainer "
+            "(same arguments and checkpoints as monoloco.train.Trainer; monoloco_amd.train.HipTrainer is the step underneath), "
+            "or call monoloco_amd.compat.install(trainer=True) so that `monoloco.train.Trainer` IS that class; call .eval() "
+            "for inference; MC-dropout runs through Loco(n_dropout=...)" % type(self).__name__)
+
+
+class _TrainForward(torch.autograd.Function):
+    """`outputs = self.model(inputs)` / `loss.backward()` of a caller-owned training loop (reference trainer.py:155-158,
+    hyp_tuning.py) on the HIP training kernels: forward = ml_trainer_forward_train (LocoModel.forward in train mode,
+    architectures.py:48-71), backward = ml_trainer_backward from the caller's gradient of the outputs; the parameter gradients come
+    back as the Function's input gradients, so `loss.backward()`, `clip_grad_norm_` and any torch optimizer work on the module's own
+    nn.Parameters.  Dropout masks come from the library's counter-based generator (statistically, not bitwise, torch's)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        tr = module._hip_trainer(x.device if x.is_cuda else None)
+        ctx.tr, ctx.keys, ctx.home = tr, [k for k, _ in module.named_parameters()], [p_.device for p_ in params]
+        out = tr.forward_train(x.detach())
+        # BatchNorm's running statistics moved inside the library: bring them back into the module's buffers
+        torch.cuda.synchronize(tr.device)
+        with torch.no_grad():
+            for name, buf in module.named_buffers():
+                if name.endswith(('running_mean', 'running_var')):
+                    buf.copy_(tr._get(_lib_load().ml_trainer_get_tensor, name).to(buf.device))
+                elif name.endswith('num_batches_tracked'):
+                    buf += 1
+        module._hip_trainer_key = module._train_key()     # (the buffers just written are the trainer's own values)
+        return out.to(x.device)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.tr.backward(grad_out.contiguous())
+        g = ctx.tr.grads()
+        return (None, None) + tuple(g[k].to(dev_) for k, dev_ in zip(ctx.keys, ctx.home))
+
+
+def _lib_load():
+    from .. import _lib
+    return _lib.load()
 
 
 class LocoModel(_HipForward):
@@ -92,6 +129,40 @@ class LocoModel(_HipForward):
         self.w_fin = nn.Linear(linear_size, self.output_size)
         self.relu = nn.ReLU(inplace=True)
         self.dropout = nn.Dropout(p_dropout)
+
+
+    # ---- train mode: an autograd-capable forward (round 6; the reference trains by calling the module, trainer.py:155-161)
+    _hip_tr = None
+    _hip_trainer_key = None
+
+    def _train_key(self):
+        return tuple((t.data_ptr(), t._version) for t in self.state_dict().values())
+
+    def _hip_trainer(self, device=None):
+        """The library-side twin of this module in train mode: created once, its parameters and running statistics refreshed
+        whenever the module's tensors were replaced or modified in place (an optimizer step, load_state_dict)."""
+        from ..train.hip_trainer import HipTrainer
+        dev = engine._require_cuda(device)
+        if self._hip_tr is not None and self._hip_tr.device != dev:
+            self._hip_tr.close()
+            self._hip_tr = None
+        if self._hip_tr is None:
+            self._hip_tr = HipTrainer(self.state_dict(), p_dropout=self.p_dropout, device=dev)
+            self._hip_trainer_key = self._train_key()
+        elif self._hip_trainer_key != self._train_key():
+            self._hip_tr.load_state_dict(self.state_dict())
+            self._hip_trainer_key = self._train_key()
+        return self._hip_tr
+
+    def _forward_train(self, x):
+        if self.training != self.dropout.training and self.p_dropout > 0:
+            # BatchNorm in train mode with dropout switched off (or the reverse): the library's train-mode forward has one switch
+            raise NotImplementedError("LocoModel: BatchNorm and Dropout must be in the same mode (model.train() / model.eval())")
+        assert x.dim() == 2 and x.shape[1] == self.stereo_size, "inputs must be (m, %d)" % self.stereo_size
+        if x.requires_grad:
+            raise NotImplementedError("LocoModel in train mode: the gradient with respect to the inputs is not computed (the "
+                                      "reference's inputs are data, trainer.py:152)")
+        return _TrainForward.apply(self, x, *[p_ for _, p_ in self.named_parameters()])
 
 
 class MonolocoModel(_HipForward):

@@ -66,6 +66,32 @@ def preprocess_pifpaf(annotations, im_size=None, enlarge_boxes=True, min_conf=0.
     return boxes, keypoints
 
 
+def preprocess_mask(dir_ann, basename, mode='left'):
+    """Boxes and keypoints of the instance-mask annotations next to a PifPaf annotation directory (reference process.py:136-152;
+    a host-side file reader off the keypoint -> 3D path, kept so that callers of the reference's `process` module find it):
+    `<parent of dir_ann>/mask[_right]/<basename>.json` -> (boxes, [[xs, ys, cs], ...]); ([], []) when the file is missing."""
+    from ..utils.iou import open_annotations
+    mask_dir = os.path.join(os.path.split(dir_ann)[0], 'mask')
+    assert mode in ('left', 'right'), "mode not recognized"
+    path_ann = os.path.join(mask_dir if mode == 'left' else mask_dir + '_right', basename + '.json')
+    dic = open_annotations(path_ann)
+    if isinstance(dic, list):
+        return [], []
+    keypoints = [prepare_pif_kps(np.array(kps).reshape(51,).tolist()) for kps in dic['keypoints']]
+    return dic['boxes'], keypoints
+
+
+def image_transform(image):
+    """ImageNet normalisation of a PIL image for the OpenPifPaf CNN (reference process.py:221-228): the CNN is out of scope here, the
+    helper only forwards to torchvision when the caller's environment has it."""
+    try:
+        import torchvision
+    except ImportError as exc:
+        raise ImportError("image_transform feeds the OpenPifPaf CNN (outside the keypoint -> 3D path) and needs torchvision") from exc
+    normalize = torchvision.transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+    return torchvision.transforms.Compose([torchvision.transforms.ToTensor(), normalize])(image)
+
+
 def load_calibration(calibration, im_size, focal_length=5.7):
     """Intrinsic matrix as nested lists (reference process.py:70-86): 'custom' derives it from the
     image size and a focal length in mm, otherwise intrinsics.yaml rescaled to im_size."""

@@ -147,6 +147,30 @@ class HipTrainer:
         self.last_plain = self._plain(vals)
         return (out, raw) if want_outputs else out
 
+    def forward_train(self, inputs):
+        """The train-mode forward on its own (reference trainer.py:155 `outputs = self.model(inputs)`; ml_trainer_forward_train):
+        batch-statistics BatchNorm (running statistics updated), fresh dropout masks -> (m, out_features) device tensor.  `inputs`
+        must stay alive and unchanged until backward() has run (the returned tensor keeps a reference)."""
+        dev = self.device
+        x = _dev_f32(inputs, dev)
+        assert x.dim() == 2 and x.shape[1] == self.in_features
+        raw = torch.empty((x.shape[0], self.out_features), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.load().ml_trainer_forward_train(self._h, _ptr(x), int(x.shape[0]), _ptr(raw), _stream(dev)), train=True)
+        self.version += 1          # (the running statistics moved)
+        self._pending_x = x
+        return raw
+
+    def backward(self, grad_outputs):
+        """`loss.backward()` for the outputs of the last forward_train (trainer.py:158; ml_trainer_backward): grad_outputs (m,
+        out_features) = gradient of the caller's loss with respect to them.  The UNCLIPPED parameter gradients are then in grads()."""
+        dev = self.device
+        g = _dev_f32(grad_outputs, dev)
+        assert g.dim() == 2 and g.shape[1] == self.out_features
+        with torch.cuda.device(dev):
+            check(_lib.load().ml_trainer_backward(self._h, _ptr(g), int(g.shape[0]), _stream(dev)), train=True)
+        self._pending_x = None
+
     @staticmethod
     def _plain(vals):
         """The unweighted means of one batch: training-type task values d (Laplace), x, y, h, w, l, ori, aux and the two

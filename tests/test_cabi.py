@@ -58,8 +58,12 @@ def test_no_fallback_without_gpu():
         Loco(model=None, mode='mono', device='cpu')
     # the module in train mode points at the Trainer and at compat.install(trainer=True)
     from monoloco_amd.network.architectures import LocoModel
-    with pytest.raises(NotImplementedError, match=r"monoloco_amd\.train\.Trainer.*compat\.install\(trainer=True\)"):
+    with pytest.raises(_lib.MonolocoHipError):          # (round 6: LocoModel has a train-mode forward -- on a HIP device only)
         LocoModel(34, 9, 256).train()(torch.zeros(2, 34))
+    # the legacy module has none: its message points at the Trainer and at compat.install(trainer=True)
+    from monoloco_amd.network.architectures import MonolocoModel
+    with pytest.raises(NotImplementedError, match=r"monoloco_amd\.train\.Trainer.*compat\.install\(trainer=True\)"):
+        MonolocoModel(34).train()(torch.zeros(2, 34))
 
 
 def test_product_never_imports_oracle():

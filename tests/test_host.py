@@ -317,3 +317,17 @@ def test_route_plan_per_row_count(hip_lib):
         assert hip_lib.ml_loco_plan(h, 16, 0, 1, ctypes.create_string_buffer(8), 8) == 1   # ML_ERR_ARG: buffer too small
     finally:
         hip_lib.ml_loco_destroy(h)
+
+
+def test_preprocess_mask_reads_the_mask_annotations(tmp_path):
+    """reference process.py:136-152: `<parent>/mask[_right]/<basename>.json` -> (boxes, [[xs, ys, cs]]); a missing file gives ([], [])."""
+    import json
+    from monoloco_amd.network.process import preprocess_mask
+    kps = [[float(3 * j + c) for j in range(17) for c in range(3)]]
+    for sub in ('mask', 'mask_right'):
+        (tmp_path / sub).mkdir()
+        (tmp_path / sub / 'img.json').write_text(json.dumps({'boxes': [[1, 2, 3, 4]], 'keypoints': kps}))
+    for mode in ('left', 'right'):
+        boxes, keypoints = preprocess_mask(str(tmp_path / 'annotations'), 'img', mode)
+        assert boxes == [[1, 2, 3, 4]] and keypoints == [[kps[0][0::3], kps[0][1::3], kps[0][2::3]]]
+    assert preprocess_mask(str(tmp_path / 'annotations'), 'nothing') == ([], [])
