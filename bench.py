@@ -118,17 +118,18 @@ def cpu_baseline(sd, kps_np, kk, budget_s):
     best_t = max(results, key=results.get)
     # the port against the REAL reference on the build container's CPU (tools/cpu_port_vs_reference.py: same threads, same batch,
     # outputs bit-identical): a committed calibration -- the reference itself does not exist on the GPU box
-    pvr, pvr_src = None, None
-    for name in ('r05_port_vs_reference.json', 'r04_port_vs_reference.json'):
+    pvr, pvr_src, pvr_host = None, None, None
+    for name in ('r06_port_vs_reference.json', 'r05_port_vs_reference.json', 'r04_port_vs_reference.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             rec = json.load(open(path))
             pvr, pvr_src = rec.get("port_vs_reference"), "replayed:profiles/%s (%s, %s host cores; per thread count: %s)" % (
                 name, rec.get("cpu_model"), rec.get("host_cores"),
                 {k: v.get("port_vs_reference") for k, v in rec.get("by_threads", {}).items()})
+            pvr_host = "%s, %s host cores: the BUILD container, not the box this line was measured on" % (rec.get("cpu_model"), rec.get("host_cores"))
             break
     return {"value": round(results[best_t], 1), "unit": "persons/s", "cores": best_t, "kind": "port",
-            "port_vs_reference": pvr, "port_vs_reference_source": pvr_src,
+            "port_vs_reference": pvr, "port_vs_reference_measured_on": pvr_host, "port_vs_reference_source": pvr_src,
             "reference_estimate": round(results[best_t] / pvr, 1) if pvr else None,
             "one_thread": round(results.get(1, 0.0), 1), "host_cores": ncpu, "usable_cores": usable,
             "cgroup_cpu_quota": quota, "cpu_model": cpu_model(),
@@ -145,7 +146,7 @@ def traffic_from_profiles(args):
     committed measurement does not cover this configuration."""
     if args.workload != 'mono' or args.precision != 'f16x2' or args.batch != 65536 or args.no_merge or args.total_rows:
         return None
-    for name in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
+    for name in ('r06_traffic.json', 'r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             return json.load(open(path)), "replayed:profiles/" + name
@@ -658,7 +659,7 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms, main_out=None):
         g = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_train_inputs.npz'))
         res = {"config": "BASELINE configs[4]: LocoModel 34->1024->9 train-mode fwd + MultiTaskLoss + bwd + clip + Adam, "
                          "dropout 0.2; fp32 tensors.  Below 4096 rows the mid route (monoloco_amd/csrc/train_mid.h): every GEMM "
-                         "on the exact fp32 MFMA reading the row-major tensors as they lie (launch list: profiles/r04_train_kernel_stats_rows331.txt) -> fraction of "
+                         "on the exact fp32 MFMA reading the row-major tensors as they lie (launch list: profiles/r06_train_kernel_stats_rows331.txt) -> fraction of "
                          "the 157 TF fp32-MFMA peak.  From 4096 rows the hidden-layer GEMMs run on the 3-product fp16 MFMA "
                          "kernel (fp32-class accuracy): fraction of the 833 TF (2500 / 3) a 3-product scheme can reach"}
         sd_tr = {k: torch.tensor(v) for k, v in synth.make_state_dict(31, 34, 9, 1024).items()}

@@ -53,6 +53,13 @@ struct DenseParams {
                         // k ranges per output tile (the K / 32 steps divide evenly), partial tiles in kpart, tickets in kcount
     float* kpart = nullptr;       // [tiles][ksplit][128 x TM] fp32 partial tiles (dense_mid_kernel<.., SPLITK>)
     unsigned* kcount = nullptr;   // [tiles] arrival counters, zero between launches
+    // dense_mid_kernel<.., PREP> (the mono pipeline's input layer): the workgroup pre-processes its own persons -- raw keypoints
+    // (prep_m, 3, 17) fp32, rows 0 and 1 of inverse(K), z (10 m), optional box centres out (prep_m, 2); x is not read then
+    const float* prep_kps = nullptr;
+    float* prep_centre = nullptr;
+    float prep_kinv[6] = {0, 0, 0, 0, 0, 0};
+    float prep_z = 0.f;
+    int prep_m = 0;
     int relu;
     int debug;          // bring-up/ablation bits (0 in production), see dense_kernel_pp.h
     unsigned long long* trace;  // optional s_memtime trace [grid][8 waves][64], nullptr in production

@@ -37,6 +37,7 @@
 // assumption, no deadlock.  Split 0 starts from the bias, the others from zero.
 #pragma once
 #include "dense_kernel_pp.h"
+#include "geom_kernels.h"   // cam_row, NKP / KPS_ROW / NIN: the fused pre-process of the input layer (PREP)
 
 // timing ablations of the LDS-DMA loop, COMPILE-TIME (-DML_MID_ABL=<bits>, results are garbage): 1 no requests inside the loop, 2 no MFMAs,
 // 4 no fragment reads, 8 no barrier / vmcnt wait per step, 16 no epilogue stores
@@ -76,10 +77,16 @@ struct MidCfg {
 // changed nothing; the LDS-DMA path delivers 34-36 B/clk/CU in the same micro-benchmark.  One raw s_barrier per step; the stage read in
 // step i - 1 is refilled with step i + 2 right behind step i's barrier; every wave waits for its OWN share of a stage with a counted
 // vmcnt(NI) (requests retire in order; past the end the requests repeat the last step so that the count never changes).
-template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0, bool SPLITK = false, bool DMA = false>
+// PREP (round 6, the input layer of the mono pipeline, K = 64): the workgroup computes its TM persons' network inputs itself --
+// preprocess_monoloco (reference process.py:47-67 = pixel_to_camera, utils/camera.py:10-29, of the 17 keypoints at z = 10) with
+// prep_kernel's very arithmetic (cam_row: the same bits) -- and writes them as hi|lo lines straight into the two stages' X rows; only the
+// weight rows are requested.  prep_kernel and its 8 + 0.5 bytes per person and input of HBM round trip disappear from the mid window
+// (5.6 us per forward); the column tile 0 workgroups also leave the box centres (get_keypoints(.., 'center'), camera.py:82-86).
+template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0, bool SPLITK = false, bool DMA = false, bool PREP = false>
 __global__ __launch_bounds__(MID_THREADS, (DMA && MidCfg<TM>::LDS_DMA > 80 * 1024) ? 1 : 2) void dense_mid_kernel(DenseParams p) {   // (a ring above 80 KiB: one workgroup per CU)
     typedef MidCfg<TM> C;
     constexpr int NB = C::NB, XL = C::XL;
+    static_assert(!PREP || (DMA && !SPLITK && !RES && HEAD == 0 && MidCfg<TM>::RING == 3), "the fused pre-process: the plain input layer on the LDS-DMA loader");
     constexpr bool AUX = HEAD == -1;
     static_assert(HEAD == 0 || HEAD == -1 || ((HEAD == 8 || HEAD == 9) && RELU && !RES), "fused head: w_aux (-1) or w_fin (8 | 9) behind relu, no residual");
     __shared__ __attribute__((aligned(16))) char smem[DMA ? C::LDS_DMA : C::LDS];
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(MID_THREADS, (DMA && MidCfg<TM>::LDS_DMA > 80 * 102
             const int gq = w + 4 * j;
             const bool is_w = gq < MID_TN / 8;   // (wave-uniform)
             const int rr = 8 * gq + (lane >> 3) - (is_w ? 0 : MID_TN);
-            const char* base = is_w ? p.w + (size_t)(n0 + rr) * rowb : p.x + (size_t)(m0 + rr) * rowb;
+            const char* base = (is_w || PREP) ? p.w + (size_t)(n0 + (is_w ? rr : 0)) * rowb : p.x + (size_t)(m0 + rr) * rowb;
             gsrc[j] = base + kbase + (((lane & 7) ^ ((rr >> 1) & 7)) * 16);
         }
         // instructions [ja, jb) of this wave's share of stage `st` <- k-step k
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(MID_THREADS, (DMA && MidCfg<TM>::LDS_DMA > 80 * 102
             char* sb = smem + st * C::STAGE + w * 1024;
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                if (j >= ja && j < jb) glds16(gsrc[j] + (size_t)kk * LINE, sb + j * 4096);
+                if (j >= ja && j < jb && !(PREP && j >= 4)) glds16(gsrc[j] + (size_t)kk * LINE, sb + j * 4096);   // (PREP: the W rows only)
         };
         // the bias loads above are the only ordinary vector loads in front of the epilogue: complete them HERE (left alone, hipcc
         // sinks their wait to the first MFMA inside the loop and, with LDS-DMA in the same queue, makes it a vmcnt(0) per step --
@@ -214,8 +221,54 @@ __global__ __launch_bounds__(MID_THREADS, (DMA && MidCfg<TM>::LDS_DMA > 80 * 102
 #pragma unroll
             for (int c = 0; c < NB; ++c) asm volatile("" : "+v"(acc[a][c]));
         constexpr int RING = C::RING;
+        if (PREP) {
+            // K = 64: two k-steps, both stages requested now (W rows), nothing inside the loop; stage 2 is the keypoint scratch
+            issue(0, 0, 0, NI);
+            issue(1, 1, 0, NI);
+            float* const s_in = (float*)(smem + 2 * C::STAGE);                 // TM persons x 51 floats (u[17], v[17], conf[17])
+            const int64_t left = (int64_t)p.prep_m - m0;
+            const int nvalid = left < 0 ? 0 : (left < TM ? (int)left : TM);
+            const float* src = p.prep_kps + (size_t)m0 * KPS_ROW;
+            for (int i = tid; i < nvalid * KPS_ROW; i += MID_THREADS) s_in[i] = src[i];
+            __syncthreads();
+            if (p.prep_centre && nt == 0 && tid < nvalid) {                     // get_keypoints(.., 'center'): (max - min) / 2 + min
+                const float* u = s_in + tid * KPS_ROW;
+                const float* v = u + NKP;
+                float umin = u[0], umax = u[0], vmin = v[0], vmax = v[0];
 #pragma unroll
-        for (int r0 = 0; r0 < RING; ++r0) issue(r0, r0, 0, NI);
+                for (int j = 1; j < NKP; ++j) {
+                    umin = __builtin_fminf(umin, u[j]);
+                    umax = __builtin_fmaxf(umax, u[j]);
+                    vmin = __builtin_fminf(vmin, v[j]);
+                    vmax = __builtin_fmaxf(vmax, v[j]);
+                }
+                p.prep_centre[(size_t)(m0 + tid) * 2 + 0] = __fadd_rn(__fmul_rn(__fsub_rn(umax, umin), 0.5f), umin);
+                p.prep_centre[(size_t)(m0 + tid) * 2 + 1] = __fadd_rn(__fmul_rn(__fsub_rn(vmax, vmin), 0.5f), vmin);
+            }
+            // one 16-byte chunk of a line per thread and pass: person pi, line b (= k-step = stage), chunk sub (< 4: hi, else lo) of
+            // k = 32 b + 8 (sub & 3) .. + 7; input k = 2 j + (0: x, 1: y) of joint j (process.py:65: interleaved), zero beyond 34 inputs
+            // and beyond the valid rows -- prep_kernel's statement, value for value
+            for (int id = tid; id < TM * 16; id += MID_THREADS) {
+                const int pi = id >> 4, c = id & 15, b = c >> 3, sub = c & 7;
+                const int k0 = b * 32 + (sub & 3) * 8;
+                const float* u = s_in + pi * KPS_ROW;
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + e, j = k >> 1;
+                    float val = 0.0f;
+                    if (k < NIN && pi < nvalid) val = cam_row(u[j], u[NKP + j], p.prep_kinv + ((k & 1) ? 3 : 0), p.prep_z);
+                    _Float16 hi, lo;
+                    split_f16(val, hi, lo);
+                    o[e] = (sub < 4) ? hi : lo;
+                }
+                *(half8*)(smem + b * C::STAGE + C::W_BYTES + pi * LINE + ((sub ^ ((pi >> 1) & 7)) * 16)) = o;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // both stages' W rows (the loop's counted waits find nothing outstanding)
+        } else {
+#pragma unroll
+            for (int r0 = 0; r0 < RING; ++r0) issue(r0, r0, 0, NI);
+        }
         // One request behind every unit of three MFMAs (one 32 x 32 output block's hi.lo + lo.hi + hi.hi: 96 matrix-pipe cycles against
         // ~110 of issue) -- TM = 128: eight units, eight requests; TM = 64: four units, six requests (2 + 2 + 1 + 1).
         auto mma_unit = [&](const Frag& f, int a, int c) {
@@ -266,7 +319,7 @@ __global__ __launch_bounds__(MID_THREADS, (DMA && MidCfg<TM>::LDS_DMA > 80 * 102
                         mma_unit(hs ? c1 : c0, a, c);     // (same order as mma_rows: the same bits as the register-staged loop)
                         const int unit = (hs * 2 + a) * NB + c, n_here = NB == 2 ? 1 : (unit < 2 ? 2 : 1);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (!MID_DBG(1)) issue(st, i + RING, j, j + n_here);
+                        if (!MID_DBG(1) && !PREP) issue(st, i + RING, j, j + n_here);
                         __builtin_amdgcn_sched_barrier(0);
                         j += n_here;
                     }

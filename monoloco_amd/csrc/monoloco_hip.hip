@@ -166,6 +166,7 @@ struct Tuning {
                             // -1 = auto (as many as it takes to reach mid_wgs workgroups: 1 | 2 | 4), 0 / 1 = off, 2 / 4 = forced where K allows
     int mid_wgs = 256;      // ... auto: workgroups a dense_mid_kernel launch should reach: one per CU -- splitting only fills IDLE CUs (fewer
                             // tiles than CUs); two co-resident workgroups per CU lose 10-40 % (measured, profiles/r06_ablation.md)
+    int mid_prep = 1;       // the mono pipeline's input layer pre-processes its own persons (dense_mid_kernel<.., PREP>; 0: prep_kernel in front)
     int mid_dma = 1;        // dense_mid_kernel's loader: 1 = LDS-DMA into a three-stage ring (round 6), 0 = global -> VGPR -> ds_write (rounds 3-5)
     int half_heads = 1;     // the whole mid window: both heads ride in the dense epilogues (half-size w4 tile / dense_mid_kernel) + tail_mono_kernel
                             // (option "mid_heads"; 0: heads_pair_kernel behind the last layer, rounds 3-4)
@@ -552,6 +553,16 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
         p.ksplit = ksplit;
         const dim3 grid((unsigned)(((tiles * ksplit + 7) / 8) * 8));
         const bool dma = tu.mid_dma && precision == ML_PREC_F16X2;
+        if (p.prep_kps) {   // the mono pipeline's input layer with the pre-process inside (run_network only asks where mid_prep_runs says so)
+            if (!(dma && head_nh == 0 && p.relu && !p.res && p.K == 64))
+                return fail(ML_ERR_STATE, "dense_mid_kernel: the fused pre-process needs the plain K = 64 input layer on the LDS-DMA loader");
+            p.ksplit = 1;
+            const dim3 pgrid((unsigned)(((tiles + 7) / 8) * 8));
+            if (tm == 128) hipLaunchKernelGGL((mlk::dense_mid_kernel<3, true, false, 128, 0, false, true, true>), pgrid, dim3(mlk::MID_THREADS), 0, st, p);
+            else hipLaunchKernelGGL((mlk::dense_mid_kernel<3, true, false, 64, 0, false, true, true>), pgrid, dim3(mlk::MID_THREADS), 0, st, p);
+            HIP_TRY(hipGetLastError());
+            return ML_OK;
+        }
 #define ML_MID_L(NS, RL, RS, TMV, HD, SK, DM) \
     hipLaunchKernelGGL((mlk::dense_mid_kernel<NS, RL, RS, TMV, HD, SK, DM>), grid, dim3(mlk::MID_THREADS), 0, st, p)
 #define ML_MID(NS, RL, RS, HD)                                                   \
@@ -783,6 +794,10 @@ struct TailMono {
     const float* geo_kps = nullptr;
     float* geo_out = nullptr;
     bool geo_done = false;
+    // optional (round 6): the raw keypoints (m, 3, 17) when the input layer is to pre-process its own persons (mid_prep_runs): the
+    // caller then launches no prep_kernel, the layer writes the box centres `centre` points at
+    const float* prep_kps = nullptr;
+    float* prep_centre = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1035,6 +1050,13 @@ int run_network(ml_loco* h, int64_t rows, float* raw_out, hipStream_t st, McPass
             p.kpart = h->d_kpart;          // (launch_dense decides whether this layer's reduction is split)
             p.kcount = h->d_kcount;
             p.ksplit = (int)(h->kpart_floats / ((int64_t)m_pad * L.n > 0 ? (int64_t)m_pad * L.n : 1));   // k ranges the workspace can hold
+            if (li == 0 && tail && tail->prep_kps) {   // (forward_mono_impl checked mid_prep_runs: the whole call is one chunk on the mid path)
+                p.prep_kps = tail->prep_kps;
+                p.prep_centre = tail->prep_centre;
+                for (int q = 0; q < 6; ++q) p.prep_kinv[q] = tail->ki.k[q];
+                p.prep_z = 10.0f;
+                p.prep_m = (int)rows;
+            }
             if (step.fused_fin) {
                 p.head_w = step.fused_fin->d_w;
                 p.head_part = h->d_part + r0 * (int64_t)nparts * 16;
@@ -1627,6 +1649,19 @@ int ml_loco_forward_raw(ml_loco* h, const float* x_dev, int64_t m, float* raw_de
 // ---------------------------------------------------------------- fused pipelines
 // geo_out != null: also the post_process geometry block (from the same keypoints); *geo_done = it was written by the launch that
 // ended the forward (a single image), otherwise the caller runs ml_post_geometry_strided
+// does the mono pipeline's input layer pre-process its own persons for a call of `rows` rows (dense_mid_kernel<.., PREP>)?  Inside the
+// mid window (its K = 64 layer runs dense_mid_kernel on both of the window's tile families), 3-product mode, LDS-DMA loader, the
+// whole call one chunk, the plain first layer of a LocoModel (34 inputs padded to 64, ReLU, nothing riding in its epilogue)
+static bool mid_prep_runs(const ml_loco* h, int64_t rows) {
+    if (!h->tune.mid_prep || !h->tune.mid_dma || h->precision != ML_PREC_F16X2 || h->tune.chunk_rows > 0) return false;
+    if (!use_mid_path(h->tune, h->precision, rows) || h->layers.empty()) return false;
+    const DenseLayer& L = h->layers[0];
+    if (!(L.kpad == 64 && L.relu && L.res < 0 && L.src == 0 && L.n % mlk::MID_TN == 0 && h->in_f == mlk::NIN && h->k0pad == 64)) return false;
+    for (const Head& hd : h->heads)
+        if (hd.after_layer == 0) return false;
+    return rows <= 0x7fffffff;
+}
+
 static int forward_mono_impl(ml_loco* h, const float* kps_dev, int64_t m, const float* kinv_host, const float* box_conf_dev,
                              float* raw_dev, float* out_dev, float* xyzds_dev, void* stream, float* geo_out, bool* geo_done) {
     int rc = check_ready(h);
@@ -1642,11 +1677,16 @@ static int forward_mono_impl(ml_loco* h, const float* kps_dev, int64_t m, const 
     const int64_t m_pad = round_up64(m, 256);
     const mlk::Kinv ki = make_kinv(kinv_host);
     // the small-row dense kernels read whole 32-row tiles only: no need to zero-fill up to the 256-row panel
-    if ((rc = launch_prep(st, kps_dev, m, ki, 10.0f, (float*)nullptr, h->d_centre, h->buf[0], h->k0pad,
-                          use_small_path(h->tune, h->precision, m) ? round_up64(m, 32) : m_pad, 0)))
+    const bool fused_prep = mid_prep_runs(h, m);   // the input layer pre-processes its own persons (no prep_kernel, no X0 round trip)
+    if (!fused_prep && (rc = launch_prep(st, kps_dev, m, ki, 10.0f, (float*)nullptr, h->d_centre, h->buf[0], h->k0pad,
+                                         use_small_path(h->tune, h->precision, m) ? round_up64(m, 32) : m_pad, 0)))
         return rc;
     float* raw = raw_dev ? raw_dev : h->d_raw;
     TailMono tail{h->d_centre, ki, box_conf_dev, out_dev, xyzds_dev, raw_dev};
+    if (fused_prep) {
+        tail.prep_kps = kps_dev;
+        tail.prep_centre = h->d_centre;
+    }
     tail.geo_kps = kps_dev;
     tail.geo_out = geo_out;
     if ((rc = run_network(h, m, raw, st, McPass(), &tail))) return rc;
@@ -1871,6 +1911,7 @@ int ml_loco_set_option(ml_loco* h, const char* name, int value) {
     else if (n == "mid_splitk") h->tune.mid_splitk = value;
     else if (n == "mid_wgs") h->tune.mid_wgs = value;
     else if (n == "mid_dma") h->tune.mid_dma = value ? 1 : 0;
+    else if (n == "mid_prep") h->tune.mid_prep = value ? 1 : 0;
     else return fail(ML_ERR_ARG, "unknown option '%s'", name);
     ++h->tune_version;
     return ML_OK;

@@ -283,3 +283,31 @@ def test_mid_split_k_whole_model(hip_lib, cuda_device, m, mode):
             for _ in range(50):
                 assert torch.equal(eng.forward_raw(x).cpu(), raw), (tile, sk)
     eng.close()
+
+
+@pytest.mark.parametrize("m", [257, 300, 1000, 2048, 2049, 3072, 4096, 5000, 8192])
+def test_input_layer_preprocesses_its_own_persons(hip_lib, cuda_device, m):
+    """Round 6: inside the mid window the mono pipeline's input layer computes preprocess_monoloco (reference process.py:47-67)
+    for its own persons in its prologue (dense_mid_kernel<.., PREP>) instead of reading prep_kernel's lines: the SAME bits in every
+    output (packed rows, parity tensor, raw rows -- the box centres feed the back-projection) as with prep_kernel in front, row
+    counts that are no multiple of the tile, both tile heights and the half-size-tile part of the window (whose K = 64 layer is
+    dense_mid_kernel's too), and the oracle's bar on a sample."""
+    from monoloco_amd import engine
+    from oracle import monoloco_oracle as O
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(4).items()}
+    eng = engine.LocoEngine(sd, device=cuda_device)
+    kinv = engine.inverse_intrinsics(synth.KITTI_K)
+    kps = torch.tensor(synth.make_poses(m, seed=m)).to(cuda_device)
+    conf = torch.rand(m, device=cuda_device)
+    got = {}
+    for fused in (1, 0):
+        eng.set_option('mid_prep', fused)
+        out, xyzds, raw = eng.forward_mono(kps, kinv, box_conf=conf, want_raw=True)
+        got[fused] = (out.clone(), xyzds.clone(), raw.clone())
+    for a, b in zip(got[1], got[0]):
+        assert torch.equal(a, b)
+    idx = torch.arange(0, m, max(1, m // 200))
+    ref = O.forward_mono(sd, kps[idx].cpu(), synth.KITTI_K, box_conf=conf[idx].cpu())
+    assert (got[1][1][idx].cpu() - ref['xyzds']).abs().max().item() <= 1e-4
+    assert (got[1][0][idx, 14:16].cpu() - O.get_keypoints(kps[idx].cpu(), 'center')).abs().max().item() == 0.0   # uc, vc: the box centres
+    eng.close()
