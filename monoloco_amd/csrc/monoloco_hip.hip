@@ -166,7 +166,10 @@ struct Tuning {
                             // -1 = auto (as many as it takes to reach mid_wgs workgroups: 1 | 2 | 4), 0 / 1 = off, 2 / 4 = forced where K allows
     int mid_wgs = 256;      // ... auto: workgroups a dense_mid_kernel launch should reach: one per CU -- splitting only fills IDLE CUs (fewer
                             // tiles than CUs); two co-resident workgroups per CU lose 10-40 % (measured, profiles/r06_ablation.md)
-    int mid_prep = 1;       // the mono pipeline's input layer pre-processes its own persons (dense_mid_kernel<.., PREP>; 0: prep_kernel in front)
+    int mid_prep = 0;       // 1: the mono pipeline's input layer pre-processes its own persons (dense_mid_kernel<.., PREP>) instead of prep_kernel
+                            // in front of it -- built, bit-identical, and NO gain (2048 rows 133.6 vs 133.5 us per forward, 8192 rows
+                            // 361.8 vs 368.2: eight column tiles repeat the work in a serial prologue, and prep_kernel's 5.6 us already hid
+                            // behind the previous call's tail; profiles/r06_ablation.md section 6): off, kept as the A/B switch
     int mid_dma = 1;        // dense_mid_kernel's loader: 1 = LDS-DMA into a three-stage ring (round 6), 0 = global -> VGPR -> ds_write (rounds 3-5)
     int half_heads = 1;     // the whole mid window: both heads ride in the dense epilogues (half-size w4 tile / dense_mid_kernel) + tail_mono_kernel
                             // (option "mid_heads"; 0: heads_pair_kernel behind the last layer, rounds 3-4)

@@ -287,8 +287,9 @@ def test_mid_split_k_whole_model(hip_lib, cuda_device, m, mode):
 
 @pytest.mark.parametrize("m", [257, 300, 1000, 2048, 2049, 3072, 4096, 5000, 8192])
 def test_input_layer_preprocesses_its_own_persons(hip_lib, cuda_device, m):
-    """Round 6: inside the mid window the mono pipeline's input layer computes preprocess_monoloco (reference process.py:47-67)
-    for its own persons in its prologue (dense_mid_kernel<.., PREP>) instead of reading prep_kernel's lines: the SAME bits in every
+    """Round 6 (an option, off by default: it measured no gain): inside the mid window the mono pipeline's input layer can compute
+    preprocess_monoloco (reference process.py:47-67) for its own persons in its prologue (dense_mid_kernel<.., PREP>, option
+    `mid_prep`) instead of reading prep_kernel's lines: the SAME bits in every
     output (packed rows, parity tensor, raw rows -- the box centres feed the back-projection) as with prep_kernel in front, row
     counts that are no multiple of the tile, both tile heights and the half-size-tile part of the window (whose K = 64 layer is
     dense_mid_kernel's too), and the oracle's bar on a sample."""
