@@ -684,6 +684,66 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms, main_out=None):
             tr.close()
             if not args.no_parity:
                 res[tag]["parity"] = train_parity(sd_tr, x, y, dev)
+        # the same 512-row iteration as a CALLER-OWNED loop over the module (reference trainer.py:150-161 verbatim: model(inputs), the
+        # caller's criterion, loss.backward(), clip_grad_norm_, torch's Adam): LocoModel's train-mode forward on the HIP training kernels
+        from monoloco_amd.network.architectures import LocoModel
+        import torch.nn.functional as F_
+
+        def multitask_loss(out_, lab_):
+            # the CALLER's criterion, plain torch on the device (MultiTaskLoss of the reference, train/losses.py:59-131: Laplace on d,
+            # L1 on x, y, h, w, l, ori; all lambdas 1) -- the caller's code, not the library's and not the oracle's
+            mu, si, xx = out_[:, 2:3], out_[:, 3:4], lab_[:, 3:4]
+            total = torch.mean(torch.abs(1 - mu / xx) * torch.exp(-si) + 0.01 + si + 2)
+            for c_ in (0, 1, 4, 5, 6):
+                total = total + F_.l1_loss(out_[:, c_:c_ + 1], lab_[:, c_:c_ + 1])
+            return total + F_.l1_loss(out_[:, 7:9], lab_[:, 7:9]), None
+        rep = (512 + 330) // 331
+        xm = torch.tensor(g['mono_x']).repeat(rep, 1)[:512].contiguous().to(dev)
+        ym = torch.tensor(g['mono_y']).repeat(rep, 1)[:512].contiguous().to(dev)
+        model = LocoModel(34, 9, 1024, p_dropout=0.2)
+        model.load_state_dict(sd_tr)
+        model = model.to(dev).train()
+        opt = torch.optim.Adam(model.parameters(), lr=0.001)
+
+        def iteration():
+            opt.zero_grad()
+            loss_, _ = multitask_loss(model(xm), ym)
+            loss_.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 3)
+            opt.step()
+        ms = _ms(iteration, 20, 5, dev)
+        entry = {"rows": 512, "ms_per_iteration": round(ms, 4), "route": "exact (ml_trainer_forward_train / ml_trainer_backward behind a "
+                 "torch.autograd.Function; loss, clip and Adam are torch's own kernels on the module's nn.Parameters)"}
+        if not args.no_parity:   # one dropout-0 iteration on fresh weights against the oracle's autograd (fp64, with its fp32 run beside it)
+            from oracle.train_oracle import OracleTrainer
+            m0 = LocoModel(34, 9, 1024, p_dropout=0.0)
+            m0.load_state_dict(sd_tr)
+            m0 = m0.to(dev).train()
+            l0, _ = multitask_loss(m0(xm), ym)
+            l0.backward()
+            o64 = OracleTrainer(sd_tr, lr=0.001, dtype=torch.float64)
+            r64, _ = o64.step(xm.cpu().double(), ym.cpu().double(), update=False)
+            o32 = OracleTrainer(sd_tr, lr=0.001)
+            o32.step(xm.cpu(), ym.cpu(), update=False)
+            # (the oracle clips to norm 3 inside step(): undo nothing -- compare directions and sizes through the clip factor of each side)
+            gn = float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in m0.parameters())))
+            clip = min(1.0, 3.0 / (gn + 1e-6))
+            worst, worst32, wk = 0.0, 0.0, None
+            g64, g32 = o64.grads(), o32.grads()
+            for k, p_ in m0.named_parameters():
+                if k.endswith('.bias') and 'batch_norm' not in k and not k.startswith(('w_aux', 'w_fin', 'w2.')):
+                    continue
+                ref = g64[k]
+                sc = float(ref.abs().max()) + 1e-300
+                e = float((p_.grad.cpu().double() * clip - ref).abs().max()) / sc
+                e32 = float((g32[k].double() - ref).abs().max()) / sc
+                if e > worst:
+                    worst, worst32, wk = e, e32, k
+            entry["parity"] = {"rel_loss_vs_fp64": float('%.3e' % (abs(float(l0) - r64['loss']) / max(1.0, abs(r64['loss'])))),
+                               "worst_gradient_element_over_tensor_max_vs_fp64": float('%.3e' % worst), "fp32_oracle_same_tensor": float('%.3e' % worst32),
+                               "worst_tensor": wk, "against": "oracle/train_oracle.OracleTrainer (fp64 / fp32), dropout 0, one iteration; "
+                               "tests/test_gpu_autograd.py holds the per-tensor bars"}
+        res["module_512"] = entry
         return res
     guarded("train", train)
 

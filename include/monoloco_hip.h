@@ -251,7 +251,9 @@ typedef struct ml_trainer ml_trainer;
  * dropout masks (counter-based RNG; p_dropout = 0 gives the deterministic path used for parity). */
 int ml_trainer_create(int in_features, int hidden, int out_features, int num_stage, float p_dropout, float lr,
                       float sched_gamma, int sched_step, uint32_t seed, ml_trainer** out);
-/* state_dict access by the reference's keys (parameters and BatchNorm running statistics). */
+/* state_dict access by the reference's keys (parameters and BatchNorm running statistics).  `host_data` may also be a DEVICE
+ * pointer of the trainer's device (the copy is hipMemcpyDefault): the autograd-capable module hands its CUDA parameters in and takes
+ * the gradients out without a host round trip.  Each call synchronises the device. */
 int ml_trainer_set_tensor(ml_trainer* t, const char* key, const float* host_data, int64_t numel);
 int ml_trainer_get_tensor(ml_trainer* t, const char* key, float* host_data, int64_t numel);
 /* gradient of the last step (after clipping when the step updated), parameters only */

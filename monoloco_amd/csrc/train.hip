@@ -1097,9 +1097,11 @@ static int xfer(ml_trainer* t, const char* key, float* host, const float* chost,
     float* base = what == 2 ? t->g : (it->second.is_param ? t->w : t->stat);
     if (what == 2 && !it->second.is_param) return tfail(ML_ERR_ARG, "'%s' is a buffer, it has no gradient", key);
     T_TRY(hipDeviceSynchronize());
+    // (hipMemcpyDefault: the caller's pointer may be host OR device memory -- the autograd module hands its CUDA parameters and
+    //  gradient buffers over without a host round trip)
     if (what == 0) {
-        T_TRY(hipMemcpy(base + it->second.off, chost, (size_t)numel * 4, hipMemcpyHostToDevice));
-    } else T_TRY(hipMemcpy(host, base + it->second.off, (size_t)numel * 4, hipMemcpyDeviceToHost));
+        T_TRY(hipMemcpy(base + it->second.off, chost, (size_t)numel * 4, hipMemcpyDefault));
+    } else T_TRY(hipMemcpy(host, base + it->second.off, (size_t)numel * 4, hipMemcpyDefault));
     return ML_OK;
 }
 int ml_trainer_set_tensor(ml_trainer* t, const char* key, const float* host_data, int64_t numel) {

@@ -83,7 +83,7 @@ class _TrainForward(torch.autograd.Function):
         with torch.no_grad():
             for name, buf in module.named_buffers():
                 if name.endswith(('running_mean', 'running_var')):
-                    buf.copy_(tr._get(_lib_load().ml_trainer_get_tensor, name).to(buf.device))
+                    buf.copy_(tr._get_device(_lib_load().ml_trainer_get_tensor, name).to(buf.device))
                 elif name.endswith('num_batches_tracked'):
                     buf += 1
         module._hip_trainer_key = module._train_key()     # (the buffers just written are the trainer's own values)
@@ -92,7 +92,7 @@ class _TrainForward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         ctx.tr.backward(grad_out.contiguous())
-        g = ctx.tr.grads()
+        g = ctx.tr.grads_device()      # device to device: the 34 MB of gradients never visit the host
         return (None, None) + tuple(g[k].to(dev_) for k, dev_ in zip(ctx.keys, ctx.home))
 
 

@@ -104,6 +104,12 @@ class HipTrainer:
             for key, val in state_dict.items():
                 if key.endswith('num_batches_tracked'):
                     continue
+                if isinstance(val, torch.Tensor) and val.is_cuda and val.device == self.device:
+                    # already on the trainer's device: device to device (ml_trainer_set_tensor copies with hipMemcpyDefault)
+                    dv = val.detach().to(torch.float32).contiguous()
+                    check(lib.ml_trainer_set_tensor(self._h, key.encode(), ctypes.cast(dv.data_ptr(), ctypes.POINTER(ctypes.c_float)),
+                                                    dv.numel()), train=True)
+                    continue
                 arr = np.ascontiguousarray(val.detach().to('cpu', torch.float32).numpy() if isinstance(val, torch.Tensor)
                                            else np.asarray(val, dtype=np.float32))
                 check(lib.ml_trainer_set_tensor(self._h, key.encode(), fptr(arr), arr.size), train=True)
@@ -113,6 +119,18 @@ class HipTrainer:
         with torch.cuda.device(self.device):
             check(fn(self._h, key.encode(), fptr(arr), arr.size), train=True)
         return torch.from_numpy(arr)
+
+    def _get_device(self, fn, key):
+        """The same tensor as a DEVICE tensor on the trainer's device (no host round trip)."""
+        out = torch.empty(self.shapes[key], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(fn(self._h, key.encode(), ctypes.cast(out.data_ptr(), ctypes.POINTER(ctypes.c_float)), out.numel()), train=True)
+        return out
+
+    def grads_device(self):
+        """grads() as device tensors."""
+        lib = _lib.load()
+        return {k: self._get_device(lib.ml_trainer_get_grad, k) for k in self.shapes if 'running_' not in k}
 
     def state_dict(self):
         lib = _lib.load()
