@@ -739,7 +739,7 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms, main_out=None):
                 e32 = float((g32[k].double() - ref).abs().max()) / sc
                 if e > worst:
                     worst, worst32, wk = e, e32, k
-            entry["parity"] = {"rel_loss_vs_fp64": float('%.3e' % (abs(float(l0) - r64['loss']) / max(1.0, abs(r64['loss'])))),
+            entry["parity"] = {"rel_loss_vs_fp64": float('%.3e' % (abs(float(l0.detach()) - r64['loss']) / max(1.0, abs(r64['loss'])))),
                                "worst_gradient_element_over_tensor_max_vs_fp64": float('%.3e' % worst), "fp32_oracle_same_tensor": float('%.3e' % worst32),
                                "worst_tensor": wk, "against": "oracle/train_oracle.OracleTrainer (fp64 / fp32), dropout 0, one iteration; "
                                "tests/test_gpu_autograd.py holds the per-tensor bars"}

@@ -51,10 +51,10 @@ def test_train_mode_forward_and_backward_match_the_oracle(hip_lib, cuda_device, 
         o = forward_train(params, run, x.to(dt), 0.0, 3)
         l, _ = multitask_loss(o, y.to(dt))
         l.backward()
-        res[dt] = (o.detach(), float(l), {k: v.grad for k, v in params.items()}, run)
+        res[dt] = (o.detach(), float(l.detach()), {k: v.grad for k, v in params.items()}, run)
     o64, l64, g64, run64 = res[torch.float64]
     o32, l32, g32, _ = res[torch.float32]
-    assert abs(float(loss) - l64) <= 2e-5 * max(1.0, abs(l64))
+    assert abs(float(loss.detach()) - l64) <= 2e-5 * max(1.0, abs(l64))
     noise = float((o32.double() - o64).abs().max())
     assert float((out.detach().cpu().double() - o64).abs().max()) <= 2 * noise + 2e-5
     gmax = max(float(v.abs().max()) for v in g64.values())
