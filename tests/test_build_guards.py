@@ -105,7 +105,15 @@ def test_pp_and_mid_loops_keep_their_shape(reports):
             assert loop.get('lds_dma') == 14 and loop.get('barrier') == 4 and loop.get('vmcnt_waits') == {0: 2, 2: 1}, (name, loop)
             assert loop.get('mfma') == {3: 48, 1: 16, 0: 16}[nsplit] and 'other_vmem' not in loop and 'ds_write' not in loop, (name, loop)
             seen_pp += 1
-        if name.startswith('dense_mid_kernel<') and loop is not None and name.rstrip('>').endswith(', true'):
+        targs = name[name.index('<') + 1:name.rindex('>')].split(', ') if name.startswith('dense_mid_kernel<') else []
+        is_dma = len(targs) >= 7 and targs[6] == 'true'        # <NSPLIT, RELU, RES, TM, HEAD, SPLITK, DMA, PREP>
+        is_prep = len(targs) >= 8 and targs[7] == 'true'
+        if is_prep and loop is not None:
+            # the input layer with the pre-process inside (K = 64: both stages requested in front of the loop): no request, no vector-memory
+            # instruction inside the loop at all
+            assert 'lds_dma' not in loop and 'other_vmem' not in loop and loop.get('barrier') == 2, (name, loop)
+            continue
+        if name.startswith('dense_mid_kernel<') and loop is not None and is_dma:
             # round 6, the LDS-DMA loader (last template argument): two steps per iteration (the two fragment register sets), per step
             # NI = (128 + TM) / 32 requests per wave, ONE counted wait vmcnt(NI), one barrier, the next step's fragment reads (2 half-steps
             # x (4 W + 2 TM / 64 X) ds_read_b128); no register-staged load or LDS store left, and no wait of hipcc's own in front of the
