@@ -126,6 +126,10 @@ int main(int argc, char** argv) {
         printf("c-abi client: frame entry, %lld persons, max |frame - pipeline| = %.3e\n", (long long)mf, wf);
         if (!(wf <= 5e-5)) worst = 1.0;   /* fails the run.  (16 persons take the small-row kernels, the batch above another dense
                                              kernel family: same operands, another fp32 summation order -- a few ulps at 20-60 m) */
+        /* the pinned-buffer contract (include/monoloco_hip.h): the handle remembers p_kps / p_out as verified pinned ranges -- tell it to
+         * forget them BEFORE they are freed (a later malloc may reuse the addresses as pageable memory) */
+        ML(ml_loco_forget_pinned(h, p_kps));
+        ML(ml_loco_forget_pinned(h, NULL));
         hipHostFree(p_kps); hipHostFree(p_out); hipFree(d_stage); hipFree(d_buf);
     }
     /* ground-truth association of post_process through the ABI (reference utils/iou.py:44-100): 4 detections x 3 ground-truth boxes,
