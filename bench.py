@@ -686,6 +686,13 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms, main_out=None):
             tr.close()
             if not args.no_parity:
                 res[tag]["parity"] = train_parity(sd_tr, x, y, dev)
+        return res
+    guarded("train", train)
+
+    def train_module_loop():
+        from monoloco_amd.train import HipTrainer  # noqa: F401  (same library entry points underneath)
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_train_inputs.npz'))
+        sd_tr = {k: torch.tensor(v) for k, v in synth.make_state_dict(31, 34, 9, 1024).items()}
         # the same 512-row iteration as a CALLER-OWNED loop over the module (reference trainer.py:150-161 verbatim: model(inputs), the
         # caller's criterion, loss.backward(), clip_grad_norm_, torch's Adam): LocoModel's train-mode forward on the HIP training kernels
         from monoloco_amd.network.architectures import LocoModel
@@ -745,9 +752,8 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms, main_out=None):
                                "worst_gradient_element_over_tensor_max_vs_fp64": float('%.3e' % worst), "fp32_oracle_same_tensor": float('%.3e' % worst32),
                                "worst_tensor": wk, "against": "oracle/train_oracle.OracleTrainer (fp64 / fp32), dropout 0, one iteration; "
                                "tests/test_gpu_autograd.py holds the per-tensor bars"}
-        res["module_512"] = entry
-        return res
-    guarded("train", train)
+        return entry
+    guarded("train_module_loop", train_module_loop)
 
     def train_epoch():
         # the reference's only training figure is the wall time of its fixture run (tests/test_train_mono.py:42-50:
