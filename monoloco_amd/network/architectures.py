@@ -34,6 +34,14 @@ class _HipForward(nn.Module):
     _engine = None
     _engine_key = None
 
+    def __getstate__(self):
+        # copy.deepcopy(model) / torch.save(model): the native handles (the packed engine, the train-mode twin) are per-object caches that
+        # hold raw pointers -- a copy starts without them and rebuilds them on first use
+        state = self.__dict__.copy()
+        for k in ('_engine', '_engine_key', '_hip_tr', '_hip_trainer_key'):
+            state.pop(k, None)
+        return state
+
     # -- engine management: re-pack when parameters were replaced or modified in place
     def _params_key(self, dev):
         return (str(dev), self.precision, self.merge_w2w3) + tuple(

@@ -331,3 +331,22 @@ def test_preprocess_mask_reads_the_mask_annotations(tmp_path):
         boxes, keypoints = preprocess_mask(str(tmp_path / 'annotations'), 'img', mode)
         assert boxes == [[1, 2, 3, 4]] and keypoints == [[kps[0][0::3], kps[0][1::3], kps[0][2::3]]]
     assert preprocess_mask(str(tmp_path / 'annotations'), 'nothing') == ([], [])
+
+
+def test_modules_copy_and_pickle_without_their_native_handles():
+    """copy.deepcopy(model) and torch.save(model) work whatever native caches the module holds (the packed eval engine, the train-mode
+    twin): they are raw-pointer handles, dropped from the copied state and rebuilt on first use."""
+    import copy
+    import ctypes
+    import io
+    import torch
+    from monoloco_amd.network.architectures import LocoModel
+
+    class Handle:
+        def __init__(self):
+            self._h = ctypes.c_void_p(5)
+    m = LocoModel(34, 9, 256)
+    m._hip_tr, m._engine = Handle(), Handle()
+    m2 = copy.deepcopy(m)
+    assert m2._engine is None and m2._hip_tr is None and torch.equal(m2.w1.weight, m.w1.weight)
+    torch.save(m, io.BytesIO())
