@@ -86,7 +86,7 @@ template <int NSPLIT, bool RELU, bool RES, int TM, int HEAD = 0, bool SPLITK = f
 __global__ __launch_bounds__(MID_THREADS, (DMA && MidCfg<TM>::LDS_DMA > 80 * 1024) ? 1 : 2) void dense_mid_kernel(DenseParams p) {   // (a ring above 80 KiB: one workgroup per CU)
     typedef MidCfg<TM> C;
     constexpr int NB = C::NB, XL = C::XL;
-    static_assert(!PREP || (DMA && !SPLITK && !RES && HEAD == 0 && MidCfg<TM>::RING == 3), "the fused pre-process: the plain input layer on the LDS-DMA loader");
+    static_assert(!PREP || (DMA && !SPLITK && !RES && HEAD == 0 && MidCfg<TM>::RING >= 3), "the fused pre-process: the plain input layer on the LDS-DMA loader");
     constexpr bool AUX = HEAD == -1;
     static_assert(HEAD == 0 || HEAD == -1 || ((HEAD == 8 || HEAD == 9) && RELU && !RES), "fused head: w_aux (-1) or w_fin (8 | 9) behind relu, no residual");
     __shared__ __attribute__((aligned(16))) char smem[DMA ? C::LDS_DMA : C::LDS];
