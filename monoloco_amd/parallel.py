@@ -18,6 +18,22 @@ def shard_bounds(total_rows, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def visibility_masked():
+    """Did a launcher restrict this process to a subset of the node's GPUs?"""
+    return any(os.environ.get(v) not in (None, '') for v in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
+
+
+def local_device_index(local_rank):
+    """The HIP device of this process: device `local_rank` when the process sees the node's GPUs (torchrun's default), device 0 when a
+    launcher masked the visibility to ONE device per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = its own GPU)."""
+    have = torch.cuda.device_count()
+    if have == 1 and visibility_masked():
+        return 0
+    if local_rank >= have:
+        raise RuntimeError("local rank %d has no HIP device of its own: torch.cuda.device_count() = %d" % (local_rank, have))
+    return local_rank
+
+
 def init_from_env(backend=None, force=False):
     """Initialise torch.distributed from torchrun's env (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*).
     Returns (rank, world_size, local_rank).  A single process is (0, 1, 0) with no group -- unless ``force``: then a
@@ -32,9 +48,10 @@ def init_from_env(backend=None, force=False):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
-            torch.cuda.set_device(local)
+            dev_index = local_device_index(local)
+            torch.cuda.set_device(dev_index)
             dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device('cuda', local))
+                                    device_id=torch.device('cuda', dev_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
