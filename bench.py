@@ -1224,6 +1224,10 @@ def main(argv=None):
         dist.all_gather_object(seen, me)
     else:
         seen = [me]
+    if multi and not stub and len({r["device"] for r in seen}) < world:
+        # (possible only when a launcher masked every rank to "its" one visible device and two masks name the same GPU)
+        raise SystemExit("bench.py: %d ranks share %d HIP device(s) (%s): one process per GPU is the contract"
+                         % (world, len({r["device"] for r in seen}), sorted({r["device"] for r in seen})))
 
     gather_check = None
     if sharded is not None:
