@@ -1130,9 +1130,7 @@ def main(argv=None):
     if not stub and multi:
         # one-line, non-zero failure BEFORE the rendezvous when this rank has no device of its own (torchrun with more ranks than GPUs)
         have, want_local = torch.cuda.device_count(), int(os.environ.get('LOCAL_RANK', '0'))
-        # (have == 1 with several local ranks: a launcher that masks the visibility to one device per rank -- each rank then uses its device 0)
-        masked_one = have == 1 and parallel.visibility_masked()
-        if have == 0 or (not masked_one and (have <= want_local or have < min(args.gpus, int(os.environ.get('LOCAL_WORLD_SIZE', args.gpus))))):
+        if have <= want_local or have < min(args.gpus, int(os.environ.get('LOCAL_WORLD_SIZE', args.gpus))):
             raise SystemExit("bench.py: rank %s (local rank %d) has no HIP device of its own: --gpus %d, torch.cuda.device_count() = %d"
                              % (os.environ.get('RANK', '0'), want_local, args.gpus, have))
     rank, world, local = parallel.init_from_env(('gloo' if stub else 'nccl') if multi else None, force=args.force_distributed)
@@ -1225,7 +1223,7 @@ def main(argv=None):
     else:
         seen = [me]
     if multi and not stub and len({r["device"] for r in seen}) < world:
-        # (possible only when a launcher masked every rank to "its" one visible device and two masks name the same GPU)
+        # (cannot happen under torchrun's device-per-local-rank convention; kept as the line's own guarantee)
         raise SystemExit("bench.py: %d ranks share %d HIP device(s) (%s): one process per GPU is the contract"
                          % (world, len({r["device"] for r in seen}), sorted({r["device"] for r in seen})))
 

@@ -18,17 +18,10 @@ def shard_bounds(total_rows, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def visibility_masked():
-    """Did a launcher restrict this process to a subset of the node's GPUs?"""
-    return any(os.environ.get(v) not in (None, '') for v in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
-
-
 def local_device_index(local_rank):
-    """The HIP device of this process: device `local_rank` when the process sees the node's GPUs (torchrun's default), device 0 when a
-    launcher masked the visibility to ONE device per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = its own GPU)."""
+    """The HIP device of this process under torchrun: device `local_rank` of the node's GPUs (every rank sees them all); a rank beyond
+    the visible devices has none of its own and must not silently share another rank's."""
     have = torch.cuda.device_count()
-    if have == 1 and visibility_masked():
-        return 0
     if local_rank >= have:
         raise RuntimeError("local rank %d has no HIP device of its own: torch.cuda.device_count() = %d" % (local_rank, have))
     return local_rank
