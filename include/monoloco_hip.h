@@ -256,6 +256,14 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
  * the gradients out without a host round trip.  Each call synchronises the device. */
 int ml_trainer_set_tensor(ml_trainer* t, const char* key, const float* host_data, int64_t numel);
 int ml_trainer_get_tensor(ml_trainer* t, const char* key, float* host_data, int64_t numel);
+/* The flat buffers behind the keyed access (parameters and their gradients in slot order in one allocation, the BatchNorm running
+ * statistics in another): where `key` starts (elements; -1: unknown key; *is_param says which buffer), the two sizes, and ONE
+ * stream-ordered device-to-device copy of a whole buffer -- what 0: parameters <- dev_ptr, 1: parameters -> dev_ptr, 2: gradients ->
+ * dev_ptr, 3: statistics <- dev_ptr, 4: statistics -> dev_ptr.  (No reference counterpart: torch modules own their tensors; the
+ * autograd-capable LocoModel moves its 62 tensors with two copies per iteration this way.) */
+int64_t ml_trainer_flat_offset(const ml_trainer* t, const char* key, int* is_param);
+int ml_trainer_flat_numel(const ml_trainer* t, int64_t* n_param, int64_t* n_stat);
+int ml_trainer_copy_flat(ml_trainer* t, int what, float* dev_ptr, int64_t numel, void* stream);
 /* gradient of the last step (after clipping when the step updated), parameters only */
 int ml_trainer_get_grad(ml_trainer* t, const char* key, float* host_data, int64_t numel);
 /* One step on a batch resident on the device: x_dev (m, in_features), labels_dev (m, label_cols) with the

@@ -90,6 +90,9 @@ SIGNATURES = {
     'ml_trainer_get_log_sigmas': (c_int, [_P, POINTER(c_float)]),
     'ml_trainer_set_log_sigmas': (c_int, [_P, POINTER(c_float)]),
     'ml_trainer_step': (c_int, [_P, _P, _P, c_int, c_int64, c_int, POINTER(c_double), _P, _P]),
+    'ml_trainer_flat_offset': (c_int64, [_P, c_char_p, POINTER(c_int)]),
+    'ml_trainer_flat_numel': (c_int, [_P, POINTER(c_int64), POINTER(c_int64)]),
+    'ml_trainer_copy_flat': (c_int, [_P, c_int, _P, c_int64, _P]),
     'ml_trainer_forward_train': (c_int, [_P, _P, c_int64, _P, _P]),
     'ml_trainer_backward': (c_int, [_P, _P, c_int64, _P]),
     'ml_trainer_num_steps': (c_int64, [_P]),

@@ -1110,6 +1110,34 @@ int ml_trainer_set_tensor(ml_trainer* t, const char* key, const float* host_data
 int ml_trainer_get_tensor(ml_trainer* t, const char* key, float* host_data, int64_t numel) {
     return xfer(t, key, host_data, nullptr, numel, 1);
 }
+// The flat buffers behind the keyed access: parameters (and their gradients) lie in ONE allocation in slot order, the BatchNorm
+// running statistics in another.  ml_trainer_flat_offset: where `key` starts in its buffer (elements; -1: unknown) and which buffer
+// (*is_param); ml_trainer_flat_numel: the two sizes; ml_trainer_copy_flat: one stream-ordered copy of a whole buffer, device to device --
+// what 0: parameters <- dev_ptr, 1: parameters -> dev_ptr, 2: gradients -> dev_ptr, 3: statistics <- dev_ptr, 4: statistics -> dev_ptr.
+// The autograd-capable module moves its 62 tensors with two copies per iteration this way instead of 62 synchronising ones.
+int64_t ml_trainer_flat_offset(const ml_trainer* t, const char* key, int* is_param) {
+    if (!t || !key) return -1;
+    auto it = t->slots.find(key);
+    if (it == t->slots.end()) return -1;
+    if (is_param) *is_param = it->second.is_param ? 1 : 0;
+    return it->second.off;
+}
+int ml_trainer_flat_numel(const ml_trainer* t, int64_t* n_param, int64_t* n_stat) {
+    if (!t) return tfail(ML_ERR_ARG, "null argument");
+    if (n_param) *n_param = t->n_param;
+    if (n_stat) *n_stat = t->n_stat;
+    return ML_OK;
+}
+int ml_trainer_copy_flat(ml_trainer* t, int what, float* dev_ptr, int64_t numel, void* stream) {
+    if (!t || !dev_ptr || what < 0 || what > 4) return tfail(ML_ERR_ARG, "bad argument");
+    const bool stats = what >= 3;
+    if (numel != (stats ? t->n_stat : t->n_param))
+        return tfail(ML_ERR_ARG, "ml_trainer_copy_flat: %lld elements, the buffer has %lld", (long long)numel, (long long)(stats ? t->n_stat : t->n_param));
+    float* mine = what == 2 ? t->g : (stats ? t->stat : t->w);
+    const bool in = what == 0 || what == 3;
+    T_TRY(hipMemcpyAsync(in ? mine : dev_ptr, in ? dev_ptr : mine, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ML_OK;
+}
 int ml_trainer_get_grad(ml_trainer* t, const char* key, float* host_data, int64_t numel) {
     return xfer(t, key, host_data, nullptr, numel, 2);
 }

@@ -87,11 +87,11 @@ class _TrainForward(torch.autograd.Function):
         ctx.tr, ctx.keys, ctx.home = tr, [k for k, _ in module.named_parameters()], [p_.device for p_ in params]
         out = tr.forward_train(x.detach())
         # BatchNorm's running statistics moved inside the library: bring them back into the module's buffers
-        torch.cuda.synchronize(tr.device)
         with torch.no_grad():
+            stats = tr.stats_flat()            # (one stream-ordered device-to-device copy)
             for name, buf in module.named_buffers():
                 if name.endswith(('running_mean', 'running_var')):
-                    buf.copy_(tr._get_device(_lib_load().ml_trainer_get_tensor, name).to(buf.device))
+                    buf.copy_(stats[name].to(buf.device))
                 elif name.endswith('num_batches_tracked'):
                     buf += 1
         module._hip_trainer_key = module._train_key()     # (the buffers just written are the trainer's own values)
@@ -100,7 +100,7 @@ class _TrainForward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         ctx.tr.backward(grad_out.contiguous())
-        g = ctx.tr.grads_device()      # device to device: the 34 MB of gradients never visit the host
+        g = ctx.tr.grads_flat()        # ONE device-to-device copy: the 34 MB of gradients never visit the host
         return (None, None) + tuple(g[k].to(dev_) for k, dev_ in zip(ctx.keys, ctx.home))
 
 
@@ -158,7 +158,11 @@ class LocoModel(_HipForward):
             self._hip_tr = HipTrainer(self.state_dict(), p_dropout=self.p_dropout, device=dev)
             self._hip_trainer_key = self._train_key()
         elif self._hip_trainer_key != self._train_key():
-            self._hip_tr.load_state_dict(self.state_dict())
+            sd = self.state_dict()
+            if all(v.is_cuda and v.device == dev for k, v in sd.items() if not k.endswith('num_batches_tracked')):
+                self._hip_tr.load_tensors_flat(sd)        # two flat device-to-device copies (after every optimizer step)
+            else:
+                self._hip_tr.load_state_dict(sd)
             self._hip_trainer_key = self._train_key()
         return self._hip_tr
 

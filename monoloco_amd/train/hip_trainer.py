@@ -120,6 +120,51 @@ class HipTrainer:
             check(fn(self._h, key.encode(), fptr(arr), arr.size), train=True)
         return torch.from_numpy(arr)
 
+    # ---- flat exchange (ml_trainer_copy_flat): all parameters / gradients / running statistics in ONE device-to-device copy each
+    def _flat_layout(self):
+        if getattr(self, '_layout', None) is None:
+            lib = _lib.load()
+            n_p, n_s = ctypes.c_int64(), ctypes.c_int64()
+            check(lib.ml_trainer_flat_numel(self._h, ctypes.byref(n_p), ctypes.byref(n_s)), train=True)
+            lay = {}
+            for k, shape in self.shapes.items():
+                isp = ctypes.c_int()
+                off = int(lib.ml_trainer_flat_offset(self._h, k.encode(), ctypes.byref(isp)))
+                assert off >= 0, k
+                lay[k] = (off, int(np.prod(shape)) if len(shape) else 1, bool(isp.value))
+            self._layout = (lay, int(n_p.value), int(n_s.value))
+        return self._layout
+
+    def _copy_flat(self, what, flat):
+        with torch.cuda.device(self.device):
+            check(_lib.load().ml_trainer_copy_flat(self._h, int(what), _ptr(flat), flat.numel(), _stream(self.device)), train=True)
+
+    def load_tensors_flat(self, tensors):
+        """`tensors`: {state_dict key: CUDA tensor on this device} covering EVERY parameter and running statistic: two flat
+        device-to-device copies instead of one synchronising copy per tensor."""
+        lay, n_p, n_s = self._flat_layout()
+        flat_p = torch.empty((n_p,), dtype=torch.float32, device=self.device)
+        flat_s = torch.empty((n_s,), dtype=torch.float32, device=self.device)
+        for k, (off, n, isp) in lay.items():
+            (flat_p if isp else flat_s)[off:off + n].copy_(tensors[k].detach().reshape(-1))
+        self._copy_flat(0, flat_p)
+        self._copy_flat(3, flat_s)
+        self.version += 1
+
+    def grads_flat(self):
+        """{key: device tensor (a view of one flat buffer)} of every parameter gradient."""
+        lay, n_p, _ = self._flat_layout()
+        flat = torch.empty((n_p,), dtype=torch.float32, device=self.device)
+        self._copy_flat(2, flat)
+        return {k: flat[off:off + n].view(self.shapes[k]) for k, (off, n, isp) in lay.items() if isp}
+
+    def stats_flat(self):
+        """{key: device tensor} of the BatchNorm running statistics."""
+        lay, _, n_s = self._flat_layout()
+        flat = torch.empty((n_s,), dtype=torch.float32, device=self.device)
+        self._copy_flat(4, flat)
+        return {k: flat[off:off + n].view(self.shapes[k]) for k, (off, n, isp) in lay.items() if not isp}
+
     def _get_device(self, fn, key):
         """The same tensor as a DEVICE tensor on the trainer's device (no host round trip)."""
         out = torch.empty(self.shapes[key], dtype=torch.float32, device=self.device)
