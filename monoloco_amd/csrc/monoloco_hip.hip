@@ -493,7 +493,11 @@ bool use_half_tile(const Tuning& tu, int precision, int64_t rows) {
 // tile height of a dense_mid_kernel launch whose 128-row tiling has `tiles128` tiles (ONE rule for launch_dense and for the route label)
 int mid_tile_rows(const Tuning& tu, int precision, int tiles128) {
     if (tu.mid_tile == 64 || tu.mid_tile == 128) return tu.mid_tile;
-    return tiles128 >= (tu.mid_dma && precision == ML_PREC_F16X2 ? (3 * num_cus()) / 4 : num_cus()) ? 128 : 64;
+    // (LDS-DMA loader: 128-row tiles as soon as the 64-row tiles no longer fit the CUs in ONE wave -- a forward costs 128-139 us with up to
+    //  256 of the 64-row tiles, 197-203 us with 272 ... 384 of them and 183-190 us with the 136 ... 192 128-row tiles of the same rows:
+    //  2176 ... 3072 rows, tools/ab_options.py, profiles/r06_ablation.md section 3)
+    if (tu.mid_dma && precision == ML_PREC_F16X2) return 2 * tiles128 > num_cus() ? 128 : 64;
+    return tiles128 >= num_cus() ? 128 : 64;
 }
 
 // k ranges per output tile of a dense_mid_kernel launch (round 6): the smallest of 1, 2, 4 that reaches tu.mid_wgs workgroups, limited
@@ -546,8 +550,8 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
             return ML_OK;
         }
         const int tiles128 = (p.M_pad / 128) * (p.N / mlk::MID_TN);
-        // 128-row tiles once they cover the CUs -- with the LDS-DMA loader (one 96 KiB workgroup per CU) already from three quarters of
-        // them (3072 rows: 188 vs 199 us per forward; 2048 rows, half of them: 181 vs 134)
+        // 128-row tiles once they cover the CUs -- with the LDS-DMA loader (one 96 KiB workgroup per CU) as soon as the 64-row tiles would
+        // need a second wave (2304 rows: 183 vs 198 us per forward; 2048 rows, 256 64-row tiles: 139 vs 181)
         const int tm = mid_tile_rows(tu, precision, tiles128);
         const int tiles = (p.M_pad / tm) * (p.N / mlk::MID_TN);
         // round 6, split-K: k ranges per output tile so that the launch reaches tu.mid_wgs workgroups (two per CU) -- 1, 2 or 4, each at

@@ -155,9 +155,10 @@ def test_route_query_follows_the_tuning(hip_lib, cuda_device):
     from monoloco_amd import engine
     sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(1, 34, 9, 1024).items()}
     eng = engine.LocoEngine(sd, device=cuda_device)
-    got = [eng.route_for_rows(r) for r in (16, 128, 129, 256, 257, 512, 513, 2048, 3072, 4096, 4097, 6144, 8192, 8193, 65536)]
-    # (round 6, hidden 1024: the small-row kernels hand over at 256 rows, the 128-row tiles start at three quarters of the CUs = 3072 rows)
-    assert got == ['small16', 'small16', 'small32', 'small32', 'mid64', 'mid64', 'mid64', 'mid64', 'mid128', 'mid128', 'half', 'half', 'half',
+    got = [eng.route_for_rows(r) for r in (16, 128, 129, 256, 257, 512, 513, 2048, 2304, 3072, 4096, 4097, 6144, 8192, 8193, 65536)]
+    # (round 6, hidden 1024: the small-row kernels hand over at 256 rows, the 128-row tiles start where the 64-row tiles would need a second
+    #  wave on the CUs = above 2048 rows)
+    assert got == ['small16', 'small16', 'small32', 'small32', 'mid64', 'mid64', 'mid64', 'mid64', 'mid128', 'mid128', 'mid128', 'half', 'half', 'half',
                    'tile', 'tile']
     narrow = engine.LocoEngine({k: torch.tensor(v) for k, v in synth.make_state_dict(1, 34, 9, 256).items()}, device=cuda_device)
     assert narrow.route_for_rows(512) == 'small32' and narrow.route_for_rows(513) == 'mid64'   # narrower models keep the 512-row hand-over

@@ -170,7 +170,7 @@ def test_mid_fused_heads_match_the_pair_kernel(hip_lib, cuda_device, m, mode):
     rng = np.random.default_rng(m + 1)
     x = torch.tensor((rng.standard_normal((m, in_f)) * 3).astype(np.float32), device=cuda_device)
     eng = engine.LocoEngine(sd, device=cuda_device)
-    fam = 'half' if m > 4096 else ('mid128' if m == 4096 else 'mid64')
+    fam = 'half' if m > 4096 else ('mid128' if m > 2048 else 'mid64')
     assert eng.plan_for_rows(m, with_post=False).endswith("L6 %s+aux; L7 %s+fin%d; end=reduce" % (fam, fam, out_f - 1))
     raw_fused = eng.forward_raw(x).cpu()
     eng.set_option('mid_heads', 0)
