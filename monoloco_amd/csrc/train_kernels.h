@@ -360,6 +360,10 @@ __device__ __forceinline__ void bwd_elem(float dout, float z, float mean, float 
     dy = g;
 }
 
+// rows a thread of the two backward passes requests per trip of its row loop (-DBWD_ROWS=<n> for the A/B, tools/lib_ab_train.py)
+#ifndef BWD_ROWS
+#define BWD_ROWS 2
+#endif
 // pass 1: s1[j] += sum_i dy[i][j], s2[j] += sum_i dy[i][j] * xhat[i][j]   (nothing written but the sums); n % 4 == 0
 __global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict__ dout, const float* __restrict__ z, int64_t m,
                                                        int n, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -376,9 +380,7 @@ __global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict_
     if (j0 + 3 < n) {
         const f32x4 mu = *(const f32x4*)(mean + j0), is = *(const f32x4*)(invstd + j0);
         const f32x4 ga = *(const f32x4*)(gamma + j0), be = *(const f32x4*)(beta + j0);
-        for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += step) {
-            const f32x4 d = *(const f32x4*)(dout + i * n + j0);
-            const f32x4 zz = *(const f32x4*)(z + i * n + j0);
+        auto one = [&](const f32x4& d, const f32x4& zz, int64_t i) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float dy, xh;
@@ -388,7 +390,20 @@ __global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict_
                 mdy[e] = __builtin_fmaxf(mdy[e], __builtin_fabsf(dy));
                 mxh[e] = __builtin_fmaxf(mxh[e], __builtin_fabsf(xh));
             }
+        };
+        // BWD_ROWS rows per trip, all their loads requested before the first use (same rows in the same order: the same sums)
+        int64_t i = (int64_t)blockIdx.y * 16 + rg;
+        for (; i + (BWD_ROWS - 1) * step < m; i += BWD_ROWS * step) {
+            f32x4 dd[BWD_ROWS], zv[BWD_ROWS];
+#pragma unroll
+            for (int u = 0; u < BWD_ROWS; ++u) {
+                dd[u] = *(const f32x4*)(dout + (i + u * step) * n + j0);
+                zv[u] = *(const f32x4*)(z + (i + u * step) * n + j0);
+            }
+#pragma unroll
+            for (int u = 0; u < BWD_ROWS; ++u) one(dd[u], zv[u], i + u * step);
         }
+        for (; i < m; i += step) one(*(const f32x4*)(dout + i * n + j0), *(const f32x4*)(z + i * n + j0), i);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -747,9 +762,7 @@ __global__ __launch_bounds__(256) void bn_bwd_lines_kernel(const float* din, con
         }
         const bool odd = cg & 1;
         const int g8 = j0 >> 3;   // 8-column group of the row: the even lane stores its hi halves, the odd lane its lo halves
-        for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += step) {
-            const f32x4 d = *(const f32x4*)(din + i * n + j0);
-            const f32x4 zz = *(const f32x4*)(z + i * n + j0);
+        auto one = [&](const f32x4& d, const f32x4& zz, int64_t i) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -772,7 +785,20 @@ __global__ __launch_bounds__(256) void bn_bwd_lines_kernel(const float* din, con
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             const u4 out = odd ? u4{s0, s1, lo2[0], lo2[1]} : u4{hi2[0], hi2[1], s0, s1};
             *(u4*)(lines + i * (int64_t)n * 4 + (g8 >> 2) * 128 + (g8 & 3) * 16 + (odd ? 64 : 0)) = out;
+        };
+        // BWD_ROWS rows per trip, all their loads requested before the first use (bwd_stats_kernel's form: same rows, same order, same sums)
+        int64_t i = (int64_t)blockIdx.y * 16 + rg;
+        for (; i + (BWD_ROWS - 1) * step < m; i += BWD_ROWS * step) {
+            f32x4 dd[BWD_ROWS], zv[BWD_ROWS];
+#pragma unroll
+            for (int u = 0; u < BWD_ROWS; ++u) {
+                dd[u] = *(const f32x4*)(din + (i + u * step) * n + j0);
+                zv[u] = *(const f32x4*)(z + (i + u * step) * n + j0);
+            }
+#pragma unroll
+            for (int u = 0; u < BWD_ROWS; ++u) one(dd[u], zv[u], i + u * step);
         }
+        for (; i < m; i += step) one(*(const f32x4*)(din + i * n + j0), *(const f32x4*)(z + i * n + j0), i);
         if (blockIdx.y == 0 && rg == 0) {  // one thread per column publishes the parameter gradients
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
