@@ -123,9 +123,12 @@ def test_host_matching_cost(hip_lib, host_only):
     for m, bound in ((16, 2e-3), (2048, 0.5)):
         boxes, gt = synth.make_boxes(m, m, 5)
         I.get_iou_matches_ordered(boxes, gt)
-        t0 = time.perf_counter()
-        I.get_iou_matches_ordered(boxes, gt)
-        assert time.perf_counter() - t0 < bound
+        times = []
+        for _ in range(3):   # (the best of three: a loaded host must not fail a cost bound that is 10 x off either way)
+            t0 = time.perf_counter()
+            I.get_iou_matches_ordered(boxes, gt)
+            times.append(time.perf_counter() - t0)
+        assert min(times) < bound, times
 
 
 def test_matching_property_random_boxes_with_many_ties(hip_lib, host_only):

@@ -2,6 +2,8 @@
 //   mode 0: global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave-instruction)
 //   mode 1: global_load_dwordx4 -> VGPR -> ds_write_b128
 //   mode 2: global_load_dwordx4 -> VGPR only (sink into an xor so the loads are not dead)
+//   mode 3 (round 6): waves 0-3 as mode 0, waves 4-7 as mode 1 at the same time -- are the two paths separate resources?
+//   mode 4: waves 0-5 as mode 0, waves 6-7 as mode 1 (the byte split of a 128 x 64 tile: W rows by DMA, X rows through registers)
 // grid = #CUs workgroups of 512 threads (8 waves), 128 KiB of LDS so that one workgroup sits on a CU.
 // Every workgroup walks a private 1 MiB window of a 256 MiB buffer?  No: to stay L2 resident all workgroups
 // of an XCD walk the SAME 2 MiB region (like the weight/X panel re-use of the dense kernel).
@@ -32,16 +34,17 @@ __global__ __launch_bounds__(512) void feed(const char* __restrict__ buf, size_t
         for (int j = 0; j < 8; ++j) {
             if (j >= per_iter) break;
             const size_t o = (off + (size_t)j * 1024) % region;
-            if (MODE == 0) {
+            const bool dma = MODE == 0 || (MODE == 3 && w < 4) || (MODE == 4 && w < 6);
+            if (dma) {
                 glds16(base + o + lane * 16, dst + j * 1024);
             } else {
                 const f32x4 v = *(const f32x4*)(base + o + lane * 16);
-                if (MODE == 1) *(f32x4*)(dst + j * 1024 + lane * 16) = v;
+                if (MODE == 1 || MODE >= 3) *(f32x4*)(dst + j * 1024 + lane * 16) = v;
                 else acc += v;
             }
         }
         off += (size_t)8 * 1024 * per_iter;
-        if (MODE == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (MODE == 0 || (MODE == 3 && w < 4) || (MODE == 4 && w < 6)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -62,13 +65,15 @@ int main(int argc, char** argv) {
     float* sink; CHECK(hipMalloc(&sink, 4096));
     unsigned long long* cyc; CHECK(hipMalloc(&cyc, cus * 8));
     const int iters = 2000;
-    for (int per_iter : {4, 8}) for (int mode = 0; mode < 3; ++mode) {
+    for (int per_iter : {4, 8}) for (int mode = 0; mode < 5; ++mode) {
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         for (int rep = 0; rep < 2; ++rep) {
             CHECK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(feed<0>, dim3(cus), dim3(512), 0, 0, buf, region, iters, per_iter, sink, cyc);
             if (mode == 1) hipLaunchKernelGGL(feed<1>, dim3(cus), dim3(512), 0, 0, buf, region, iters, per_iter, sink, cyc);
             if (mode == 2) hipLaunchKernelGGL(feed<2>, dim3(cus), dim3(512), 0, 0, buf, region, iters, per_iter, sink, cyc);
+            if (mode == 3) hipLaunchKernelGGL(feed<3>, dim3(cus), dim3(512), 0, 0, buf, region, iters, per_iter, sink, cyc);
+            if (mode == 4) hipLaunchKernelGGL(feed<4>, dim3(cus), dim3(512), 0, 0, buf, region, iters, per_iter, sink, cyc);
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         }
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
