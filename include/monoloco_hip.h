@@ -280,7 +280,8 @@ int ml_trainer_step(ml_trainer* t, const float* x_dev, const float* labels_dev, 
  * LocoModel.forward in train mode (architectures.py:48-71) -> raw_out_dev (m, out_features), running BatchNorm statistics updated,
  * fresh dropout masks per call; ml_trainer_backward = backward from dout_dev (m, out_features), the gradient of the caller's loss with
  * respect to those outputs -> every parameter gradient, UNCLIPPED, through ml_trainer_get_grad.  x_dev must stay valid and unchanged
- * between the two calls; exactly one backward per forward (ML_ERR_STATE otherwise); the gradient with respect to x is not computed.
+ * between the two calls; exactly one backward per forward, and no ml_trainer_step / ml_trainer_eval in between -- they run through the
+ * same workspace and cancel the pending forward (ML_ERR_STATE from the backward); the gradient with respect to x is not computed.
  * Exact-fp32 route below fast_rows rows, the large-batch route from there on.  ml_trainer_backward synchronises the stream.
  * monoloco_amd.network.architectures.LocoModel routes its train-mode forward through these (torch.autograd.Function). */
 int ml_trainer_forward_train(ml_trainer* t, const float* x_dev, int64_t m, float* raw_out_dev, void* stream);

@@ -1189,6 +1189,7 @@ int ml_trainer_eval(ml_trainer* t, const float* x_dev, const float* labels_dev, 
     // the column-owner kernels at the row counts they were built for; the chunk means are combined weighted by their rows
     const int64_t CH = 8192;
     hipStream_t st = (hipStream_t)stream;
+    t->fwd_pending_rows = 0;   // (the evaluation runs through the workspace a pending ml_trainer_forward_train left its activations in)
     double acc[mlt::LOSS_NV];
     for (int q = 0; q < mlt::LOSS_NV; ++q) acc[q] = 0.0;
     int rc;

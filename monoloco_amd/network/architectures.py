@@ -86,6 +86,7 @@ class _TrainForward(torch.autograd.Function):
         tr = module._hip_trainer(x.device if x.is_cuda else None)
         ctx.tr, ctx.keys, ctx.home = tr, [k for k, _ in module.named_parameters()], [p_.device for p_ in params]
         out = tr.forward_train(x.detach())
+        ctx.seq = tr.forward_seq
         # BatchNorm's running statistics moved inside the library: bring them back into the module's buffers
         with torch.no_grad():
             stats = tr.stats_flat()            # (one stream-ordered device-to-device copy)
@@ -99,6 +100,12 @@ class _TrainForward(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        if ctx.seq != ctx.tr.forward_seq:
+            # the library keeps ONE forward's activations (the reference's autograd keeps one graph per call): a second train-mode
+            # forward of the module has overwritten what this backward needs -- say so instead of differentiating the wrong batch
+            raise RuntimeError("LocoModel (train mode): another train-mode forward ran before this backward; the HIP trainer keeps the "
+                               "activations of the last forward only -- call backward() before the next forward, or use eval mode / "
+                               "torch.no_grad() for forwards that are not differentiated")
         ctx.tr.backward(grad_out.contiguous())
         g = ctx.tr.grads_flat()        # ONE device-to-device copy: the 34 MB of gradients never visit the host
         return (None, None) + tuple(g[k].to(dev_) for k, dev_ in zip(ctx.keys, ctx.home))

@@ -222,6 +222,7 @@ class HipTrainer:
             check(_lib.load().ml_trainer_forward_train(self._h, _ptr(x), int(x.shape[0]), _ptr(raw), _stream(dev)), train=True)
         self.version += 1          # (the running statistics moved)
         self._pending_x = x
+        self.forward_seq = getattr(self, 'forward_seq', 0) + 1   # (which forward the workspace holds: _TrainForward checks it)
         return raw
 
     def backward(self, grad_outputs):

@@ -117,3 +117,26 @@ def test_a_caller_owned_training_loop_learns(hip_lib, cuda_device):
     xr = xd.clone().requires_grad_(True)
     with pytest.raises(NotImplementedError, match="inputs"):
         model(xr)
+
+
+def test_a_backward_behind_a_second_forward_is_refused(hip_lib, cuda_device):
+    """The library keeps ONE train-mode forward's activations: a backward whose forward has been overwritten by another train-mode
+    forward of the module must say so (torch's autograd would differentiate the right batch; differentiating the wrong one silently is
+    the failure to exclude), and the later forward's own backward still works."""
+    from oracle.train_oracle import multitask_loss
+    x, y = _batch('mono')
+    sd = {k: torch.tensor(v) for k, v in synth.make_state_dict(19, 34, 9, 256).items()}
+    model = _module(sd, 34, 9, 256, 0.0, cuda_device).train()
+    xd, yd = x.to(cuda_device), y.to(cuda_device)
+    out1 = model(xd)
+    out2 = model(xd * 1.01)
+    with pytest.raises(RuntimeError, match="another train-mode forward"):
+        multitask_loss(out1, yd)[0].backward()
+    multitask_loss(out2, yd)[0].backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    # the plain C entry points refuse a backward without its forward, and one behind an evaluation through the same workspace
+    tr = model._hip_trainer(cuda_device)
+    out3 = tr.forward_train(xd)
+    tr.evaluate_batch(xd, yd)
+    with pytest.raises(Exception, match="pending"):
+        tr.backward(torch.ones_like(out3))
