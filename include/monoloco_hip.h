@@ -345,7 +345,11 @@ int ml_trainer_restore(ml_trainer* t, void* stream);
  * weight-gradient GEMM dW = dz^T . x reads dz and x reduction-major, as the [batch][hidden] lines they already exist as
  * (gfx950's transposing LDS read feeds the MFMA), and dz / a stage's inner activation / the residual stream exist as lines only;
  * 0 = through transposed copies of both operands with the fp32 chain of rounds 2-3 (2.2 ms more per 65536-row step); 2 = the
- * reduction-major GEMM on that same fp32 chain (same bits as 0: the test's reference); < 0 leaves it. */
+ * reduction-major GEMM on that same fp32 chain (same bits as 0: the test's reference); < 0 leaves it.  Round 6: with layout 1 the pair
+ * w2 -> w3 (reference architectures.py:60-66, nothing non-linear between them) runs as ONE Linear -- z3 = a (W3 W2)^T + (W3 b2 + b3),
+ * aux = a (W2^T w_aux) + (w_aux . b2 + b_aux); dW3 = (dz3^T a) W2^T + s3 (x) b2, dW2 = W3^T (dz3^T a) + w_aux (x) (daux^T a),
+ * da = dz3 (W3 W2) + daux (x) (W2^T w_aux): three batch-sized GEMMs instead of six, y2 and its gradient never exist; the H x H
+ * products of weights on the exact-fp32 GEMM -- 3 = layout 1 with the two Linears apart (rounds 4-5; the A/B reference). */
 int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream, int dw_layout);
 int ml_trainer_destroy(ml_trainer* t);
 const char* ml_train_last_error(void);

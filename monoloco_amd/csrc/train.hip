@@ -86,6 +86,7 @@ struct ml_trainer {
     std::vector<float*> wbs;                          // bias * 2^e
     std::vector<char*> wlT;                           // ... and of W^T (data gradient); all images of a step are packed up front
     mlt::WLayer* d_wdesc = nullptr;                   // device table of the 2S + 2 Linears for wmax_multi / wpack_multi
+    mlt::WLayer* d_wdesc_m = nullptr;                 // ... with w2 and w3 replaced by their product (2S + 1 entries; the merged pair)
     bool packed_all = false;
     mlt::ColSumItems csf;                             // deferred fp64 column sums -> fp32 gradient vectors (flushed before the optimizer)
     bool csf_defer = false;                          // this step's images are already packed (pack_all_weights)
@@ -94,6 +95,10 @@ struct ml_trainer {
     int64_t capT = 0;
     int ks = 1;                                       // split of the batch reduction of the fast weight-gradient GEMM
     float* zero_bias = nullptr;                       // H zeros (the data-gradient GEMMs have no bias)
+    // round 6, large-batch route: w2 -> w3 as ONE Linear (train_kernels.h "w2 -> w3 pair"): W3 W2 and W3 b2 + b3 (packed as Linear slot
+    // 2S + 2), u = W2^T w_aux, c = w_aux . b2 + b_aux, v = daux^T a_S, and the H x H scratch the weight gradients go through
+    int merge23 = 1;
+    float *d_w32 = nullptr, *d_b32 = nullptr, *d_u23 = nullptr, *d_c23 = nullptr, *d_v23 = nullptr, *d_m23 = nullptr;
     int n_cu = 256;
     // AutoTuneMultiTaskLoss (reference losses.py:17-43, trainer.py:95-96): one learnable log_sigma per task, optimised by
     // the same Adam (same lr schedule, NOT clipped: clip_grad_norm_ sees model.parameters() only), not part of the
@@ -599,11 +604,17 @@ int ensure_cap(ml_trainer* t, int64_t m) {
             int dev = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                 t->n_cu = prop.multiProcessorCount;
-            T_TRY(hipMalloc((void**)&t->wsc_base, (size_t)(2 * t->S + 2) * 32));
-            T_TRY(hipMalloc((void**)&t->d_colmax, (size_t)(2 * t->S + 2) * 2 * t->H * sizeof(float)));
+            T_TRY(hipMalloc((void**)&t->wsc_base, (size_t)(2 * t->S + 3) * 32));
+            T_TRY(hipMalloc((void**)&t->d_colmax, (size_t)(2 * t->S + 3) * 2 * t->H * sizeof(float)));
+            T_TRY(hipMalloc((void**)&t->d_w32, (size_t)t->H * t->H * 4));
+            T_TRY(hipMalloc((void**)&t->d_m23, (size_t)t->H * t->H * 4));
+            T_TRY(hipMalloc((void**)&t->d_b32, (size_t)t->H * 4));
+            T_TRY(hipMalloc((void**)&t->d_u23, (size_t)t->H * 4));
+            T_TRY(hipMalloc((void**)&t->d_v23, (size_t)t->H * 4));
+            T_TRY(hipMalloc((void**)&t->d_c23, 64));
             T_TRY(hipMalloc((void**)&t->zero_bias, (size_t)t->H * 4));
             T_TRY(hipMemset(t->zero_bias, 0, (size_t)t->H * 4));
-            for (int i = 0; i < 2 * t->S + 2; ++i) {
+            for (int i = 0; i < 2 * t->S + 3; ++i) {   // (slot 2S + 2: the merged w3 . w2)
                 char* w = nullptr;
                 float* b = nullptr;
                 T_TRY(hipMalloc((void**)&w, (size_t)t->H * t->H * 4));
@@ -628,8 +639,18 @@ int ensure_cap(ml_trainer* t, int64_t m) {
                 }
                 add("w2", 2 * t->S);
                 add("w3", 2 * t->S + 1);
+                {
+                    const int slot = 2 * t->S + 2;
+                    mlt::WLayer l;
+                    l.w = t->d_w32; l.bias = t->d_b32; l.sc = t->wsc_base + 8 * slot;
+                    l.lines = t->wl[slot]; l.linesT = t->wlT[slot]; l.bias_scaled = t->wbs[slot];
+                    desc.push_back(l);
+                }
                 T_TRY(hipMalloc((void**)&t->d_wdesc, desc.size() * sizeof(mlt::WLayer)));
                 T_TRY(hipMemcpy(t->d_wdesc, desc.data(), desc.size() * sizeof(mlt::WLayer), hipMemcpyHostToDevice));
+                desc.erase(desc.begin() + 2 * t->S, desc.begin() + 2 * t->S + 2);   // (w2, w3 themselves are not multiplied with anything batch-sized)
+                T_TRY(hipMalloc((void**)&t->d_wdesc_m, desc.size() * sizeof(mlt::WLayer)));
+                T_TRY(hipMemcpy(t->d_wdesc_m, desc.data(), desc.size() * sizeof(mlt::WLayer), hipMemcpyHostToDevice));
             }
         }
     }
@@ -1073,12 +1094,13 @@ int ml_trainer_destroy(ml_trainer* t) {
     for (char* p : t->wl) (void)hipFree(p);
     for (char* p : t->wlT) (void)hipFree(p);
     if (t->d_wdesc) (void)hipFree(t->d_wdesc);
+    if (t->d_wdesc_m) (void)hipFree(t->d_wdesc_m);
     for (float* p : t->wbs) (void)hipFree(p);
     if (t->h_loss) (void)hipHostFree(t->h_loss);
     for (hipEvent_t e : t->ev_dz) (void)hipEventDestroy(e);
     for (hipEvent_t e : t->ev_w) (void)hipEventDestroy(e);
     if (t->st2) (void)hipStreamDestroy(t->st2);
-    void* ptrs[] = {t->w_snap, t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->dzl, t->d_colpart, t->d_colmax, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk};
+    void* ptrs[] = {t->w_snap, t->d_lpart, t->d_ssq, t->d_gn, t->d_tw, t->tl_dz, t->tl_x, t->dzl, t->d_colpart, t->d_colmax, t->wsc_base, t->zero_bias, t->w, t->g, t->m1, t->m2, t->stat, t->d_out, t->d_dout, t->bn_mean, t->bn_invstd, t->d_red_base, t->d_splitk, t->d_w32, t->d_b32, t->d_u23, t->d_c23, t->d_v23, t->d_m23};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete t;
@@ -1287,7 +1309,8 @@ int ml_trainer_set_tuning(ml_trainer* t, int apply_cols, int side_stream, int dw
     if (apply_cols) t->apply_cols = apply_cols;
     if (dw_layout >= 0) {   // large-batch route: 0 transposed operand copies (round 2); 1 reduction-major operands + lines-only chain
         t->dw_trans = dw_layout ? 1 : 0;   // (default); 2 reduction-major operands, fp32 chain as with 0
-        t->lines_chain = dw_layout == 1 ? 1 : 0;
+        t->lines_chain = (dw_layout == 1 || dw_layout == 3) ? 1 : 0;
+        t->merge23 = dw_layout == 3 ? 0 : 1;   // 3: layout 1 with w2 and w3 as two Linears (rounds 4-5: the A/B reference of round 6's merged pair)
     }
     if (side_stream >= 0) {   // 0: both gradients of a Linear in one launch (default); 1: weight gradients on the side stream; 2: two launches
         t->side_stream = side_stream == 1 ? 1 : 0;
@@ -1361,14 +1384,27 @@ int step_phases(ml_trainer* t, const float* x_dev, const float* labels_dev, int 
     // Linear `slot`s: 2s = stage s w1, 2s + 1 = stage s w2, 2S = w2, 2S + 1 = w3
     const bool fast = route == 1;
     if (phases & PH_FWD) t->packed_all = false;
+    // w2 -> w3 as one Linear (train_kernels.h): where every consumer of the residual stream reads lines and the heads run on the skinny kernels
+    const bool merged = fast && t->merge23 && t->dw_trans && t->lines_chain && skinny_ok(t, C - 1) && H % 512 == 0 && H <= 4096 && t->d_w32;
     if (fast && (phases & PH_FWD)) {
-        T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 2) * 32, st));
-        T_TRY(hipMemsetAsync(t->d_colmax, 0, (size_t)(2 * S + 2) * 2 * H * sizeof(float), st));
+        T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 3) * 32, st));
+        T_TRY(hipMemsetAsync(t->d_colmax, 0, (size_t)(2 * S + 3) * 2 * H * sizeof(float), st));
+        if (merged) {   // W3 W2 (exact-fp32 MFMA GEMM of the mid route), W3 b2 + b3, u = W2^T w_aux, c = w_aux . b2 + b_aux
+            if ((rc = launch_xgemm(st, P(t, "w3.weight"), H, 0, P(t, "w2.weight"), H, 1, t->d_w32, H, H, H, H, nullptr, nullptr, nullptr)))
+                return rc;
+            hipLaunchKernelGGL(mlt::gemv_rows_kernel, dim3(H / 4), dim3(256), 0, st, (const float*)P(t, "w3.weight"), H, H, H,
+                               (const float*)P(t, "w2.bias"), (const float*)P(t, "w3.bias"), (const float*)nullptr, t->d_b32);
+            hipLaunchKernelGGL(mlt::gemv_cols_kernel, dim3(H / 16), dim3(256), 0, st, (const float*)P(t, "w2.weight"), H, H, H,
+                               (const float*)P(t, "w_aux.weight"), (const float*)nullptr, (const float*)nullptr, t->d_u23);
+            hipLaunchKernelGGL(mlt::gemv_rows_kernel, dim3(1), dim3(256), 0, st, (const float*)P(t, "w_aux.weight"), H, 1, H,
+                               (const float*)P(t, "w2.bias"), (const float*)P(t, "w_aux.bias"), (const float*)nullptr, t->d_c23);
+        }
         // every weight image of the step -- W for the forward GEMMs, W^T for the data-gradient GEMMs -- in two launches up front
         // (the weights only change in the optimizer at the end of a step)
-        hipLaunchKernelGGL(mlt::wmax_multi_kernel, dim3(64, 2 * S + 2), dim3(256), 0, st, (const mlt::WLayer*)t->d_wdesc, (int64_t)H * H);
-        hipLaunchKernelGGL(mlt::wpack_multi_kernel, dim3(nblk((int64_t)H * H / 8), 2 * S + 2, 2), dim3(256), 0, st,
-                           (const mlt::WLayer*)t->d_wdesc, H);
+        const int nslots = merged ? 2 * S + 1 : 2 * S + 2;
+        const mlt::WLayer* wdesc = merged ? t->d_wdesc_m : t->d_wdesc;
+        hipLaunchKernelGGL(mlt::wmax_multi_kernel, dim3(64, nslots), dim3(256), 0, st, wdesc, (int64_t)H * H);
+        hipLaunchKernelGGL(mlt::wpack_multi_kernel, dim3(nblk((int64_t)H * H / 8), nslots, 2), dim3(256), 0, st, wdesc, H);
         t->packed_all = true;
         if (t->pad_m != m) {
             // the weight-gradient GEMMs reduce over whole 64-row k-steps per split: rows m .. mT of every line buffer must be
@@ -1406,7 +1442,20 @@ int step_phases(ml_trainer* t, const float* x_dev, const float* labels_dev, int 
     Block b3;
     b3.lin = "w3"; b3.bn = "batch_norm3"; b3.bn_idx = 2 * S + 1; b3.in_dim = H; b3.x = y2; b3.x_lines = ly2; b3.z = z3; b3.y = y3;
     b3.site = 2 * S + 1;
-    if (fwd) {
+    if (merged) {   // z3 = a_S (W3 W2)^T + (W3 b2 + b3): y2 is never formed
+        b3.x = nullptr;
+        b3.x_lines = la(S);
+    }
+    if (fwd && merged) {
+        int64_t ga = (m + 7) / 8;
+        if (ga > 2048) ga = 2048;
+        hipLaunchKernelGGL(mlt::aux_lines_kernel, dim3((unsigned)ga), dim3(256), 0, st, (const char*)la(S), m, H, (const float*)t->d_u23,
+                           (const float*)t->d_c23, t->d_out + (C - 1), C);
+        if ((rc = block_fwd(t, st, b3, m, nullptr, la(S), nullptr, 2 * S + 2))) return rc;
+        if (!skinny_heads(t, st, y3, m, P(t, "w_fin.weight"), P(t, "w_fin.bias"), C - 1, t->d_out, C))
+            if ((rc = linear_fwd(t, st, y3, H, P(t, "w_fin.weight"), P(t, "w_fin.bias"), t->d_out, C, (int)m, C - 1, H))) return rc;
+        if (raw_out_dev) T_TRY(hipMemcpyAsync(raw_out_dev, t->d_out, (size_t)m * C * 4, hipMemcpyDeviceToDevice, st));
+    } else if (fwd) {
         if (fast) {
             if ((rc = fast_linear_fwd(t, st, la(S), "w2", y2, m, 2 * S))) return rc;
             hipLaunchKernelGGL(mlt::act_lines_kernel, dim3(nblk(m * H / 8)), dim3(256), 0, st, (const float*)y2, m, H, ly2);
@@ -1452,6 +1501,42 @@ int step_phases(ml_trainer* t, const float* x_dev, const float* labels_dev, int 
     // fast path: the H x H data and weight gradients run on the 3-product kernel as well; dz goes there as scaled lines
     // (t->dzl; the forward's line buffers stay: they are the weight-gradient GEMMs' second operand), see block_bwd
     char* dzl = fast ? t->dzl : nullptr;
+    // what the merged pair still owes behind the deferred column sums (s3 = sum dz3 -> w3.bias, sum daux -> w_aux.bias): the weight
+    // gradients from M = dz3^T a_S (left in w3.weight's gradient slot by block_bwd), and the vectors
+    auto merged_tail = [&]() -> int {
+        if (!merged) return 0;
+        int r2;
+        T_TRY(hipMemcpyAsync(t->d_m23, G(t, "w3.weight"), (size_t)H * H * 4, hipMemcpyDeviceToDevice, st));
+        // dW3 = M W2^T + s3 (x) b2
+        if ((r2 = launch_xgemm(st, t->d_m23, H, 0, P(t, "w2.weight"), H, 0, G(t, "w3.weight"), H, H, H, H, nullptr, nullptr, nullptr))) return r2;
+        hipLaunchKernelGGL(mlt::rank1_add_kernel, dim3(nblk((int64_t)H * H)), dim3(256), 0, st, G(t, "w3.weight"), H, H, H,
+                           (const float*)G(t, "w3.bias"), (const float*)P(t, "w2.bias"));
+        // dW2 = W3^T M + w_aux (x) v
+        if ((r2 = launch_xgemm(st, P(t, "w3.weight"), H, 1, t->d_m23, H, 1, G(t, "w2.weight"), H, H, H, H, nullptr, nullptr, nullptr))) return r2;
+        hipLaunchKernelGGL(mlt::rank1_add_kernel, dim3(nblk((int64_t)H * H)), dim3(256), 0, st, G(t, "w2.weight"), H, H, H,
+                           (const float*)P(t, "w_aux.weight"), (const float*)t->d_v23);
+        // db2 = W3^T s3 + w_aux sum(daux);  dw_aux = W2 v + b2 sum(daux)
+        hipLaunchKernelGGL(mlt::gemv_cols_kernel, dim3(H / 16), dim3(256), 0, st, (const float*)P(t, "w3.weight"), H, H, H,
+                           (const float*)G(t, "w3.bias"), (const float*)P(t, "w_aux.weight"), (const float*)G(t, "w_aux.bias"),
+                           G(t, "w2.bias"));
+        hipLaunchKernelGGL(mlt::gemv_rows_kernel, dim3(H / 4), dim3(256), 0, st, (const float*)P(t, "w2.weight"), H, H, H,
+                           (const float*)t->d_v23, (const float*)P(t, "w2.bias"), (const float*)G(t, "w_aux.bias"), G(t, "w_aux.weight"));
+        if (hipGetLastError() != hipSuccess) return tfail(ML_ERR_HIP, "merged w2 / w3 gradient launches failed");
+        return 0;
+    };
+    if (merged) {
+        if ((rc = block_bwd(t, st, b3, m, gA, xhat, 2 * S + 2))) return rc;            // dz3 as lines; M = dz3^T a_S in w3.weight's gradient slot
+        if ((rc = fast_linear_bwd_data(t, st, dzl, "w3", gA, m, 2 * S + 2, false))) return rc;   // gA = dz3 (W3 W2)
+        {   // v = daux^T a_S, then gA += daux (x) u: gA = d a_S
+            int64_t gy = (m + 15) / 16;
+            if (gy > 64) gy = 64;
+            while (gy > 1 && (size_t)gy * H > t->splitk_cap) gy /= 2;
+            hipLaunchKernelGGL(mlt::dvec_lines_kernel, dim3(H / 128, (unsigned)gy), dim3(256), 0, st, (const float*)(t->d_dout + (C - 1)), C,
+                               (const char*)la(S), m, H, t->d_splitk);
+            hipLaunchKernelGGL(mlt::skinny_reduce_kernel, dim3(nblk(H)), dim3(256), 0, st, (const float*)t->d_splitk, (int)gy, 1, H, t->d_v23, 0);
+            if ((rc = skinny_out(t, st, t->d_dout + (C - 1), C, 1, t->d_u23, H, 1, nullptr, gA, m, 1))) return rc;
+        }
+    } else {
     if ((rc = block_bwd(t, st, b3, m, gA, xhat, fast ? 2 * S + 1 : -1))) return rc;                              // gA = dz3
     if (fast) rc = fast_linear_bwd_data(t, st, dzl, "w3", gB, m, 2 * S + 1, false);
     else rc = linear_bwd_data(t, st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0);                          // gB = dy2
@@ -1477,6 +1562,7 @@ int step_phases(ml_trainer* t, const float* x_dev, const float* labels_dev, int 
         rc = linear_bwd_data(t, st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0);                            // gA = da_S
     }
     if (rc) return rc;
+    }   // (!merged)
     // residual stages, last to first:  a_{s+1} = a_s + B(A(a_s))
     for (int s = S - 1; s >= 0; --s) {
         // gB = dz_b from gA = d a_{s+1} (which stays: the skip connection adds to it below)
@@ -1497,6 +1583,7 @@ int step_phases(ml_trainer* t, const float* x_dev, const float* labels_dev, int 
     if (!(phases & PH_OPT)) {   // the caller clips and steps its own optimizer: the raw gradients stay in t->g
         flush_col_sums(t, st);
         t->csf_defer = false;
+        if ((rc = merged_tail())) return rc;
         T_TRY(hipStreamSynchronize(st));
         return ML_OK;
     }
@@ -1508,6 +1595,7 @@ int step_phases(ml_trainer* t, const float* x_dev, const float* labels_dev, int 
         double* d_ss = t->d_red + 2 * H + 16;  // pre-zeroed, never shared with d_loss (other offset)
         flush_col_sums(t, st);
         t->csf_defer = false;
+        if ((rc = merged_tail())) return rc;
         hipLaunchKernelGGL(mlt::sumsq_kernel, dim3(512), dim3(256), 0, st, (const float*)t->g, t->n_param, d_ss);
         hipLaunchKernelGGL(mlt::clip_adam_kernel, dim3(nblk(t->n_param)), dim3(256), 0, st, t->w, t->g, t->m1, t->m2, t->n_param,
                            (const double*)d_ss, 3.0f, lr, 0.9f, 0.999f, 1e-8f, bc1, bc2, update ? 1 : 0);

@@ -1196,6 +1196,125 @@ __global__ __launch_bounds__(256) void skinny_heads_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 6, the large-batch route's w2 -> w3 pair as ONE Linear (reference architectures.py:60-66: y = w2(y); aux = w_aux(y); y = w3(y) --
+// nothing non-linear between the two): z3 = a (W3 W2)^T + (W3 b2 + b3) and aux = a (W2^T w_aux) + (w_aux . b2 + b_aux), so the forward
+// needs one batch-sized GEMM where it ran two, and the backward -- dW3 = (dz3^T a) W2^T + s3 (x) b2, dW2 = W3^T (dz3^T a) + w_aux (x) v,
+// da = dz3 (W3 W2) + daux (x) u with v = daux^T a, u = W2^T w_aux, s3 = sum dz3 -- two where it ran four; y2 and its gradient never
+// exist.  The H x H products of weights run on the exact-fp32 GEMM of the mid route (xgemm_kernel); these are the vector pieces.
+
+// y[i] = sum_k A[i * lda + k] x[k] + add[i] * (scale ? *scale : 1)      (a wave per row)
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ A, int lda, int rows, int cols, const float* __restrict__ x,
+                                                       const float* __restrict__ add, const float* __restrict__ scale,
+                                                       float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= rows) return;
+    float a = 0.f;
+    for (int k = lane; k < cols; k += 64) a = __builtin_fmaf(A[(int64_t)i * lda + k], x[k], a);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) y[i] = a + (add ? add[i] * (scale ? *scale : 1.0f) : 0.0f);
+}
+// y[k] = sum_i A[i * lda + k] x[i] + add[k] * (scale ? *scale : 1)      (a workgroup per 16 columns: 16 row groups x 16 columns, the row
+// groups' sums added in order; cols % 16 == 0 -- one thread per column walking all rows took 200 us for a 1024 x 1024 matrix)
+__global__ __launch_bounds__(256) void gemv_cols_kernel(const float* __restrict__ A, int lda, int rows, int cols, const float* __restrict__ x,
+                                                       const float* __restrict__ add, const float* __restrict__ scale,
+                                                       float* __restrict__ y) {
+    __shared__ float red[16][16];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + c;
+    float a = 0.f;
+#pragma unroll 8
+    for (int i = rg; i < rows; i += 16) a = __builtin_fmaf(A[(int64_t)i * lda + k], x[i], a);
+    red[rg][c] = a;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += red[r][threadIdx.x];
+        y[k] = sum + (add ? add[k] * (scale ? *scale : 1.0f) : 0.0f);
+    }
+}
+// C[i][j] += a[i] * b[j]
+__global__ __launch_bounds__(256) void rank1_add_kernel(float* __restrict__ C, int ldc, int rows, int cols, const float* __restrict__ a,
+                                                       const float* __restrict__ b) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)rows * cols) return;
+    const int i = (int)(id / cols), j = (int)(id - (int64_t)i * cols);
+    C[(int64_t)i * ldc + j] = __builtin_fmaf(a[i], b[j], C[(int64_t)i * ldc + j]);
+}
+// out[i * ldo] = sum_k value(lines[i][k]) u[k] + c[0]   -- skinny_heads_kernel<1> for an activation that exists as lines only (the value of
+// a line entry is hi + lo, exact in fp32); a wave per row, two rows per pass, u in LDS.  n % 512 == 0.
+__global__ __launch_bounds__(256) void aux_lines_kernel(const char* __restrict__ lines, int64_t m, int n, const float* __restrict__ u,
+                                                       const float* __restrict__ c, float* __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) float ul[4096];
+    for (int idx = threadIdx.x; idx < n; idx += 256) ul[idx] = u[idx];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    auto dot = [&](int64_t i) {
+        float a = 0.f;
+        for (int g = lane; g < n / 8; g += 64) {   // 8-column group g of the row: 8 hi halves, 64 bytes further its 8 lo halves
+            const char* q = lines + i * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16;
+            const h8 hi = *(const h8*)q, lo = *(const h8*)(q + 64);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = __builtin_fmaf((float)hi[e] + (float)lo[e], ul[g * 8 + e], a);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+        return a;
+    };
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wv; i < m; i += 2 * stride) {
+        const int64_t i2 = i + stride;
+        const float a = dot(i);
+        const float a2 = i2 < m ? dot(i2) : 0.f;
+        if (lane == 0) {
+            out[i * ldo] = a + c[0];
+            if (i2 < m) out[i2 * ldo] = a2 + c[0];
+        }
+    }
+}
+// part[blockIdx.y][k] = sum over this workgroup's rows of s[i * lds] * value(lines[i][k])  -- skinny_dw_kernel<1> for an activation that
+// exists as lines only (v = daux^T a); thread = one 8-column group x a row group, two rows per trip; skinny_reduce_kernel adds the planes.
+__global__ __launch_bounds__(256) void dvec_lines_kernel(const float* __restrict__ s, int lds, const char* __restrict__ lines, int64_t m,
+                                                        int n, float* __restrict__ part) {
+    __shared__ float red[16][128];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int g = blockIdx.x * 16 + cg;                  // 8-column group of the row
+    const char* base = lines + (g >> 2) * 128 + (g & 3) * 16;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const int64_t step = (int64_t)gridDim.y * 16;
+    auto one = [&](const h8& hi, const h8& lo, float sv) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(sv, (float)hi[e] + (float)lo[e], acc[e]);
+    };
+    int64_t i = (int64_t)blockIdx.y * 16 + rg;
+    for (; i + step < m; i += 2 * step) {
+        const char* q0 = base + i * (int64_t)n * 4;
+        const char* q1 = base + (i + step) * (int64_t)n * 4;
+        const h8 h0 = *(const h8*)q0, l0 = *(const h8*)(q0 + 64), h1 = *(const h8*)q1, l1 = *(const h8*)(q1 + 64);
+        const float s0 = s[i * lds], s1 = s[(i + step) * lds];
+        one(h0, l0, s0);
+        one(h1, l1, s1);
+    }
+    if (i < m) {
+        const char* q0 = base + i * (int64_t)n * 4;
+        one(*(const h8*)q0, *(const h8*)(q0 + 64), s[i * lds]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rg][cg * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += red[r][threadIdx.x];
+        part[(int64_t)blockIdx.y * n + blockIdx.x * 128 + threadIdx.x] = a;
+    }
+}
+
 __global__ __launch_bounds__(256) void col_sum_to_float_kernel(const double* __restrict__ s, int n, float* __restrict__ out) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < n) out[j] = (float)s[j];

@@ -58,8 +58,10 @@ class HipTrainer:
         """Large-batch route (>= fast_rows rows) only.  1 (the default): the residual stream, the stages' inner activations and dz exist
         between kernels as fp16 hi+lo lines only (~22 significant bits, re-rounded once per stage; dz scaled by a bound of its column
         maxima) -- 1.5 ms faster per 65536-row step; the parity numbers of tests/test_gpu_train.py are for this layout.  0 / 2: those
-        tensors stay fp32 between kernels like the reference's (0 = transposed operand copies, 2 = reduction-major operands; same bits)."""
-        assert int(dw_layout) in (0, 1, 2)
+        tensors stay fp32 between kernels like the reference's (0 = transposed operand copies, 2 = reduction-major operands; same bits).
+        Round 6: layout 1 also runs w2 -> w3 as ONE Linear (three batch-sized GEMMs instead of six, include/monoloco_hip.h); 3 = layout 1
+        with the two Linears apart (the A/B reference)."""
+        assert int(dw_layout) in (0, 1, 2, 3)
         check(_lib.load().ml_trainer_set_tuning(self._h, 0, -1, int(dw_layout)), train=True)
 
     @property

@@ -335,8 +335,9 @@ def test_headline_batch_training_step_against_fp64_oracle(hip_lib, cuda_device):
     lines only, where the reference keeps fp32 tensors -- against the loop body of monoloco/train/trainer.py:150-161 with
     train/losses.py:59-131 restated in fp64 (oracle/train_oracle.py): the loss values, every train-mode output row and every
     gradient tensor; next to it the SAME oracle in fp32 (= the reference's own arithmetic), so that every bar reads "as close to
-    exact as the reference itself, times a stated factor".  Then layouts 0 and 2 (fp32 tensors between kernels) on the same batch:
-    the line format must not move anything beyond ReLU-flip class."""
+    exact as the reference itself, times a stated factor".  Then layouts 0 and 2 (fp32 tensors between kernels) and 3 (w2 and w3 as two
+    Linears: layout 1 runs them as one, round 6) on the same batch: neither the line format nor the merged pair may move anything beyond
+    ReLU-flip class."""
     from monoloco_amd.train import HipTrainer
     from oracle.train_oracle import OracleTrainer
     rows, hidden = 65536, 1024
@@ -344,7 +345,7 @@ def test_headline_batch_training_step_against_fp64_oracle(hip_lib, cuda_device):
     sd0 = {k: torch.tensor(v) for k, v in synth.make_state_dict(43, 34, 9, hidden).items()}
     names = ['loss', 'd', 'x', 'y', 'h', 'w', 'l', 'ori']
     got = {}
-    for layout in (1, 0, 2):
+    for layout in (1, 0, 2, 3):   # (3: layout 1 with w2 and w3 as two Linears -- rounds 4-5; 1 runs the pair as ONE Linear since round 6)
         tr = HipTrainer(sd0, p_dropout=0.0, lr=0.001, device=cuda_device, dw_layout=layout)
         res, out = tr.step(x, y, update=False, want_outputs=True)
         assert tr.last_route == 'fast'
@@ -389,7 +390,7 @@ def test_headline_batch_training_step_against_fp64_oracle(hip_lib, cuda_device):
         assert mx <= max(3.0 * mx32, 3e-3), (k, mx, mx32)
         assert rms <= 4.0 * max(rms32, 2.5e-5), (k, rms, rms32)
     # the fp32-between-kernels layouts on the same batch: same losses and outputs to fp32 class, gradients to ReLU-flip class
-    for layout in (0, 2):
+    for layout in (0, 2, 3):
         res_b, out_b, g_b = got[layout]
         for n in names:
             assert abs(res[n] - res_b[n]) <= 2e-5 * max(1.0, abs(res[n])), (layout, n, res[n], res_b[n])
