@@ -663,7 +663,8 @@ def extras(args, dev, sd, eng, kps, conf, kinv, kk, main_ms, main_out=None):
                          "dropout 0.2; fp32 tensors.  Below 4096 rows the mid route (monoloco_amd/csrc/train_mid.h): every GEMM "
                          "on the exact fp32 MFMA reading the row-major tensors as they lie (launch list: profiles/r06_train_kernel_stats_rows331.txt) -> fraction of "
                          "the 157 TF fp32-MFMA peak.  From 4096 rows the hidden-layer GEMMs run on the 3-product fp16 MFMA "
-                         "kernel (fp32-class accuracy): fraction of the 833 TF (2500 / 3) a 3-product scheme can reach"}
+                         "kernel (fp32-class accuracy), w2 -> w3 as ONE Linear (round 6: 21 batch-sized GEMMs instead of 24; the algorithmic "
+                         "FLOP count below stays the reference's 24): fraction of the 833 TF (2500 / 3) a 3-product scheme can reach"}
         sd_tr = {k: torch.tensor(v) for k, v in synth.make_state_dict(31, 34, 9, 1024).items()}
         for tag, rows in (("fixture_331", 331), ("batch_512", 512), ("batch_65536", 65536)):
             tr = HipTrainer(sd_tr, p_dropout=0.2, lr=0.001, device=dev)
