@@ -98,6 +98,7 @@ struct ml_trainer {
     // round 6, large-batch route: w2 -> w3 as ONE Linear (train_kernels.h "w2 -> w3 pair"): W3 W2 and W3 b2 + b3 (packed as Linear slot
     // 2S + 2), u = W2^T w_aux, c = w_aux . b2 + b_aux, v = daux^T a_S, and the H x H scratch the weight gradients go through
     int merge23 = 1;
+    int head_in_bwd = 1;   // ... and b3's backward passes form dy3 = dout . w_fin themselves (0: skinny_out_kernel writes it; MONOLOCO_TRAIN_HEAD_IN_BWD)
     float *d_w32 = nullptr, *d_b32 = nullptr, *d_u23 = nullptr, *d_c23 = nullptr, *d_v23 = nullptr, *d_m23 = nullptr;
     int n_cu = 256;
     // AutoTuneMultiTaskLoss (reference losses.py:17-43, trainer.py:95-96): one learnable log_sigma per task, optimised by
@@ -292,9 +293,10 @@ bool skinny_heads(ml_trainer* t, hipStream_t st, const float* x, int64_t m, cons
     int64_t g = (m + 3) / 4;
     if (g > 2048) g = 2048;
     const dim3 grid((unsigned)g), block(256);
-    if (nc == 1) hipLaunchKernelGGL(mlt::skinny_heads_kernel<1>, grid, block, 0, st, x, m, t->H, w, b, out, ldo);
-    else if (nc == 8) hipLaunchKernelGGL(mlt::skinny_heads_kernel<8>, grid, block, 0, st, x, m, t->H, w, b, out, ldo);
-    else if (nc == 9) hipLaunchKernelGGL(mlt::skinny_heads_kernel<9>, grid, block, 0, st, x, m, t->H, w, b, out, ldo);
+    const size_t lds = (size_t)nc * t->H * 4;   // (<= 61440: no attribute needed)
+    if (nc == 1) hipLaunchKernelGGL(mlt::skinny_heads_kernel<1>, grid, block, lds, st, x, m, t->H, w, b, out, ldo);
+    else if (nc == 8) hipLaunchKernelGGL(mlt::skinny_heads_kernel<8>, grid, block, lds, st, x, m, t->H, w, b, out, ldo);
+    else if (nc == 9) hipLaunchKernelGGL(mlt::skinny_heads_kernel<9>, grid, block, lds, st, x, m, t->H, w, b, out, ldo);
     else return false;
     return hipGetLastError() == hipSuccess;   // (a failed launch sends the caller to the generic GEMM, which reports its own errors)
 }
@@ -308,6 +310,11 @@ struct Block {  // Linear + BatchNorm + ReLU + Dropout
     float* z = nullptr;        // pre-BN (m x H)
     float* y = nullptr;        // output (m x H) (residual already added if any)
     uint32_t site;
+    // round 6, the block right under the w_fin head on the large-batch route: its incoming gradient dy = hs . hw is formed inside the two
+    // backward passes (bwd_stats_kernel<NHG>) instead of being written by skinny_out_kernel and read back twice
+    const float* hs = nullptr;
+    int ldh = 0, nh = 0;
+    const float* hw = nullptr;
 };
 
 // one launch of the inference path's dense kernel with the fp32 epilogue: out (m x H fp32) [+]= x_lines . w_lines^T + bias
@@ -524,17 +531,25 @@ int block_bwd(ml_trainer* t, hipStream_t st, Block& b, int64_t m, float* dout, f
         // the statistics pass collects the column maxima for
         const bool lines_only = slot >= 0 && t->dw_trans && t->lines_chain && b.x_lines;
         float* colmax = lines_only ? t->d_colmax + (size_t)slot * 2 * H : nullptr;
-        hipLaunchKernelGGL(mlt::bwd_stats_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, src, (const float*)b.z, m, H,
-                           (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
-                           (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, s_dy, s_dy + H, colmax);
+        const bool headg = lines_only && b.hs && (b.nh == 8 || b.nh == 9);
+#define ML_BWD_STATS(NHG) hipLaunchKernelGGL(mlt::bwd_stats_kernel<NHG>, dim3((H + 63) / 64, gy), dim3(256), 0, st, src, (const float*)b.z, m, H, \
+                           (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),                                   \
+                           (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, s_dy, s_dy + H, colmax, b.hs, b.ldh, b.hw)
+        if (headg && b.nh == 8) ML_BWD_STATS(8);
+        else if (headg) ML_BWD_STATS(9);
+        else ML_BWD_STATS(0);
+#undef ML_BWD_STATS
         if ((rc = next_red_slot(t, st))) return rc;
         double* s_dz = t->d_red;
-        if (lines_only)
-            hipLaunchKernelGGL(mlt::bn_bwd_lines_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, src, (const float*)b.z, m, H,
-                               (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
-                               (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, (const double*)s_dy,
-                               (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz, (const float*)colmax,
-                               t->wsc_base + 8 * slot, t->dzl);
+#define ML_BWD_LINES(NHG) hipLaunchKernelGGL(mlt::bn_bwd_lines_kernel<NHG>, dim3((H + 63) / 64, gy), dim3(256), 0, st, src, (const float*)b.z, m, H, \
+                               (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),                                  \
+                               (const float*)P(t, b.bn + ".bias"), t->p_drop, seed, b.site, (const double*)s_dy,                            \
+                               (const double*)(s_dy + H), G(t, b.bn + ".weight"), G(t, b.bn + ".bias"), s_dz, (const float*)colmax,        \
+                               t->wsc_base + 8 * slot, t->dzl, b.hs, b.ldh, b.hw)
+        if (lines_only && headg && b.nh == 8) ML_BWD_LINES(8);
+        else if (lines_only && headg) ML_BWD_LINES(9);
+        else if (lines_only) ML_BWD_LINES(0);
+#undef ML_BWD_LINES
         else
             hipLaunchKernelGGL(mlt::bn_bwd_fused_kernel, dim3((H + 63) / 64, gy), dim3(256), 0, st, dout, src, (const float*)b.z, m, H,
                                (const float*)mean, (const float*)inv, (const float*)P(t, b.bn + ".weight"),
@@ -1000,6 +1015,7 @@ int ml_trainer_create(int in_features, int hidden, int out_features, int num_sta
     if (!t) return tfail(ML_ERR_HIP, "out of host memory");
     t->in_f = in_features; t->H = hidden; t->C = out_features; t->S = num_stage;
     t->p_drop = p_dropout; t->lr0 = lr; t->gamma = sched_gamma; t->sched_step = sched_step; t->seed = seed;
+    if (const char* e = getenv("MONOLOCO_TRAIN_HEAD_IN_BWD")) t->head_in_bwd = atoi(e) ? 1 : 0;   // (the A/B switch of round 6's change)
     add_linear(t, "w1", hidden, in_features);
     add_bn(t, "batch_norm1", hidden);
     for (int s = 0; s < num_stage; ++s) {
@@ -1490,9 +1506,17 @@ int step_phases(ml_trainer* t, const float* x_dev, const float* labels_dev, int 
     if ((rc = col_stats(t, st, t->d_dout, nullptr, m, C))) return rc;
     col_sum_to_float(t, st, (const double*)t->d_red, C - 1, G(t, "w_fin.bias"));
     col_sum_to_float(t, st, (const double*)(t->d_red + (C - 1)), 1, G(t, "w_aux.bias"));
+    // (round 6: with the merged pair b3's backward passes are lines-only -- they form dy3 = dout . w_fin themselves, Block::hs)
+    const bool head_in_bwd = merged && (C - 1 == 8 || C - 1 == 9) && t->head_in_bwd;
+    if (head_in_bwd) {
+        b3.hs = t->d_dout;
+        b3.ldh = C;
+        b3.nh = C - 1;
+        b3.hw = P(t, "w_fin.weight");
+    }
     if (skinny) {
         if ((rc = skinny_dw(t, st, t->d_dout, C, C - 1, y3, m, G(t, "w_fin.weight"), 0))) return rc;
-        rc = skinny_out(t, st, t->d_dout, C, C - 1, P(t, "w_fin.weight"), H, 1, nullptr, gA, m, 0);
+        if (!head_in_bwd) rc = skinny_out(t, st, t->d_dout, C, C - 1, P(t, "w_fin.weight"), H, 1, nullptr, gA, m, 0);
     } else {
         if ((rc = linear_bwd_weight(t, st, t->d_dout, C, y3, H, G(t, "w_fin.weight"), (int)m, C - 1, H))) return rc;
         rc = linear_bwd_data(t, st, t->d_dout, C, P(t, "w_fin.weight"), gA, H, (int)m, C - 1, H, 0);  // dy3

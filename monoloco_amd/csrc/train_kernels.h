@@ -365,11 +365,30 @@ __device__ __forceinline__ void bwd_elem(float dout, float z, float mean, float 
 #define BWD_ROWS 2
 #endif
 // pass 1: s1[j] += sum_i dy[i][j], s2[j] += sum_i dy[i][j] * xhat[i][j]   (nothing written but the sums); n % 4 == 0
+// NHG (round 6; 0: dout is the (m, n) gradient): the block sits right under an output head -- its incoming gradient is dy = hs . hw (hs: the
+// loss gradient of the head's NHG outputs, row stride ldh; hw: the head's weights (NHG, n)) and is formed HERE, with skinny_out_kernel's very
+// fma chain (c = 0 .. NHG - 1 from zero: the same bits), instead of being written by that kernel and read back by both backward passes --
+// three crossings of the (m, n) matrix per step.
+template <int NHG>
+__device__ __forceinline__ f32x4 head_grad(const float* __restrict__ hs, int ldh, const f32x4 (&hw4)[NHG > 0 ? NHG : 1], int64_t i) {
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+    const float* sp = hs + i * ldh;
+#pragma unroll
+    for (int c = 0; c < NHG; ++c) {
+        const float sv = sp[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = __builtin_fmaf(sv, hw4[c][e], d[e]);
+    }
+    return d;
+}
+template <int NHG = 0>
 __global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict__ dout, const float* __restrict__ z, int64_t m,
                                                        int n, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float p_drop, uint32_t seed, uint32_t site, double* __restrict__ s1,
-                                                       double* __restrict__ s2, float* __restrict__ colmax = nullptr) {
+                                                       double* __restrict__ s2, float* __restrict__ colmax = nullptr,
+                                                       const float* __restrict__ hs = nullptr, int ldh = 0,
+                                                       const float* __restrict__ hw = nullptr) {
     __shared__ double r1[16][64], r2[16][64];
     const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int j0 = blockIdx.x * 64 + cg * 4;
@@ -391,19 +410,23 @@ __global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict_
                 mxh[e] = __builtin_fmaxf(mxh[e], __builtin_fabsf(xh));
             }
         };
+        f32x4 hw4[NHG > 0 ? NHG : 1];
+#pragma unroll
+        for (int c = 0; c < NHG; ++c) hw4[c] = *(const f32x4*)(hw + (int64_t)c * n + j0);
+        auto grad_in = [&](int64_t r) { return NHG > 0 ? head_grad<NHG>(hs, ldh, hw4, r) : *(const f32x4*)(dout + r * n + j0); };
         // BWD_ROWS rows per trip, all their loads requested before the first use (same rows in the same order: the same sums)
         int64_t i = (int64_t)blockIdx.y * 16 + rg;
         for (; i + (BWD_ROWS - 1) * step < m; i += BWD_ROWS * step) {
             f32x4 dd[BWD_ROWS], zv[BWD_ROWS];
 #pragma unroll
             for (int u = 0; u < BWD_ROWS; ++u) {
-                dd[u] = *(const f32x4*)(dout + (i + u * step) * n + j0);
+                dd[u] = grad_in(i + u * step);
                 zv[u] = *(const f32x4*)(z + (i + u * step) * n + j0);
             }
 #pragma unroll
             for (int u = 0; u < BWD_ROWS; ++u) one(dd[u], zv[u], i + u * step);
         }
-        for (; i < m; i += step) one(*(const f32x4*)(dout + i * n + j0), *(const f32x4*)(z + i * n + j0), i);
+        for (; i < m; i += step) one(grad_in(i), *(const f32x4*)(z + i * n + j0), i);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -718,6 +741,7 @@ __global__ __launch_bounds__(256) void grad_lines_kernel(const float* __restrict
 // evaluates the same bound over all n columns (L2-resident vectors): same scale everywhere, no extra launch; workgroup (0, 0)
 // publishes the descales (sc[4] = 2^-e x the weights' descale for dx, sc[5] = 2^-e for dW).  Same per-element arithmetic as
 // bn_bwd_fused_kernel (the fp32 dz is formed, then scaled by a power of two and split).
+template <int NHG = 0>
 __global__ __launch_bounds__(256) void bn_bwd_lines_kernel(const float* din, const float* __restrict__ z, int64_t m, int n,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -725,7 +749,9 @@ __global__ __launch_bounds__(256) void bn_bwd_lines_kernel(const float* din, con
                                                           const double* __restrict__ sdy, const double* __restrict__ sdyx,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           double* __restrict__ sdz, const float* __restrict__ colmax,
-                                                          float* __restrict__ sc, char* __restrict__ lines) {
+                                                          float* __restrict__ sc, char* __restrict__ lines,
+                                                          const float* __restrict__ hs = nullptr, int ldh = 0,
+                                                          const float* __restrict__ hw = nullptr) {
     __shared__ double r1[16][64];
     __shared__ float wmax[4];
     float bound = 0.f;
@@ -786,19 +812,23 @@ __global__ __launch_bounds__(256) void bn_bwd_lines_kernel(const float* din, con
             const u4 out = odd ? u4{s0, s1, lo2[0], lo2[1]} : u4{hi2[0], hi2[1], s0, s1};
             *(u4*)(lines + i * (int64_t)n * 4 + (g8 >> 2) * 128 + (g8 & 3) * 16 + (odd ? 64 : 0)) = out;
         };
+        f32x4 hw4[NHG > 0 ? NHG : 1];
+#pragma unroll
+        for (int c = 0; c < NHG; ++c) hw4[c] = *(const f32x4*)(hw + (int64_t)c * n + j0);
+        auto grad_in = [&](int64_t r) { return NHG > 0 ? head_grad<NHG>(hs, ldh, hw4, r) : *(const f32x4*)(din + r * n + j0); };
         // BWD_ROWS rows per trip, all their loads requested before the first use (bwd_stats_kernel's form: same rows, same order, same sums)
         int64_t i = (int64_t)blockIdx.y * 16 + rg;
         for (; i + (BWD_ROWS - 1) * step < m; i += BWD_ROWS * step) {
             f32x4 dd[BWD_ROWS], zv[BWD_ROWS];
 #pragma unroll
             for (int u = 0; u < BWD_ROWS; ++u) {
-                dd[u] = *(const f32x4*)(din + (i + u * step) * n + j0);
+                dd[u] = grad_in(i + u * step);
                 zv[u] = *(const f32x4*)(z + (i + u * step) * n + j0);
             }
 #pragma unroll
             for (int u = 0; u < BWD_ROWS; ++u) one(dd[u], zv[u], i + u * step);
         }
-        for (; i < m; i += step) one(*(const f32x4*)(din + i * n + j0), *(const f32x4*)(z + i * n + j0), i);
+        for (; i < m; i += step) one(grad_in(i), *(const f32x4*)(z + i * n + j0), i);
         if (blockIdx.y == 0 && rg == 0) {  // one thread per column publishes the parameter gradients
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1154,7 +1184,9 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restr
 template <int NC>
 __global__ __launch_bounds__(256) void skinny_heads_kernel(const float* __restrict__ x, int64_t m, int n, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out, int ldo) {
-    __shared__ __attribute__((aligned(16))) float wl[15360];
+    // (dynamic: NC * n floats -- a fixed 60 KiB array held a CU to two workgroups = 8 waves, and the w_fin head at 65536 x 1024 ran at
+    //  2.2 TB/s: 119 us; with its own 32 KiB five workgroups fit)
+    extern __shared__ __attribute__((aligned(16))) float wl[];
     for (int idx = threadIdx.x; idx < NC * n; idx += 256) wl[idx] = w[idx];
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
