@@ -1401,7 +1401,7 @@ int step_phases(ml_trainer* t, const float* x_dev, const float* labels_dev, int 
     const bool fast = route == 1;
     if (phases & PH_FWD) t->packed_all = false;
     // w2 -> w3 as one Linear (train_kernels.h): where every consumer of the residual stream reads lines and the heads run on the skinny kernels
-    const bool merged = fast && t->merge23 && t->dw_trans && t->lines_chain && skinny_ok(t, C - 1) && H % 512 == 0 && H <= 4096 && t->d_w32;
+    const bool merged = fast && t->merge23 && t->dw_trans && t->lines_chain && skinny_ok(t, C - 1) && H % 256 == 0 && H <= 4096 && t->d_w32;
     if (fast && (phases & PH_FWD)) {
         T_TRY(hipMemsetAsync(t->wsc_base, 0, (size_t)(2 * S + 3) * 32, st));
         T_TRY(hipMemsetAsync(t->d_colmax, 0, (size_t)(2 * S + 3) * 2 * H * sizeof(float), st));

@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(256) void rank1_add_kernel(float* __restrict__ C, i
     C[(int64_t)i * ldc + j] = __builtin_fmaf(a[i], b[j], C[(int64_t)i * ldc + j]);
 }
 // out[i * ldo] = sum_k value(lines[i][k]) u[k] + c[0]   -- skinny_heads_kernel<1> for an activation that exists as lines only (the value of
-// a line entry is hi + lo, exact in fp32); a wave per row, two rows per pass, u in LDS.  n % 512 == 0.
+// a line entry is hi + lo, exact in fp32); a wave per row, two rows per pass, u in LDS.  n % 8 == 0, n <= 4096.
 __global__ __launch_bounds__(256) void aux_lines_kernel(const char* __restrict__ lines, int64_t m, int n, const float* __restrict__ u,
                                                        const float* __restrict__ c, float* __restrict__ out, int ldo) {
     __shared__ __attribute__((aligned(16))) float ul[4096];
