@@ -1560,33 +1560,33 @@ int step_phases(ml_trainer* t, const float* x_dev, const float* labels_dev, int 
             hipLaunchKernelGGL(mlt::skinny_reduce_kernel, dim3(nblk(H)), dim3(256), 0, st, (const float*)t->d_splitk, (int)gy, 1, H, t->d_v23, 0);
             if ((rc = skinny_out(t, st, t->d_dout + (C - 1), C, 1, t->d_u23, H, 1, nullptr, gA, m, 1))) return rc;
         }
-    } else {
-    if ((rc = block_bwd(t, st, b3, m, gA, xhat, fast ? 2 * S + 1 : -1))) return rc;                              // gA = dz3
-    if (fast) rc = fast_linear_bwd_data(t, st, dzl, "w3", gB, m, 2 * S + 1, false);
-    else rc = linear_bwd_data(t, st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0);                          // gB = dy2
-    if (rc) return rc;
-    if (skinny) {
-        if ((rc = skinny_dw(t, st, t->d_dout + (C - 1), C, 1, y2, m, G(t, "w_aux.weight"), 0))) return rc;
-        rc = skinny_out(t, st, t->d_dout + (C - 1), C, 1, P(t, "w_aux.weight"), H, 1, nullptr, gB, m, 1);
-    } else {
-        if ((rc = linear_bwd_weight(t, st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H))) return rc;
-        rc = linear_bwd_data(t, st, t->d_dout + (C - 1), C, P(t, "w_aux.weight"), gB, H, (int)m, 1, H, 1);  // += daux (x) w_aux
+    } else {   // w2 and w3 as two Linears (every other route; dw_layout 3)
+        if ((rc = block_bwd(t, st, b3, m, gA, xhat, fast ? 2 * S + 1 : -1))) return rc;                              // gA = dz3
+        if (fast) rc = fast_linear_bwd_data(t, st, dzl, "w3", gB, m, 2 * S + 1, false);
+        else rc = linear_bwd_data(t, st, gA, H, P(t, "w3.weight"), gB, H, (int)m, H, H, 0);                          // gB = dy2
+        if (rc) return rc;
+        if (skinny) {
+            if ((rc = skinny_dw(t, st, t->d_dout + (C - 1), C, 1, y2, m, G(t, "w_aux.weight"), 0))) return rc;
+            rc = skinny_out(t, st, t->d_dout + (C - 1), C, 1, P(t, "w_aux.weight"), H, 1, nullptr, gB, m, 1);
+        } else {
+            if ((rc = linear_bwd_weight(t, st, t->d_dout + (C - 1), C, y2, H, G(t, "w_aux.weight"), (int)m, 1, H))) return rc;
+            rc = linear_bwd_data(t, st, t->d_dout + (C - 1), C, P(t, "w_aux.weight"), gB, H, (int)m, 1, H, 1);  // += daux (x) w_aux
+        }
+        if (rc) return rc;
+        // y2 = w2 a_S + b2
+        if ((rc = col_stats(t, st, gB, nullptr, m, H))) return rc;
+        col_sum_to_float(t, st, (const double*)t->d_red, H, G(t, "w2.bias"));
+        if (fast) {
+            hipLaunchKernelGGL(mlt::wmax_kernel, dim3(1024), dim3(256), 0, st, (const float*)gB, m * H, t->wsc_base + 8 * (2 * S) + 3);
+            if ((rc = fast_grad_lines(t, st, gB, m, 2 * S))) return rc;
+            if ((rc = fast_linear_bwd_weight(t, st, a[S], la(S), "w2", m, 2 * S))) return rc;
+            rc = fast_linear_bwd_data(t, st, dzl, "w2", gA, m, 2 * S, false);
+        } else {
+            if ((rc = linear_bwd_weight(t, st, gB, H, a[S], H, G(t, "w2.weight"), (int)m, H, H))) return rc;
+            rc = linear_bwd_data(t, st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0);                            // gA = da_S
+        }
+        if (rc) return rc;
     }
-    if (rc) return rc;
-    // y2 = w2 a_S + b2
-    if ((rc = col_stats(t, st, gB, nullptr, m, H))) return rc;
-    col_sum_to_float(t, st, (const double*)t->d_red, H, G(t, "w2.bias"));
-    if (fast) {
-        hipLaunchKernelGGL(mlt::wmax_kernel, dim3(1024), dim3(256), 0, st, (const float*)gB, m * H, t->wsc_base + 8 * (2 * S) + 3);
-        if ((rc = fast_grad_lines(t, st, gB, m, 2 * S))) return rc;
-        if ((rc = fast_linear_bwd_weight(t, st, a[S], la(S), "w2", m, 2 * S))) return rc;
-        rc = fast_linear_bwd_data(t, st, dzl, "w2", gA, m, 2 * S, false);
-    } else {
-        if ((rc = linear_bwd_weight(t, st, gB, H, a[S], H, G(t, "w2.weight"), (int)m, H, H))) return rc;
-        rc = linear_bwd_data(t, st, gB, H, P(t, "w2.weight"), gA, H, (int)m, H, H, 0);                            // gA = da_S
-    }
-    if (rc) return rc;
-    }   // (!merged)
     // residual stages, last to first:  a_{s+1} = a_s + B(A(a_s))
     for (int s = S - 1; s >= 0; --s) {
         // gB = dz_b from gA = d a_{s+1} (which stays: the skip connection adds to it below)
