@@ -35,7 +35,7 @@ class HipTrainer:
             self._h = h
             self.load_state_dict(state_dict)
         self.set_route(route, fast_rows)
-        if dw_layout is None:   # MONOLOCO_TRAIN_DW_LAYOUT=0|1|2 picks it without touching the caller (the reference's Trainer has no such argument)
+        if dw_layout is None:   # MONOLOCO_TRAIN_DW_LAYOUT=0|1|2|3 picks it without touching the caller (the reference's Trainer has no such argument)
             import os
             dw_layout = os.environ.get('MONOLOCO_TRAIN_DW_LAYOUT')
         if dw_layout is not None:
