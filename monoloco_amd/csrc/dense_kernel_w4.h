@@ -179,10 +179,14 @@ struct W4Frag {          // the fragments of one k32 step of one half (hi or lo)
 // CUs, 57 us per layer whatever the rows): same ring, same phases, same counted waits with 6 instead of 8 DMA instructions per
 // wave and phase (4 of 64 weight rows + 2 of 32 activation rows), 16 + 32 MFMAs per phase pair, 8 epilogue passes.  The X half of
 // a slot is half used.
-template <int NSPLIT, bool RELU, bool RES, int HEAD, bool TRANS = false, int NJ = 4>
+// RESNT (round 6, RES only): the residual tile is read with non-temporal loads -- for a residual matrix larger than the Infinity Cache
+// (65536 rows x 1024: 256 MiB), which is read once per launch, long after it was written: 2526 -> 2506 us per 65536-row forward; at 16384
+// rows, where the matrix is still cached when its reader comes by, the same loads cost 0.6 % (the host picks by size).
+template <int NSPLIT, bool RELU, bool RES, int HEAD, bool TRANS = false, int NJ = 4, bool RESNT = false>
 __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void dense_kernel_w4(DenseParams p) {
     __shared__ __attribute__((aligned(16))) char smem[W4_LDS];
     static_assert(!TRANS || HEAD == -3, "reduction-major operands: the split-K weight-gradient variant only");
+    static_assert(!RESNT || (RES && NJ == 4 && HEAD >= -1), "non-temporal residual loads: the full-size inference tile with a residual");
     static_assert(NJ == 4 || (NJ == 2 && !TRANS && HEAD >= -1), "half-size tile: inference layers only (plain / residual, fused w_aux, fused w_fin)");
     constexpr int BMT = 64 * NJ;   // rows (m) of a workgroup tile
     constexpr int NQ = 4 + NJ;     // fragment quarters = DMA instructions per wave and slot: 4 of W, NJ of X
@@ -631,7 +635,10 @@ __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 const char* src = p.res + tile_off;
                 const unsigned o = pass_off(pass) + st_off;
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) rq[RES ? pass : 0][qq] = *(const f32x4*)(src + (o + qq * row8));
+                for (int qq = 0; qq < 4; ++qq) {
+                    if (RESNT) rq[RES ? pass : 0][qq] = __builtin_nontemporal_load((const f32x4*)(src + (o + qq * row8)));
+                    else rq[RES ? pass : 0][qq] = *(const f32x4*)(src + (o + qq * row8));
+                }
             };
             constexpr int RDEPTH = 3;   // residual tiles in flight (deeper does not help: 8 = same time; the tile-wide burst is HBM-bound)
             if (RES) {

@@ -679,26 +679,33 @@ int launch_dense(const Tuning& tu, int precision, const mlk::DenseParams& p_in, 
     if (w4_runs(tu, p.K, head_nh)) {
 #define ML_W4(NS, RL, RS, HD) \
     hipLaunchKernelGGL((mlk::dense_kernel_w4<NS, RL, RS, HD>), dim3(grid), dim3(mlk::W4_THREADS), 0, st, p)
+#define ML_W4_NT(RL, RS, HD) \
+    hipLaunchKernelGGL((mlk::dense_kernel_w4<3, RL, RS, HD, false, 4, true>), dim3(grid), dim3(mlk::W4_THREADS), 0, st, p)
 #define ML_W4_NS(NS)                                              \
     do {                                                          \
         if (head_nh == -1) {                                      \
-            if (p.relu && p.res) ML_W4(NS, true, true, -1);       \
+            if (p.relu && p.res && res_nt && NS == 3) ML_W4_NT(true, true, -1); \
+            else if (p.relu && p.res) ML_W4(NS, true, true, -1);  \
             else if (!p.relu && !p.res) ML_W4(NS, false, false, -1); \
             else return fail(ML_ERR_STATE, "fused aux head: unsupported layer form"); \
         } else if (head_nh == 8) ML_W4(NS, true, false, 8);       \
         else if (head_nh == 9) ML_W4(NS, true, false, 9);         \
         else if (p.relu) {                                        \
-            if (p.res) ML_W4(NS, true, true, 0);                  \
+            if (p.res && res_nt && NS == 3) ML_W4_NT(true, true, 0); \
+            else if (p.res) ML_W4(NS, true, true, 0);             \
             else ML_W4(NS, true, false, 0);                       \
         } else {                                                  \
             if (p.res) ML_W4(NS, false, true, 0);                 \
             else ML_W4(NS, false, false, 0);                      \
         }                                                         \
     } while (0)
+        // a residual matrix larger than the Infinity Cache (65536 rows x 1024: 256 MiB) is read once, long after it was written: non-temporal
+        const bool res_nt = p.res && (size_t)p.M_pad * (size_t)p.N * 4 > ((size_t)192 << 20);
         if (precision == ML_PREC_F16X2) ML_W4_NS(3);
         else if (precision == ML_PREC_F16) ML_W4_NS(1);
         else ML_W4_NS(0);
 #undef ML_W4_NS
+#undef ML_W4_NT
 #undef ML_W4
         HIP_TRY(hipGetLastError());
         return ML_OK;

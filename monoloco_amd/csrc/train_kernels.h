@@ -9,6 +9,20 @@
 #include "rng.h"
 
 namespace mlt {
+// The (m, n) matrices of a large-batch step are read once per pass and not again before ~2 GB of other traffic has gone by: their loads are
+// NON-TEMPORAL (round 6; -DML_NT=0 builds the A/B reference: 65536-row step 11.66 -> 11.43 ms with them; non-temporal STORES of the lines
+// measured nothing, profiles/r06_ablation.md section 7).  ML_LDSV: the same for any vector type.
+#ifndef ML_NT
+#define ML_NT 1
+#endif
+#if ML_NT & 1
+#define ML_LDS4(p) __builtin_nontemporal_load((const f32x4*)(p))
+#define ML_LDSV(T, p) __builtin_nontemporal_load((const T*)(p))
+#else
+#define ML_LDS4(p) (*(const f32x4*)(p))
+#define ML_LDSV(T, p) (*(const T*)(p))
+#endif
+#define ML_STU4(p, v) (*(u4*)(p) = (v))
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -199,8 +213,8 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
     const int64_t step = (int64_t)gridDim.y * 16;
     if ((n & 3) == 0 && j0 + 3 < n) {
         for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += step) {
-            const f32x4 v = *(const f32x4*)(z + i * n + j0);
-            const f32x4 u = w2 ? *(const f32x4*)(w2 + i * n + j0) : v;
+            const f32x4 v = ML_LDS4(z + i * n + j0);
+            const f32x4 u = w2 ? ML_LDS4(w2 + i * n + j0) : v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 a[e] += (double)v[e];
@@ -413,7 +427,7 @@ __global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict_
         f32x4 hw4[NHG > 0 ? NHG : 1];
 #pragma unroll
         for (int c = 0; c < NHG; ++c) hw4[c] = *(const f32x4*)(hw + (int64_t)c * n + j0);
-        auto grad_in = [&](int64_t r) { return NHG > 0 ? head_grad<NHG>(hs, ldh, hw4, r) : *(const f32x4*)(dout + r * n + j0); };
+        auto grad_in = [&](int64_t r) { return NHG > 0 ? head_grad<NHG>(hs, ldh, hw4, r) : ML_LDS4(dout + r * n + j0); };
         // BWD_ROWS rows per trip, all their loads requested before the first use (same rows in the same order: the same sums)
         int64_t i = (int64_t)blockIdx.y * 16 + rg;
         for (; i + (BWD_ROWS - 1) * step < m; i += BWD_ROWS * step) {
@@ -421,7 +435,7 @@ __global__ __launch_bounds__(256) void bwd_stats_kernel(const float* __restrict_
 #pragma unroll
             for (int u = 0; u < BWD_ROWS; ++u) {
                 dd[u] = grad_in(i + u * step);
-                zv[u] = *(const f32x4*)(z + (i + u * step) * n + j0);
+                zv[u] = ML_LDS4(z + (i + u * step) * n + j0);
             }
 #pragma unroll
             for (int u = 0; u < BWD_ROWS; ++u) one(dd[u], zv[u], i + u * step);
@@ -500,8 +514,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(float* dout, const fl
             gg[e] = ga[e] * is[e] / (float)m;
         }
         for (int64_t i = (int64_t)blockIdx.y * 16 + rg; i < m; i += step) {
-            const f32x4 d = *(const f32x4*)(din + i * n + j0);
-            const f32x4 zz = *(const f32x4*)(z + i * n + j0);
+            const f32x4 d = ML_LDS4(din + i * n + j0);
+            const f32x4 zz = ML_LDS4(z + i * n + j0);
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -810,12 +824,12 @@ __global__ __launch_bounds__(256) void bn_bwd_lines_kernel(const float* din, con
             const unsigned s0 = __shfl_xor(odd ? hi2[0] : lo2[0], 1, 64), s1 = __shfl_xor(odd ? hi2[1] : lo2[1], 1, 64);
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             const u4 out = odd ? u4{s0, s1, lo2[0], lo2[1]} : u4{hi2[0], hi2[1], s0, s1};
-            *(u4*)(lines + i * (int64_t)n * 4 + (g8 >> 2) * 128 + (g8 & 3) * 16 + (odd ? 64 : 0)) = out;
+            ML_STU4(lines + i * (int64_t)n * 4 + (g8 >> 2) * 128 + (g8 & 3) * 16 + (odd ? 64 : 0), out);
         };
         f32x4 hw4[NHG > 0 ? NHG : 1];
 #pragma unroll
         for (int c = 0; c < NHG; ++c) hw4[c] = *(const f32x4*)(hw + (int64_t)c * n + j0);
-        auto grad_in = [&](int64_t r) { return NHG > 0 ? head_grad<NHG>(hs, ldh, hw4, r) : *(const f32x4*)(din + r * n + j0); };
+        auto grad_in = [&](int64_t r) { return NHG > 0 ? head_grad<NHG>(hs, ldh, hw4, r) : ML_LDS4(din + r * n + j0); };
         // BWD_ROWS rows per trip, all their loads requested before the first use (bwd_stats_kernel's form: same rows, same order, same sums)
         int64_t i = (int64_t)blockIdx.y * 16 + rg;
         for (; i + (BWD_ROWS - 1) * step < m; i += BWD_ROWS * step) {
@@ -823,7 +837,7 @@ __global__ __launch_bounds__(256) void bn_bwd_lines_kernel(const float* din, con
 #pragma unroll
             for (int u = 0; u < BWD_ROWS; ++u) {
                 dd[u] = grad_in(i + u * step);
-                zv[u] = *(const f32x4*)(z + (i + u * step) * n + j0);
+                zv[u] = ML_LDS4(z + (i + u * step) * n + j0);
             }
 #pragma unroll
             for (int u = 0; u < BWD_ROWS; ++u) one(dd[u], zv[u], i + u * step);
@@ -865,7 +879,7 @@ __global__ __launch_bounds__(256) void bn_relu_drop_lines_kernel(const float* __
     const int q = live ? (int)(id - i * qpr) : 0;
     const int j0 = q * 4;
     const int64_t base = i * n + j0;
-    f32x4 v = *(const f32x4*)(z + base);
+    f32x4 v = ML_LDS4(z + base);
     const f32x4 mu = *(const f32x4*)(mean + j0), is = *(const f32x4*)(invstd + j0);
     const f32x4 ga = *(const f32x4*)(gamma + j0), be = *(const f32x4*)(beta + j0);
 #pragma unroll
@@ -884,7 +898,7 @@ __global__ __launch_bounds__(256) void bn_relu_drop_lines_kernel(const float* __
         // a line entry is hi + lo, exact in fp32 (22 significant bits; the stream is re-rounded to that once per stage)
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         const char* rp = res_lines + i * (int64_t)n * 4 + (q >> 3) * 128 + ((q >> 1) & 3) * 16 + (q & 1) * 8;
-        const h4 rh = *(const h4*)rp, rl = *(const h4*)(rp + 64);
+        const h4 rh = ML_LDSV(h4, rp), rl = ML_LDSV(h4, rp + 64);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
     }
@@ -904,7 +918,7 @@ __global__ __launch_bounds__(256) void bn_relu_drop_lines_kernel(const float* __
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     const u4 out = odd ? u4{s0, s1, lo2[0], lo2[1]} : u4{hi2[0], hi2[1], s0, s1};
     const int g = q >> 1;   // 8-column group
-    if (live && lines) *(u4*)(lines + i * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16 + (odd ? 64 : 0)) = out;
+    if (live && lines) ML_STU4(lines + i * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16 + (odd ? 64 : 0), out);
 }
 
 // fp32 (m, n) -> TRANSPOSED lines [n][m_pad] (row j = column j of src over the batch, k32 blocks of 32 consecutive rows:
@@ -1091,7 +1105,7 @@ __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict_
             for (int q = 0; q < 4; ++q) {
                 const int64_t i = chunk * 64 + rg + 16 * q;
                 vn[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (chunk < nchunk && i < m) vn[q] = *(const f32x4*)(x + i * n + j0);
+                if (chunk < nchunk && i < m) vn[q] = ML_LDS4(x + i * n + j0);
             }
 #pragma unroll
             for (int q = 0; q < SPT; ++q) {
@@ -1199,9 +1213,9 @@ __global__ __launch_bounds__(256) void skinny_heads_kernel(const float* __restri
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] = acc2[c] = 0.f;
         for (int j = lane * 4; j < n; j += 256) {
-            const f32x4 v = *(const f32x4*)(x + i * n + j);
+            const f32x4 v = ML_LDS4(x + i * n + j);
             f32x4 v2 = {0.f, 0.f, 0.f, 0.f};
-            if (two) v2 = *(const f32x4*)(x + i2 * n + j);
+            if (two) v2 = ML_LDS4(x + i2 * n + j);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const f32x4 ww = *(const f32x4*)&wl[c * n + j];
@@ -1289,7 +1303,7 @@ __global__ __launch_bounds__(256) void aux_lines_kernel(const char* __restrict__
         float a = 0.f;
         for (int g = lane; g < n / 8; g += 64) {   // 8-column group g of the row: 8 hi halves, 64 bytes further its 8 lo halves
             const char* q = lines + i * (int64_t)n * 4 + (g >> 2) * 128 + (g & 3) * 16;
-            const h8 hi = *(const h8*)q, lo = *(const h8*)(q + 64);
+            const h8 hi = ML_LDSV(h8, q), lo = ML_LDSV(h8, q + 64);
 #pragma unroll
             for (int e = 0; e < 8; ++e) a = __builtin_fmaf((float)hi[e] + (float)lo[e], ul[g * 8 + e], a);
         }
@@ -1327,7 +1341,7 @@ __global__ __launch_bounds__(256) void dvec_lines_kernel(const float* __restrict
     for (; i + step < m; i += 2 * step) {
         const char* q0 = base + i * (int64_t)n * 4;
         const char* q1 = base + (i + step) * (int64_t)n * 4;
-        const h8 h0 = *(const h8*)q0, l0 = *(const h8*)(q0 + 64), h1 = *(const h8*)q1, l1 = *(const h8*)(q1 + 64);
+        const h8 h0 = ML_LDSV(h8, q0), l0 = ML_LDSV(h8, q0 + 64), h1 = ML_LDSV(h8, q1), l1 = ML_LDSV(h8, q1 + 64);
         const float s0 = s[i * lds], s1 = s[(i + step) * lds];
         one(h0, l0, s0);
         one(h1, l1, s1);

@@ -34,7 +34,7 @@ def _w4(reports):
 
 
 def _args(name):
-    a = re.match(r'dense_kernel_w4<(-?\d+), (\w+), (\w+), (-?\d+), (\w+), (\d+)>', name).groups()
+    a = re.match(r'dense_kernel_w4<(-?\d+), (\w+), (\w+), (-?\d+), (\w+), (\d+)(?:, \w+)?>', name).groups()   # (7th: non-temporal residual loads)
     return int(a[0]), a[1] == 'true', a[2] == 'true', int(a[3]), a[4] == 'true', int(a[5])
 
 
@@ -42,9 +42,12 @@ def test_every_w4_instantiation_is_found(reports):
     names = set(_w4(reports))
     assert len(names) >= 36, len(names)
     # the headline's six long-K layers, the half-size tile of the upper mid window, the training GEMMs (fp32 out, split-K, reduction-major)
-    for need in ('dense_kernel_w4<3, true, false, 0, false, 4>', 'dense_kernel_w4<3, true, true, -1, false, 4>',
-                 'dense_kernel_w4<3, true, false, 0, false, 2>', 'dense_kernel_w4<3, false, false, -2, false, 4>',
-                 'dense_kernel_w4<3, false, false, -3, true, 4>'):
+    # (7th template argument, round 6: non-temporal residual loads -- the two residual layers of a batch whose activations outgrow the
+    #  Infinity Cache)
+    for need in ('dense_kernel_w4<3, true, false, 0, false, 4, false>', 'dense_kernel_w4<3, true, true, -1, false, 4, false>',
+                 'dense_kernel_w4<3, true, true, 0, false, 4, true>', 'dense_kernel_w4<3, true, true, -1, false, 4, true>',
+                 'dense_kernel_w4<3, true, false, 0, false, 2, false>', 'dense_kernel_w4<3, false, false, -2, false, 4, false>',
+                 'dense_kernel_w4<3, false, false, -3, true, 4, false>'):
         assert need in names, need
 
 
@@ -141,5 +144,5 @@ def test_the_guard_bites(tmp_path):
     expectation must fail on it -- a guard that cannot fail guards nothing.  (One more ~20 s device-only compile of train.hip,
     the smaller unit.)"""
     rep = C.report('train', ('-DML_W4_ABL=4',), 'dense_kernel_w4')
-    loop = rep['dense_kernel_w4<3, false, false, -2, false, 4>']['loop']
+    loop = rep['dense_kernel_w4<3, false, false, -2, false, 4, false>']['loop']
     assert loop['mfma'] == 192 and loop.get('lds_dma', 0) == 0, loop
